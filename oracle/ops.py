@@ -1,0 +1,150 @@
+"""Oracle restatements of the op-library functions on the hot path
+(reference: /root/reference/models/submodule.py).  TEST INFRASTRUCTURE ONLY.
+
+All functions take/return CPU fp32 torch tensors in the reference's layouts
+(NCHW features, NCDHW volumes) and follow the reference's algorithm, including
+its per-disparity slice loop (this is what `bench.py` times as the CPU port).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _overlap(W, s):
+    """Left-image column range [lo, hi) whose partner column x - s is inside
+    the right image; the partner range is [lo - s, hi - s)."""
+    lo = min(max(s, 0), W)
+    hi = max(min(W + s, W), lo)
+    return lo, hi
+
+
+def groupwise_correlation(fea1, fea2, num_groups):
+    """models/submodule.py:190-196 -- mean over each group's channels of the
+    element-wise product; [B,C,H,W]^2 -> [B,G,H,W]."""
+    B, C, H, W = fea1.shape
+    assert C % num_groups == 0
+    prod = (fea1 * fea2).reshape(B, num_groups, C // num_groups, H, W)
+    out = prod.mean(dim=2)
+    assert out.shape == (B, num_groups, H, W)
+    return out
+
+
+def groupwise_correlation_norm(fea1, fea2, num_groups):
+    """models/submodule.py:213-221 -- as above, but each group vector is first
+    divided by (its L2 norm over the group's channels + 1e-5), per pixel."""
+    B, C, H, W = fea1.shape
+    assert C % num_groups == 0
+    cg = C // num_groups
+    a = fea1.reshape(B, num_groups, cg, H, W)
+    b = fea2.reshape(B, num_groups, cg, H, W)
+    a = a / (torch.linalg.vector_norm(a, 2, dim=2, keepdim=True) + 1e-05)
+    b = b / (torch.linalg.vector_norm(b, 2, dim=2, keepdim=True) + 1e-05)
+    out = (a * b).mean(dim=2)
+    assert out.shape == (B, num_groups, H, W)
+    return out
+
+
+def _gwc_volume(ref, tgt, maxdisp, num_groups, corr):
+    B, C, H, W = ref.shape
+    vol = ref.new_zeros([B, num_groups, 2 * maxdisp, H, W])
+    for s in range(-maxdisp, maxdisp):          # signed disparity, models/submodule.py:201
+        lo, hi = _overlap(W, s)
+        if hi > lo:
+            vol[:, :, s + maxdisp, :, lo:hi] = corr(ref[:, :, :, lo:hi], tgt[:, :, :, lo - s:hi - s], num_groups)
+    return vol.contiguous()
+
+
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """models/submodule.py:198-211: V[b,g,d+m,y,x] = mean_c ref[b,g,c,y,x] *
+    tgt[b,g,c,y,x-d] for d in [-m, m), zero where x-d leaves the image."""
+    return _gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, groupwise_correlation)
+
+
+def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """models/submodule.py:224-238 (live at models/SemStereo.py:273)."""
+    return _gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, groupwise_correlation_norm)
+
+
+def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
+    """models/submodule.py:173-187: channels [0,C) = left feature, [C,2C) =
+    right feature shifted by d; BOTH halves are zero where x-d is outside."""
+    B, C, H, W = refimg_fea.shape
+    vol = refimg_fea.new_zeros([B, 2 * C, 2 * maxdisp, H, W])
+    for s in range(-maxdisp, maxdisp):
+        lo, hi = _overlap(W, s)
+        if hi > lo:
+            vol[:, :C, s + maxdisp, :, lo:hi] = refimg_fea[:, :, :, lo:hi]
+            vol[:, C:, s + maxdisp, :, lo:hi] = targetimg_fea[:, :, :, lo - s:hi - s]
+    return vol.contiguous()
+
+
+def disparity_regression(x, maxdisp):
+    """models/submodule.py:164-170: sum_d x[b,d,y,x] * (d - m), d in [0, 2m)."""
+    assert x.dim() == 4
+    values = torch.arange(-maxdisp, maxdisp, dtype=x.dtype, device=x.device).reshape(1, 2 * maxdisp, 1, 1)
+    return (x * values).sum(dim=1)
+
+
+def disparity_variance(x, maxdisp, disparity):
+    """models/submodule.py:257-263: sum_d x * ((d - m) - disparity)^2, keepdim."""
+    assert x.dim() == 4
+    values = torch.arange(-maxdisp, maxdisp, dtype=x.dtype, device=x.device).reshape(1, 2 * maxdisp, 1, 1)
+    return (x * (values - disparity) ** 2).sum(dim=1, keepdim=True)
+
+
+def SpatialTransformer_grid(x, y, disp_range_samples):
+    """models/submodule.py:265-288: bilinear resampling of the right map `y` at
+    column w - disp[b,j,h,w] (zeros padding, align_corners=True; coordinates go
+    through the normalise/unnormalise round trip) and the left map `x`
+    broadcast over the sample axis.  Returns (y_warped, x_warped), [B,C,nd,H,W]."""
+    B, C, H, W = y.shape
+    nd = disp_range_samples.shape[1]
+    rows = torch.arange(H, dtype=x.dtype, device=x.device).reshape(1, 1, H, 1).expand(B, nd, H, W)
+    cols = torch.arange(W, dtype=x.dtype, device=x.device).reshape(1, 1, 1, W).expand(B, nd, H, W)
+    gx = (cols - disp_range_samples) / ((W - 1.0) / 2.0) - 1.0
+    gy = rows / ((H - 1.0) / 2.0) - 1.0
+    grid = torch.stack([gx, gy], dim=4).reshape(B, nd * H, W, 2)
+    y_w = F.grid_sample(y, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    y_w = y_w.reshape(B, C, nd, H, W)
+    x_w = x.unsqueeze(2).repeat(1, 1, nd, 1, 1)
+    return y_w, x_w
+
+
+def regression_topk(cost, disparity_samples, k):
+    """models/submodule.py:434-442: take the k largest costs per pixel
+    (descending sort order), softmax over those k, expectation of the matching
+    disparity candidates -> [B,1,H,W].  Ties: lower index first (the reference's
+    sort is unstable, i.e. implementation-defined there)."""
+    _, order = cost.sort(dim=1, descending=True, stable=True)
+    pick = order[:, :k]
+    w = F.softmax(torch.gather(cost, 1, pick), dim=1)
+    cand = torch.gather(disparity_samples, 1, pick)
+    return (cand * w).sum(dim=1, keepdim=True)
+
+
+# 3x3 neighbourhood taps of Propagation / Propagation_prob
+# (models/submodule.py:295-300, 367-372): (dy, dx) of the source pixel per output channel.
+_PROP_TAPS = ((-1, -1), (0, 0), (1, 1), (1, -1), (-1, 1))
+
+
+def propagation(samples):
+    """models/submodule.py:290-307 (Propagation.forward): [B,1,H,W] -> [B,5,H,W],
+    channel k = the input at the k-th diagonal neighbour, replicate-padded."""
+    B, one, H, W = samples.shape
+    assert one == 1
+    p = F.pad(samples, (1, 1, 1, 1), mode="replicate")
+    return torch.cat([p[:, :, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in _PROP_TAPS], dim=1)
+
+
+def propagation_prob(volume):
+    """models/submodule.py:361-377 (Propagation_prob.forward): [B,1,D,H,W] ->
+    [B,5,D,H,W], same five taps applied in every disparity plane."""
+    B, one, D, H, W = volume.shape
+    assert one == 1
+    p = F.pad(volume, (1, 1, 1, 1, 0, 0), mode="replicate")
+    return torch.cat([p[:, :, :, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in _PROP_TAPS], dim=1)
+
+
+def epe(d_est, d_ref):
+    """EPE-vs-ref: mean |d_est - d_ref| over all pixels (utils/metrics.py:55-59
+    with the reference output as ground truth and an all-true mask)."""
+    return (d_est.double() - d_ref.double()).abs().mean().item()

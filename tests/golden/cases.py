@@ -1,0 +1,135 @@
+"""Case table shared by `make_golden.py` (which runs the REFERENCE on these
+inputs, in the build container only) and by the tests (which run the oracle
+and the HIP path on the same inputs, anywhere).  Inputs are closed-form
+(`oracle.detdata`), so only reference OUTPUTS are stored in the .npz fixtures.
+"""
+import numpy as np
+import torch
+
+from oracle import detdata as dd
+
+# name -> (B, C, H, W, maxdisp, groups)
+GWC = {
+    "odd":      (2, 16, 5, 13, 4, 4),      # odd W, Cg = 4
+    "cg8_w8":   (1, 24, 3, 8, 3, 3),       # Cg = 8, W % 4 == 0
+    "m_gt_w":   (1, 8, 2, 5, 7, 2),        # maxdisp > W  (whole planes stay zero)
+    "g1":       (1, 6, 2, 9, 2, 1),        # a single group
+    "live":     (1, 256, 4, 16, 4, 32),    # the live channel/group split (models/SemStereo.py:273)
+    "cg16":     (1, 32, 3, 12, 5, 2),      # Cg = 16
+}
+# name -> (B, C, H, W, maxdisp)
+CONCAT = {
+    "odd":    (2, 3, 4, 11, 3),
+    "m_gt_w": (1, 2, 2, 4, 6),
+    "c32":    (1, 32, 3, 16, 4),
+}
+# name -> (B, maxdisp, H, W)
+REGRESSION = {
+    "small": (2, 3, 5, 7),
+    "m16":   (1, 16, 4, 12),
+}
+# name -> (B, C, H, W, nd, kind)
+WARP = {
+    "frac":    (2, 3, 5, 9, 4, "frac"),      # fractional disparities, some leaving the image
+    "int24":   (1, 4, 6, 16, 8, "int"),      # sorted distinct integers (the :316 call)
+    "prop5":   (1, 8, 4, 12, 5, "frac"),     # 5 samples (the :291 call)
+    "h1":      (1, 2, 1, 7, 3, "frac"),      # H == 1 (degenerate row normalisation)
+}
+# name -> (B, nd, H, W, k)
+TOPK = {
+    "k2": (2, 24, 4, 9, 2),
+    "k3": (1, 7, 3, 5, 3),
+    "k1": (1, 5, 2, 4, 1),
+}
+# name -> (B, H, W) for Propagation ; (B, D, H, W) for Propagation_prob
+PROP = {"a": (2, 4, 7), "one_row": (1, 1, 5)}
+PROP_PROB = {"a": (1, 3, 4, 6)}
+
+
+def gwc_inputs(name):
+    B, C, H, W, m, G = GWC[name]
+    s = 100 + sorted(GWC).index(name) * 2
+    return dd.t_normalish((B, C, H, W), s), dd.t_normalish((B, C, H, W), s + 1), m, G
+
+
+def concat_inputs(name):
+    B, C, H, W, m = CONCAT[name]
+    s = 200 + sorted(CONCAT).index(name) * 2
+    return dd.t_normalish((B, C, H, W), s), dd.t_normalish((B, C, H, W), s + 1), m
+
+
+def regression_inputs(name):
+    B, m, H, W = REGRESSION[name]
+    s = 300 + sorted(REGRESSION).index(name) * 2
+    prob = torch.softmax(dd.t_normalish((B, 2 * m, H, W), s) * 2.0, dim=1)
+    disp = dd.t_uniform((B, 1, H, W), s + 1, -m, m)
+    return prob, m, disp
+
+
+def warp_inputs(name):
+    B, C, H, W, nd, kind = WARP[name]
+    s = 400 + sorted(WARP).index(name) * 3
+    x = dd.t_normalish((B, C, H, W), s)
+    y = dd.t_normalish((B, C, H, W), s + 1)
+    if kind == "int":
+        disp = dd.distinct_sorted_candidates(B, nd, H, W, max(nd, W // 2), s + 2)
+    else:
+        disp = dd.t_uniform((B, nd, H, W), s + 2, -0.75 * W, 0.75 * W)
+    return x, y, disp
+
+
+def topk_inputs(name):
+    B, nd, H, W, k = TOPK[name]
+    s = 500 + sorted(TOPK).index(name) * 2
+    cost = dd.t_normalish((B, nd, H, W), s) * 3.0
+    cand = dd.distinct_sorted_candidates(B, nd, H, W, 32, s + 1)
+    return cost, cand, k
+
+
+def prop_inputs(name):
+    B, H, W = PROP[name]
+    return dd.t_normalish((B, 1, H, W), 600 + sorted(PROP).index(name))
+
+
+def prop_prob_inputs(name):
+    B, D, H, W = PROP_PROB[name]
+    return dd.t_normalish((B, 1, D, H, W), 650 + sorted(PROP_PROB).index(name))
+
+
+# ---- 3-D stack module cases: (module kind, input shape) -------------------
+# Parameters come from oracle.hot_segment.deterministic_params(); inputs closed-form.
+STACK = {
+    "hourglass_att": ("hourglass_att", (1, 32, 16, 8, 12), (4, 4, 4)),
+    "hourglass":     ("hourglass", (1, 32, 24, 8, 8), (6, 4, 4)),
+    "classif":       ("classif", (1, 32, 4, 6, 10), None),
+    "concat_stem":   ("concat_stem", (1, 64, 3, 5, 8), None),
+    "attn_pad":      ("hourglass_att.attention_block", (1, 128, 4, 6, 7), (4, 4, 4)),  # H, W both padded
+    "attn_pad_w":    ("hourglass_att.attention_block", (1, 128, 4, 8, 6), (4, 4, 4)),  # only W padded (mask quirk)
+}
+
+
+def stack_input(name):
+    kind, shape, _ = STACK[name]
+    return dd.t_normalish(shape, 700 + sorted(STACK).index(name))
+
+
+# ---- hot segment (features -> pred) ----------------------------------------
+# name -> (B, H, W, maxdisp): image size; features are H/4, W/4 and H/8, W/8.
+SEGMENT = {
+    "s128": (1, 128, 128, 64),
+    "s96x160_b2": (2, 96, 160, 64),
+}
+
+
+def segment_inputs(name):
+    B, H, W, maxdisp = SEGMENT[name]
+    s = 800 + sorted(SEGMENT).index(name) * 4
+    fl8, fr8 = dd.stereo_features(B, 256, H // 8, W // 8, s, max_shift=3)
+    fl4, fr4 = dd.stereo_features(B, 128, H // 4, W // 4, s + 1, max_shift=6)
+    return fl4, fr4, fl8, fr8, maxdisp
+
+
+def sample_index(numel, n=64, salt=0):
+    """n deterministic flat indices into a tensor of `numel` elements."""
+    u = dd.uniform((n,), 9000 + salt, 0.0, 1.0).astype(np.float64)
+    return np.minimum((u * numel).astype(np.int64), numel - 1)

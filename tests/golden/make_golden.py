@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by running the REFERENCE itself.
+
+Runs ONLY in the build container, where /root/reference is mounted read-only:
+it imports the reference's Python by path (nothing is copied), feeds it the
+closed-form inputs of `cases.py`, and stores the reference's OUTPUTS as small
+.npz files next to this script.  The GPU box has no /root/reference; tests
+there only read the committed .npz files.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from golden import cases  # noqa: E402
+from oracle import hot_segment as oseg  # noqa: E402  (parameter table + deterministic fill only)
+
+REF = "/root/reference"
+warnings.filterwarnings("ignore")
+torch.set_num_threads(8)
+
+
+def load_ref_oplib():
+    spec = importlib.util.spec_from_file_location("ref_submodule", os.path.join(REF, "models/submodule.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_ref_model_module():
+    """Import models.SemStereo without models/__init__.py (needs torchvision)
+    and with a stand-in `timm` whose backbone has the attribute surface
+    Feature() reads (models/SemStereo.py:37-45).  The backbone is never run:
+    the generator replays closed-form feature maps instead."""
+    class _Backbone(nn.Module):
+        def __init__(self):
+            super().__init__()
+            mk = lambda i, o, s: nn.Sequential(nn.Conv2d(i, o, 3, s, 1, bias=False))
+            self.stem = mk(3, 32, 2)
+            self.stages_0 = nn.Sequential(mk(32, 64, 1)); self.stages_1 = nn.Sequential(mk(64, 128, 2))
+            self.stages_2 = nn.Sequential(mk(128, 256, 2)); self.stages_3 = nn.Sequential(mk(256, 384, 2))
+            self.stages_4 = nn.Sequential(mk(384, 512, 2))
+    timm = types.ModuleType("timm")
+    timm.create_model = lambda *a, **k: _Backbone()
+    sys.modules["timm"] = timm
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(REF, "models")]
+    sys.modules["models"] = pkg
+    sys.path.insert(0, REF)
+    import models.SemStereo as ms
+    return ms
+
+
+class Replay(nn.Module):
+    """Stands in for an out-of-scope module: returns queued tensors in call order."""
+    def __init__(self, *items):
+        super().__init__()
+        self.items = list(items)
+
+    def forward(self, *a, **k):
+        return self.items.pop(0)
+
+
+def f32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def summary(t, salt):
+    """checksum record for a big tensor: sum, sum of squares, 64 sampled voxels."""
+    a = t.detach().double().reshape(-1)
+    idx = cases.sample_index(a.numel(), 64, salt)
+    return np.concatenate([[a.sum().item(), (a * a).sum().item()], a[idx].numpy()]).astype(np.float64)
+
+
+def gen_ops(ref):
+    out = {}
+    for n in cases.GWC:
+        a, b, m, G = cases.gwc_inputs(n)
+        out[f"gwc/{n}"] = f32(ref.build_gwc_volume(a, b, m, G))
+        out[f"gwc_norm/{n}"] = f32(ref.build_gwc_volume_norm(a, b, m, G))
+        out[f"gcorr/{n}"] = f32(ref.groupwise_correlation(a, b, G))
+        out[f"gcorr_norm/{n}"] = f32(ref.groupwise_correlation_norm(a, b, G))
+    for n in cases.CONCAT:
+        a, b, m = cases.concat_inputs(n)
+        out[f"concat/{n}"] = f32(ref.build_concat_volume(a, b, m))
+    for n in cases.REGRESSION:
+        p, m, d = cases.regression_inputs(n)
+        out[f"regression/{n}"] = f32(ref.disparity_regression(p, m))
+        out[f"variance/{n}"] = f32(ref.disparity_variance(p, m, d))
+    for n in cases.WARP:
+        x, y, d = cases.warp_inputs(n)
+        yw, xw = ref.SpatialTransformer_grid(x, y, d)
+        out[f"warp_y/{n}"] = f32(yw)
+        out[f"warp_x/{n}"] = f32(xw)
+    for n in cases.TOPK:
+        c, s, k = cases.topk_inputs(n)
+        out[f"topk/{n}"] = f32(ref.regression_topk(c, s, k))
+    for n in cases.PROP:
+        out[f"prop/{n}"] = f32(ref.Propagation()(cases.prop_inputs(n)))
+    for n in cases.PROP_PROB:
+        out[f"prop_prob/{n}"] = f32(ref.Propagation_prob()(cases.prop_prob_inputs(n)))
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
+    print("ops.npz:", len(out), "arrays")
+
+
+def build_ref_net(ms, maxdisp):
+    net = ms.SemStereo(maxdisp, False, True, True, 6).eval()
+    P = oseg.deterministic_params()
+    res = net.load_state_dict(P, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys          # every oracle key name exists in the reference
+    ours = set(P)
+    for k in res.missing_keys:                                   # and we cover every key of the owned modules
+        owned = k.split(".")[0] in {"patch", "corr_feature_att_8", "hourglass_att", "classif_att_", "gamma", "beta",
+                                    "concat_feature", "concat_stem", "concat_feature_att_4", "hourglass", "classif"}
+        assert (not owned) or k.endswith("num_batches_tracked"), k
+    return net, P
+
+
+def gen_stack(ms):
+    net, P = build_ref_net(ms, 64)
+    out = {}
+    with torch.no_grad():
+        for n, (kind, shape, _) in cases.STACK.items():
+            mod = net
+            for part in kind.split("."):
+                mod = getattr(mod, part)
+            y = mod(cases.stack_input(n))
+            out[f"stack/{n}"] = f32(y)
+    np.savez_compressed(os.path.join(HERE, "stack.npz"), **out)
+    print("stack.npz:", {k: v.shape for k, v in out.items()})
+
+
+def gen_segment(ms):
+    out = {}
+    for n, (B, H, W, maxdisp) in cases.SEGMENT.items():
+        net, P = build_ref_net(ms, maxdisp)
+        fl4, fr4, fl8, fr8, _ = cases.segment_inputs(n)
+        z = lambda c, s: torch.zeros(B, c, H // s, W // s)
+        # out-of-scope producers replaced by replays of closed-form tensors
+        net.feature = Replay([z(1, 2)] * 5, [z(1, 2)] * 5)
+        net.feature_up = Replay(([z(1, 2)] * 5, [z(1, 2)] * 5))
+        net.head_l = Replay(torch.zeros(B, 6, H, W)); net.head_r = Replay(torch.zeros(B, 6, H, W))
+        net.chal_0 = Replay(z(64, 2)); net.chal_3 = Replay(z(384, 16)); net.chal_4 = Replay(z(256, 32))
+        net.chal_1 = Replay(fl4, fr4)
+        net.chal_2 = Replay(fl8, fr8)
+        cap = {}
+        originals = {}
+        for name in ("build_gwc_volume_norm", "regression_topk", "disparity_regression"):
+            orig = originals[name] = getattr(ms, name)
+            def wrap(*a, _o=orig, _n=name, **k):
+                r = _o(*a, **k)
+                cap.setdefault(_n, []).append((a, r))
+                return r
+            setattr(ms, name, wrap)
+        hooks = []
+        for name in ("patch", "hourglass_att", "classif_att_", "concat_stem", "hourglass", "classif"):
+            hooks.append(getattr(net, name).register_forward_hook(
+                lambda m_, i_, o_, _n=name: cap.__setitem__(_n, o_)))
+        hooks.append(net.ssr_upsample.register_forward_pre_hook(
+            lambda m_, i_: cap.setdefault("ssr_in", []).append(i_[0])))
+        with torch.no_grad():
+            net(torch.zeros(B, 3, H, W), torch.zeros(B, 3, H, W))
+        for h in hooks:
+            h.remove()
+        for name, orig in originals.items():
+            setattr(ms, name, orig)
+        (cost_sq, samples, k), pred = cap["regression_topk"][0]
+        assert k == 2
+        out[f"{n}/pred"] = f32(pred)
+        out[f"{n}/samples"] = samples.numpy().astype(np.int16)
+        out[f"{n}/pred_att0"] = f32(cap["disparity_regression"][0][1])
+        out[f"{n}/pred_att"] = f32(cap["ssr_in"][0].squeeze(1))
+        assert torch.equal(cap["ssr_in"][1], pred)
+        for i, key in enumerate(("build_gwc_volume_norm", "patch", "hourglass_att", "classif_att_", "concat_stem",
+                                 "hourglass", "classif")):
+            t = cap[key][0][1] if key == "build_gwc_volume_norm" else cap[key]
+            out[f"{n}/sum/{key}"] = summary(t, i)
+        out[f"{n}/cost_att"] = f32(cap["classif_att_"])       # [B,1,D8,H8,W8]: small
+        print(n, "pred", tuple(pred.shape), "samples", tuple(samples.shape),
+              "pred range", float(pred.min()), float(pred.max()))
+    np.savez_compressed(os.path.join(HERE, "segment.npz"), **out)
+    print("segment.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference is only mounted in the build container"
+    gen_ops(load_ref_oplib())
+    ms = load_ref_model_module()
+    gen_stack(ms)
+    gen_segment(ms)
+    for f in ("ops.npz", "stack.npz", "segment.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

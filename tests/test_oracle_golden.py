@@ -1,0 +1,120 @@
+"""CPU: the oracle (oracle/*.py) against the golden fixtures produced by the
+reference itself (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from golden import cases
+from oracle import hot_segment as oseg
+from oracle import ops as oops
+from oracle import stack as ostack
+
+
+def _eq(a, ref, atol=0.0, rtol=0.0):
+    a = a.detach().cpu().numpy()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    if atol == 0.0 and rtol == 0.0:
+        assert np.array_equal(a, ref, equal_nan=True), float(np.nanmax(np.abs(a - ref)))
+    else:
+        np.testing.assert_allclose(a, ref, atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("name", sorted(cases.GWC))
+def test_gwc(golden, name):
+    a, b, m, G = cases.gwc_inputs(name)
+    g = golden["ops"]
+    _eq(oops.build_gwc_volume(a, b, m, G), g[f"gwc/{name}"])
+    _eq(oops.build_gwc_volume_norm(a, b, m, G), g[f"gwc_norm/{name}"])
+    _eq(oops.groupwise_correlation(a, b, G), g[f"gcorr/{name}"])
+    _eq(oops.groupwise_correlation_norm(a, b, G), g[f"gcorr_norm/{name}"])
+
+
+@pytest.mark.parametrize("name", sorted(cases.CONCAT))
+def test_concat(golden, name):
+    a, b, m = cases.concat_inputs(name)
+    _eq(oops.build_concat_volume(a, b, m), golden["ops"][f"concat/{name}"])
+
+
+@pytest.mark.parametrize("name", sorted(cases.REGRESSION))
+def test_regression(golden, name):
+    p, m, d = cases.regression_inputs(name)
+    _eq(oops.disparity_regression(p, m), golden["ops"][f"regression/{name}"])
+    _eq(oops.disparity_variance(p, m, d), golden["ops"][f"variance/{name}"])
+    with pytest.raises(AssertionError):
+        oops.disparity_regression(p.unsqueeze(0), m)
+
+
+@pytest.mark.parametrize("name", sorted(cases.WARP))
+def test_warp(golden, name):
+    x, y, d = cases.warp_inputs(name)
+    yw, xw = oops.SpatialTransformer_grid(x, y, d)
+    _eq(yw, golden["ops"][f"warp_y/{name}"])
+    _eq(xw, golden["ops"][f"warp_x/{name}"])
+
+
+@pytest.mark.parametrize("name", sorted(cases.TOPK))
+def test_topk(golden, name):
+    c, s, k = cases.topk_inputs(name)
+    _eq(oops.regression_topk(c, s, k), golden["ops"][f"topk/{name}"])
+
+
+def test_propagation(golden):
+    for n in cases.PROP:
+        _eq(oops.propagation(cases.prop_inputs(n)), golden["ops"][f"prop/{n}"])
+    for n in cases.PROP_PROB:
+        _eq(oops.propagation_prob(cases.prop_prob_inputs(n)), golden["ops"][f"prop_prob/{n}"])
+
+
+def run_stack_oracle(P, name):
+    kind, shape, block = cases.STACK[name]
+    x = cases.stack_input(name)
+    if kind in ("hourglass_att", "hourglass"):
+        return ostack.hourglass(P, kind, x, block)
+    if kind == "classif":
+        return ostack.classifier(P, "classif", x)
+    if kind == "concat_stem":
+        return ostack.basic_conv(P, "concat_stem", x, is_3d=True)
+    return ostack.attention_block(P, kind, x, block)
+
+
+@pytest.mark.parametrize("name", sorted(cases.STACK))
+def test_stack(golden, name):
+    P = oseg.deterministic_params()
+    with torch.no_grad():
+        y = run_stack_oracle(P, name)
+    # same ATen kernels in a different composition: allow a few ulp
+    _eq(y, golden["stack"][f"stack/{name}"], atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", sorted(cases.SEGMENT))
+def test_hot_segment(golden, name):
+    P = oseg.deterministic_params()
+    fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
+    r = oseg.hot_segment(P, fl4, fr4, fl8, fr8, maxdisp, keep=True)
+    g = golden["segment"]
+    assert np.array_equal(r["samples"].numpy().astype(np.int16), g[f"{name}/samples"])
+    _eq(r["pred_att0"], g[f"{name}/pred_att0"], atol=1e-5)
+    _eq(r["pred_att"], g[f"{name}/pred_att"], atol=1e-5)
+    _eq(r["pred"], g[f"{name}/pred"], atol=1e-5)
+    _eq(r["cost_att"], g[f"{name}/cost_att"], atol=1e-5, rtol=1e-5)
+    for i, (key, t) in enumerate((("build_gwc_volume_norm", None), ("patch", r["corr_volume"]))):
+        if t is None:
+            continue
+        rec = g[f"{name}/sum/{key}"]
+        a = t.double().reshape(-1)
+        idx = cases.sample_index(a.numel(), 64, i)
+        np.testing.assert_allclose(a[idx].numpy(), rec[2:], atol=1e-6)
+        np.testing.assert_allclose(a.sum().item(), rec[0], rtol=1e-6, atol=1e-3)
+
+
+def test_param_table_matches_reference_names():
+    """The key table is validated against the reference in make_golden.py
+    (load_state_dict: no unexpected keys); here: it is self-consistent."""
+    S = oseg.segment_param_shapes()
+    P = oseg.deterministic_params()
+    assert set(S) == set(P)
+    assert P["hourglass_att.conv5.0.weight"].shape == (128, 64, 3, 3, 3)
+    assert P["hourglass.attention_block.qkv_3d.weight"].shape == (384, 128)
+    assert P["concat_stem.conv.weight"].shape == (32, 64, 3, 3, 3)
+    assert P["patch.weight"].shape == (32, 1, 1, 3, 3)
+    assert all(v.dtype == torch.float32 for v in P.values())
