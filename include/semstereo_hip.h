@@ -1,0 +1,165 @@
+/*
+ * semstereo_hip.h -- C ABI of libsemstereo_hip.so: the MI355X (gfx950) kernels for the
+ * SemStereo cost-volume + 3-D aggregation hot path.
+ *
+ * The reference (chenchen235/SemStereo) is pure Python: its "operator interface" for this
+ * path is a set of module-level callables in models/submodule.py that models/SemStereo.py
+ * star-imports and calls by bare name.  Each entry point below is the
+ * device-side replacement of one of those callables (or of one nn.Module.forward on the
+ * path); the Python wrappers in semstereo_amd/ops.py keep the reference names and positional
+ * signatures and call these through ctypes.
+ *
+ * Conventions
+ *  - all tensors are fp32, contiguous, in the reference's layouts: NCHW feature maps,
+ *    NCDHW volumes;
+ *  - pointers are BORROWED device pointers (owned by the caller's allocator); outputs are
+ *    fully written by the kernels (no pre-zeroing needed) unless stated;
+ *  - `stream` is a hipStream_t (NULL = the null stream); launches are asynchronous;
+ *  - re-entrant, no global mutable state, current device of the calling thread;
+ *  - return value: SS_OK (0) or a negative ss_status; nothing throws across the ABI.
+ */
+#ifndef SEMSTEREO_HIP_H
+#define SEMSTEREO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ss_stream_t; /* hipStream_t */
+
+enum ss_status {
+    SS_OK = 0,
+    SS_ERR_INVALID = -1,     /* null pointer, non-positive size, C % groups != 0 ... */
+    SS_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
+    SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
+};
+
+/* ABI version: bumped on any signature change. */
+int ss_abi_version(void);
+/* Static, human-readable text for an ss_status. */
+const char* ss_status_string(int status);
+/* hipGetErrorString of the last SS_ERR_LAUNCH on this thread ("" if none). */
+const char* ss_last_hip_error(void);
+
+/* ---- group-wise correlation ----------------------------------------------------------
+ * groupwise_correlation(fea1, fea2, num_groups)       models/submodule.py:190-196
+ * groupwise_correlation_norm(...)                     models/submodule.py:213-221
+ * out[b,g,y,x] = mean_c f1[b,g*Cg+c,y,x] * f2[b,g*Cg+c,y,x]; with normalize != 0 each group
+ * vector is first divided by (its L2 norm over the Cg channels + 1e-5).  [B,C,H,W]^2 -> [B,G,H,W] */
+int ss_groupwise_correlation_fwd(const float* fea1, const float* fea2, float* out,
+                                 int B, int C, int H, int W, int groups, int normalize,
+                                 ss_stream_t stream);
+
+/* build_gwc_volume(ref, tgt, maxdisp, num_groups)      models/submodule.py:198-211
+ * build_gwc_volume_norm(...)                           models/submodule.py:224-238 (live: SemStereo.py:273)
+ * out[b,g,d,y,x] = corr(ref[...,x], tgt[...,x-(d-maxdisp)]) for d in [0, 2*maxdisp), 0 where
+ * the partner column leaves the image.  [B,C,H,W]^2 -> [B,G,2*maxdisp,H,W] */
+int ss_gwc_volume_fwd(const float* ref, const float* tgt, float* out,
+                      int B, int C, int H, int W, int maxdisp, int groups, int normalize,
+                      ss_stream_t stream);
+/* gradients of the UN-normalised volume w.r.t. ref and tgt (both fully written). */
+int ss_gwc_volume_bwd(const float* grad_out, const float* ref, const float* tgt,
+                      float* grad_ref, float* grad_tgt,
+                      int B, int C, int H, int W, int maxdisp, int groups,
+                      ss_stream_t stream);
+
+/* build_concat_volume(ref, tgt, maxdisp)               models/submodule.py:173-187
+ * out[b,0:C,d,y,x] = ref[b,:,y,x], out[b,C:2C,d,y,x] = tgt[b,:,y,x-(d-maxdisp)], BOTH 0 where
+ * the partner column leaves the image.  [B,C,H,W]^2 -> [B,2C,2*maxdisp,H,W] */
+int ss_concat_volume_fwd(const float* ref, const float* tgt, float* out,
+                         int B, int C, int H, int W, int maxdisp, ss_stream_t stream);
+int ss_concat_volume_bwd(const float* grad_out, float* grad_ref, float* grad_tgt,
+                         int B, int C, int H, int W, int maxdisp, ss_stream_t stream);
+
+/* SpatialTransformer_grid(x, y, disp_range_samples)    models/submodule.py:265-288
+ * y_warped[b,c,j,h,w] = bilinear(y[b,c], row h, col w - disp[b,j,h,w]) with zeros padding and
+ * align_corners=True, coordinates taken through the reference's normalise/unnormalise fp32
+ * round trip; x_warped[b,c,j,h,w] = x[b,c,h,w].  x_warped may be NULL (not written).
+ * x,y [B,C,H,W], disp [B,nd,H,W] -> [B,C,nd,H,W] each. */
+int ss_warp_sampled_fwd(const float* x, const float* y, const float* disp,
+                        float* y_warped, float* x_warped,
+                        int B, int C, int H, int W, int nd, ss_stream_t stream);
+/* Fused form of SemStereo.concat_volume_generator + `att_topk * volume`
+ * (models/SemStereo.py:241-244, 318): out[b,0:C,j] = att[b,j] * left[b,:],
+ * out[b,C:2C,j] = att[b,j] * warp(right)[b,:,j].  att [B,nd,H,W] may be NULL (no gating).
+ * -> [B,2C,nd,H,W] */
+int ss_concat_sampled_fwd(const float* left, const float* right, const float* disp, const float* att,
+                          float* out, int B, int C, int H, int W, int nd, ss_stream_t stream);
+/* Fused form of models/SemStereo.py:291-292: mean over channels of left * warp(right):
+ * x,y [B,C,H,W], disp [B,nd,H,W] -> [B,nd,H,W] */
+int ss_warp_correlation_fwd(const float* x, const float* y, const float* disp, float* out,
+                            int B, int C, int H, int W, int nd, ss_stream_t stream);
+
+/* disparity_regression(x, maxdisp)                     models/submodule.py:164-170
+ * out[b,y,x] = sum_d prob[b,d,y,x] * (d - maxdisp), d in [0, 2*maxdisp).  [B,2m,H,W] -> [B,H,W] */
+int ss_disparity_regression_fwd(const float* prob, float* out, int B, int maxdisp, int H, int W,
+                                ss_stream_t stream);
+int ss_disparity_regression_bwd(const float* grad_out, float* grad_prob, int B, int maxdisp, int H, int W,
+                                ss_stream_t stream);
+/* disparity_variance(x, maxdisp, disparity)            models/submodule.py:257-263
+ * out[b,0,y,x] = sum_d prob[b,d,y,x] * ((d - maxdisp) - disparity[b,0,y,x])^2 */
+int ss_disparity_variance_fwd(const float* prob, const float* disparity, float* out,
+                              int B, int maxdisp, int H, int W, ss_stream_t stream);
+/* Fused softmax over D + regression + variance of models/SemStereo.py:281-285:
+ * logits [B,2m,H,W] -> prob (nullable) [B,2m,H,W], disp [B,H,W], var [B,1,H,W] */
+int ss_softmax_regression_fwd(const float* logits, float* prob, float* disp, float* var,
+                              int B, int maxdisp, int H, int W, ss_stream_t stream);
+
+/* regression_topk(cost, disparity_samples, k)          models/submodule.py:434-442
+ * per pixel: the k largest costs (ties: lower index first), softmax over them, expectation of
+ * the matching candidates.  cost, samples [B,nd,H,W] -> [B,1,H,W].  1 <= k <= min(nd, 32). */
+int ss_regression_topk_fwd(const float* cost, const float* samples, float* out,
+                           int B, int nd, int H, int W, int k, ss_stream_t stream);
+
+/* channelAtt gating (models/SemStereo.py:101-102): out[b,c,d,y,x] = sigmoid(att[b,c,y,x]) * cv[b,c,d,y,x] */
+int ss_channel_gate_fwd(const float* att_logits, const float* cv, float* out,
+                        int B, int C, int D, int H, int W, ss_stream_t stream);
+
+/* ---- 3-D aggregation stack -------------------------------------------------------------
+ * Conv3d(bias=False) [+ BatchNorm3d in eval] [+ residual] [+ ReLU]: convbn_3d
+ * (models/submodule_other.py:845-848), BasicConv(is_3d) (models/submodule.py:89-116), the
+ * classifier heads (models/SemStereo.py:228-234).
+ *   in      [B,Cin,D,H,W]
+ *   wpack   weights re-laid out as [Cin][kd*kh*kw][Cout] (see ss_pack_conv3d_weights)
+ *   scale, shift   per-Cout affine applied to the accumulator (folded BN; NULL = 1 / 0)
+ *   residual       [B,Cout,Do,Ho,Wo] added after the affine (NULL = none)
+ *   relu           != 0 -> max(.,0) last
+ *   kernel k in {1,3} (cubic), stride in {1,2}, pad = k/2.  out [B,Cout,Do,Ho,Wo],
+ *   Do = (D + 2*pad - k)/stride + 1 ... */
+int ss_conv3d_fwd(const float* in, const float* wpack, const float* scale, const float* shift,
+                  const float* residual, float* out,
+                  int B, int Cin, int D, int H, int W, int Cout, int k, int stride, int relu,
+                  ss_stream_t stream);
+/* ConvTranspose3d(k3, s2, p1, output_padding 1, bias=False) [+BN] fused with the 1x1x1 skip
+ * projection of hourglass.forward (models/SemStereo.py:141-142):
+ *   out = relu?( scale*deconv(in) + shift + skip_scale*conv1x1(skip) + skip_shift )
+ *   in [B,Cin,D,H,W] -> out [B,Cout,2D,2H,2W]; wpack [Cin][27][Cout] (tap = kd*9+kh*3+kw of
+ *   the ConvTranspose3d weight [Cin,Cout,3,3,3]); skip [B,Cs,2D,2H,2W] with skip_wpack
+ *   [Cs][Cout] (NULL skip = plain deconv+affine). */
+int ss_deconv3d_fwd(const float* in, const float* wpack, const float* scale, const float* shift,
+                    const float* skip, const float* skip_wpack, const float* skip_scale, const float* skip_shift,
+                    float* out, int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu,
+                    ss_stream_t stream);
+/* Weight re-layout helpers (device to device): Conv3d weight [Cout,Cin,k,k,k] or
+ * ConvTranspose3d weight [Cin,Cout,k,k,k] (transposed != 0) -> [Cin][k^3][Cout]. */
+int ss_pack_conv3d_weights(const float* w, float* wpack, int Cout, int Cin, int k, int transposed,
+                           ss_stream_t stream);
+/* `patch` (models/SemStereo.py:219, 274): depthwise Conv3d kernel (1,3,3), pad (0,1,1), no bias,
+ * optionally fused with the channelAtt gate that follows it (:276):
+ *   out[b,c,d] = sigmoid?(gate[b,c]) * conv2d_3x3(in[b,c,d], w[c])       w [C,1,1,3,3], gate [B,C,H,W] or NULL */
+int ss_depthwise_patch_fwd(const float* in, const float* w, const float* gate, float* out,
+                           int B, int C, int D, int H, int W, ss_stream_t stream);
+/* attention_block.forward (models/submodule_other.py:790-837): windowed multi-head
+ * self-attention over (bd,bh,bw) windows + 1x1x1 conv with bias.
+ *   x [B,C,D,H,W] (C = heads * 8), wqkv_t [C][3C] (= qkv_3d.weight transposed), bqkv [3C],
+ *   wout_t [C][C] (= final1x1.weight[:, :, 0,0,0] transposed), bout [C] -> out [B,C,D,H,W].
+ *   D % bd == 0; H, W are padded virtually to window multiples with the reference's masking. */
+int ss_window_attention_fwd(const float* x, const float* wqkv_t, const float* bqkv,
+                            const float* wout_t, const float* bout, float* out,
+                            int B, int C, int D, int H, int W, int heads, int bd, int bh, int bw,
+                            ss_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMSTEREO_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libsemstereo_hip.so (the C ABI declared in include/semstereo_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a kernel
+returns an error, the caller gets an exception.  PyTorch is used only for
+device memory and streams; the signatures below carry raw pointers and sizes.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
+ABI_VERSION = 1
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+
+# name -> argument types (return type is always int status); mirrors include/semstereo_hip.h
+_SIGNATURES = {
+    "ss_groupwise_correlation_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ss_gwc_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_gwc_volume_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ss_concat_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_concat_volume_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_warp_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_concat_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_warp_correlation_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_disparity_regression_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "ss_disparity_regression_bwd": [_P, _P, _I, _I, _I, _I, _P],
+    "ss_disparity_variance_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ss_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ss_regression_topk_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_channel_gate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_pack_conv3d_weights": [_P, _P, _I, _I, _I, _I, _P],
+    "ss_depthwise_patch_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_window_attention_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+}
+EXPORTS = sorted(list(_SIGNATURES) + ["ss_abi_version", "ss_status_string", "ss_last_hip_error"])
+
+_lib = None
+
+
+class SemStereoHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise (never fall back) if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SemStereoHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C semstereo_amd/csrc`. There is no CPU or PyTorch fallback for the HIP path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ss_abi_version.restype = _I
+    lib.ss_status_string.restype = ctypes.c_char_p
+    lib.ss_status_string.argtypes = [_I]
+    lib.ss_last_hip_error.restype = ctypes.c_char_p
+    if lib.ss_abi_version() != ABI_VERSION:
+        raise SemStereoHipError(f"ABI mismatch: library {lib.ss_abi_version()} != binding {ABI_VERSION}; rebuild")
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _I
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an entry point on the current stream; raise on a non-zero status."""
+    lib = load()
+    status = getattr(lib, name)(*args, stream())
+    if status != 0:
+        msg = lib.ss_status_string(status).decode()
+        if status == -3:
+            msg += ": " + lib.ss_last_hip_error().decode()
+        raise SemStereoHipError(f"{name} failed ({status}): {msg}")
+
+
+def require_device(*tensors):
+    """Every tensor must be fp32 on a HIP device; anything else is an error (no fallback)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise SemStereoHipError("semstereo_amd ops run on MI355X only: got a CPU tensor (no CPU fallback exists)")
+        if t.dtype != torch.float32:
+            raise TypeError(f"semstereo_amd ops are fp32 like the reference, got {t.dtype}")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise SemStereoHipError("all tensors of one call must live on the same device")
+    return dev

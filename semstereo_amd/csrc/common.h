@@ -1,0 +1,39 @@
+// Shared helpers for the gfx950 kernels of libsemstereo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/semstereo_hip.h"
+
+namespace ss {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// Records the text of the last launch failure on this thread (see ss_last_hip_error()).
+void note_hip_error(hipError_t e);
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        note_hip_error(e);
+        return SS_ERR_LAUNCH;
+    }
+    return SS_OK;
+}
+
+inline hipStream_t as_stream(ss_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
+
+// Unfused multiply / add (the reference materialises the product tensor, i.e. rounds it,
+// before reducing; keeping the two roundings makes several kernels bit-identical to it).
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+
+}  // namespace ss
+
+#define SS_REQUIRE(cond)                \
+    do {                                \
+        if (!(cond)) return SS_ERR_INVALID; \
+    } while (0)

@@ -1,0 +1,350 @@
+// Group-wise correlation cost volume over a signed disparity range (gfx950).
+//
+//   out[b,g,d,y,x] = (1/Cg) * sum_c  R[b,g,c,y,x] * T[b,g,c,y,x-(d-m)]      d in [0,2m)
+//
+// R/T are the left/right feature maps, optionally L2-normalised over each group's Cg
+// channels (x / (||x||_2 + 1e-5)); the value is 0 where x-(d-m) leaves the image.
+// Replaces build_gwc_volume / build_gwc_volume_norm / groupwise_correlation[_norm]
+// (reference models/submodule.py:190-238), which run a Python loop over d of ~10 ATen
+// kernels each and re-normalise the same pixels 2m times.
+//
+// HBM-bound: algorithmic traffic = 4*(2*C + G*2m)*H*W bytes per pair, 2.9 flop/byte.
+// One workgroup owns (b, g, 8 rows, 128 columns): the right-image tile (+ m columns of
+// halo each side, zero outside the image) is normalised ONCE and parked in LDS, the
+// left-image pixels stay in registers, and every thread then produces all 2m disparities
+// of its 4 consecutive columns, 8 disparities at a time from three ds_read_b128 per channel.
+// All global traffic is 16 B per lane, coalesced along W.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int XT = 128;   // columns per workgroup tile (32 lanes x float4)
+constexpr int RT = 8;     // rows per workgroup tile
+constexpr float kEps = 1e-05f;
+
+template <int CG, bool NORM>
+__global__ __launch_bounds__(256) void gwc_volume_v4(const float* __restrict__ ref,
+                                                      const float* __restrict__ tgt,
+                                                      float* __restrict__ out,
+                                                      int C, int H, int W, int m, int G) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [CG][RT][LW]
+    const int LW = XT + 2 * m;
+    const int tid = threadIdx.x;
+    const int xt0 = blockIdx.x * XT;
+    const int y0 = blockIdx.y * RT;
+    const int b = blockIdx.z / G, g = blockIdx.z % G;
+    const size_t plane = (size_t)H * W;
+    const float* refg = ref + ((size_t)b * C + (size_t)g * CG) * plane;
+    const float* tgtg = tgt + ((size_t)b * C + (size_t)g * CG) * plane;
+
+    // ---- stage the (normalised) right-image tile, zero-extended by m columns per side ----
+    const int LQ = LW / 4;
+    for (int q = tid; q < RT * LQ; q += 256) {
+        const int row = q / LQ, qi = q - row * LQ;
+        const int col0 = xt0 - m + qi * 4;
+        const int y = y0 + row;
+        float4 v[CG];
+        if (y < H && col0 >= 0 && col0 < W) {
+            const float* p = tgtg + (size_t)y * W + col0;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) v[c] = *reinterpret_cast<const float4*>(p + c * plane);
+            if (NORM) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    s.x = ss::add_rn(s.x, ss::mul_rn(v[c].x, v[c].x));
+                    s.y = ss::add_rn(s.y, ss::mul_rn(v[c].y, v[c].y));
+                    s.z = ss::add_rn(s.z, ss::mul_rn(v[c].z, v[c].z));
+                    s.w = ss::add_rn(s.w, ss::mul_rn(v[c].w, v[c].w));
+                }
+                s.x = sqrtf(s.x) + kEps; s.y = sqrtf(s.y) + kEps;
+                s.z = sqrtf(s.z) + kEps; s.w = sqrtf(s.w) + kEps;
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    v[c].x = v[c].x / s.x; v[c].y = v[c].y / s.y;
+                    v[c].z = v[c].z / s.z; v[c].w = v[c].w / s.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+            *reinterpret_cast<float4*>(&lds[(c * RT + row) * LW + qi * 4]) = v[c];
+    }
+
+    // ---- this thread's 4 left-image pixels, all CG channels, in registers ----
+    const int tx = tid & 31, ty = tid >> 5;
+    const int x0 = xt0 + tx * 4;
+    const int y = y0 + ty;
+    const bool active = (y < H) && (x0 < W);
+    float r[CG][4];
+    if (active) {
+        const float* p = refg + (size_t)y * W + x0;
+        float4 v[CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) v[c] = *reinterpret_cast<const float4*>(p + c * plane);
+        if (NORM) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                s.x = ss::add_rn(s.x, ss::mul_rn(v[c].x, v[c].x));
+                s.y = ss::add_rn(s.y, ss::mul_rn(v[c].y, v[c].y));
+                s.z = ss::add_rn(s.z, ss::mul_rn(v[c].z, v[c].z));
+                s.w = ss::add_rn(s.w, ss::mul_rn(v[c].w, v[c].w));
+            }
+            s.x = sqrtf(s.x) + kEps; s.y = sqrtf(s.y) + kEps;
+            s.z = sqrtf(s.z) + kEps; s.w = sqrtf(s.w) + kEps;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                v[c].x = v[c].x / s.x; v[c].y = v[c].y / s.y;
+                v[c].z = v[c].z / s.z; v[c].w = v[c].w / s.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CG; ++c) { r[c][0] = v[c].x; r[c][1] = v[c].y; r[c][2] = v[c].z; r[c][3] = v[c].w; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CG; ++c) { r[c][0] = r[c][1] = r[c][2] = r[c][3] = 0.f; }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // ---- all 2m disparities of these 4 columns, 8 at a time ----
+    // LDS column of image column xx is xx - xt0 + m, so output (d, x0+j) reads index
+    // tx*4 + j + 2m - d = base + (j + 8 - i) with d = d0 + i, base = tx*4 + 2m - d0 - 8.
+    const int D = 2 * m;
+    float* outp = out + (((size_t)(b * G + g) * D) * H + y) * W + x0;
+    const float den = (float)CG;
+    for (int d0 = 0; d0 < D; d0 += 8) {
+        float acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
+        const int base = tx * 4 + D - d0 - 8;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const float* lp = &lds[(c * RT + ty) * LW + base];
+            float w[12];
+            *reinterpret_cast<float4*>(&w[0]) = *reinterpret_cast<const float4*>(lp);
+            *reinterpret_cast<float4*>(&w[4]) = *reinterpret_cast<const float4*>(lp + 4);
+            *reinterpret_cast<float4*>(&w[8]) = *reinterpret_cast<const float4*>(lp + 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = ss::add_rn(acc[i][j], ss::mul_rn(r[c][j], w[j + 8 - i]));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = d0 + i;
+            const int col = x0 - (d - m);          // partner column of x0; of x0+j it is col+j
+            float4 o;
+            o.x = ((unsigned)(col + 0) < (unsigned)W) ? acc[i][0] / den : 0.f;
+            o.y = ((unsigned)(col + 1) < (unsigned)W) ? acc[i][1] / den : 0.f;
+            o.z = ((unsigned)(col + 2) < (unsigned)W) ? acc[i][2] / den : 0.f;
+            o.w = ((unsigned)(col + 3) < (unsigned)W) ? acc[i][3] / den : 0.f;
+            *reinterpret_cast<float4*>(outp + (size_t)d * plane) = o;
+        }
+    }
+}
+
+// Any W / maxdisp / Cg: one column per lane, both normalised tiles in LDS.
+// blockDim = (GX, GR); LDS = Cg * GR * (GX + GX + 2m) floats.
+template <bool NORM>
+__global__ void gwc_volume_generic(const float* __restrict__ ref, const float* __restrict__ tgt,
+                                   float* __restrict__ out, int C, int H, int W, int m, int G) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int GX = blockDim.x, GR = blockDim.y;
+    const int Cg = C / G;
+    const int LW = GX + 2 * m;
+    float* rn = lds;                       // [Cg][GR][GX]
+    float* tn = lds + (size_t)Cg * GR * GX;  // [Cg][GR][LW]
+    const int xt0 = blockIdx.x * GX, y0 = blockIdx.y * GR;
+    const int b = blockIdx.z / G, g = blockIdx.z % G;
+    const size_t plane = (size_t)H * W;
+    const float* refg = ref + ((size_t)b * C + (size_t)g * Cg) * plane;
+    const float* tgtg = tgt + ((size_t)b * C + (size_t)g * Cg) * plane;
+    const int tid = threadIdx.y * GX + threadIdx.x, nthr = GX * GR;
+
+    for (int q = tid; q < GR * LW; q += nthr) {
+        const int row = q / LW, li = q - row * LW;
+        const int col = xt0 - m + li, y = y0 + row;
+        const bool in = (y < H) && (col >= 0) && (col < W);
+        float den = 1.f;
+        if (in && NORM) {
+            float s = 0.f;
+            for (int c = 0; c < Cg; ++c) { float v = tgtg[c * plane + (size_t)y * W + col]; s = ss::add_rn(s, ss::mul_rn(v, v)); }
+            den = sqrtf(s) + kEps;
+        }
+        for (int c = 0; c < Cg; ++c) {
+            float v = in ? tgtg[c * plane + (size_t)y * W + col] : 0.f;
+            tn[((size_t)c * GR + row) * LW + li] = NORM ? v / den : v;
+        }
+    }
+    for (int q = tid; q < GR * GX; q += nthr) {
+        const int row = q / GX, li = q - row * GX;
+        const int col = xt0 + li, y = y0 + row;
+        const bool in = (y < H) && (col < W);
+        float den = 1.f;
+        if (in && NORM) {
+            float s = 0.f;
+            for (int c = 0; c < Cg; ++c) { float v = refg[c * plane + (size_t)y * W + col]; s = ss::add_rn(s, ss::mul_rn(v, v)); }
+            den = sqrtf(s) + kEps;
+        }
+        for (int c = 0; c < Cg; ++c) {
+            float v = in ? refg[c * plane + (size_t)y * W + col] : 0.f;
+            rn[((size_t)c * GR + row) * GX + li] = NORM ? v / den : v;
+        }
+    }
+    __syncthreads();
+    const int x = xt0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int D = 2 * m;
+    const float den = (float)Cg;
+    float* outp = out + (((size_t)(b * G + g) * D) * H + y) * W + x;
+    for (int d = 0; d < D; ++d) {
+        const int li = threadIdx.x + D - d;       // = (x - (d - m)) - (xt0 - m)
+        float acc = 0.f;
+        for (int c = 0; c < Cg; ++c)
+            acc = ss::add_rn(acc, ss::mul_rn(rn[((size_t)c * GR + threadIdx.y) * GX + threadIdx.x],
+                                             tn[((size_t)c * GR + threadIdx.y) * LW + li]));
+        const int col = x - (d - m);
+        outp[(size_t)d * plane] = ((unsigned)col < (unsigned)W) ? acc / den : 0.f;
+    }
+}
+
+// groupwise_correlation: no shift, one output per (b,g,pixel).
+template <bool NORM>
+__global__ void group_corr_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                  float* __restrict__ out, int C, int G, long long plane, long long total) {
+    const int Cg = C / G;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i % plane;
+        const long long bg = i / plane;          // b*G + g
+        const long long b = bg / G, g = bg % G;
+        const float* p1 = f1 + (b * C + g * Cg) * plane + pix;
+        const float* p2 = f2 + (b * C + g * Cg) * plane + pix;
+        float d1 = 1.f, d2 = 1.f;
+        if (NORM) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int c = 0; c < Cg; ++c) {
+                float a = p1[c * plane], bb = p2[c * plane];
+                s1 = ss::add_rn(s1, ss::mul_rn(a, a));
+                s2 = ss::add_rn(s2, ss::mul_rn(bb, bb));
+            }
+            d1 = sqrtf(s1) + kEps; d2 = sqrtf(s2) + kEps;
+        }
+        float acc = 0.f;
+        for (int c = 0; c < Cg; ++c) {
+            float a = p1[c * plane], bb = p2[c * plane];
+            if (NORM) { a = a / d1; bb = bb / d2; }
+            acc = ss::add_rn(acc, ss::mul_rn(a, bb));
+        }
+        out[i] = acc / (float)Cg;
+    }
+}
+
+// Backward of the un-normalised volume: one thread per input element, loop over d.
+__global__ void gwc_volume_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ ref,
+                                      const float* __restrict__ tgt, float* __restrict__ gref,
+                                      float* __restrict__ gtgt, int C, int H, int W, int m, int G,
+                                      long long total) {
+    const int Cg = C / G, D = 2 * m;
+    const long long plane = (long long)H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long long row = i / W;                 // (b*C + c)*H + y
+        const int yy = (int)(row % H);
+        const long long bc = row / H;
+        const int c = (int)(bc % C);
+        const long long b = bc / C;
+        const int g = c / Cg;
+        const float* go = gout + ((b * G + g) * D) * plane + (long long)yy * W;
+        const float* rrow = ref + row * W;
+        const float* trow = tgt + row * W;
+        float ar = 0.f, at = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const int s = d - m;
+            const int xr = x - s;                    // partner of left column x
+            if ((unsigned)xr < (unsigned)W) ar += go[d * plane + x] * trow[xr];
+            const int xl = x + s;                    // left column whose partner is right column x
+            if ((unsigned)xl < (unsigned)W) at += go[d * plane + xl] * rrow[xl];
+        }
+        gref[i] = ar / (float)Cg;
+        gtgt[i] = at / (float)Cg;
+    }
+}
+
+template <int CG>
+int launch_v4(const float* ref, const float* tgt, float* out, int B, int C, int H, int W, int m, int G,
+              int normalize, hipStream_t st) {
+    dim3 grid(ss::ceil_div(W, XT), ss::ceil_div(H, RT), B * G);
+    size_t lds = (size_t)CG * RT * (XT + 2 * m) * sizeof(float);
+    if (normalize)
+        hipLaunchKernelGGL((gwc_volume_v4<CG, true>), grid, dim3(256), lds, st, ref, tgt, out, C, H, W, m, G);
+    else
+        hipLaunchKernelGGL((gwc_volume_v4<CG, false>), grid, dim3(256), lds, st, ref, tgt, out, C, H, W, m, G);
+    return ss::check_launch();
+}
+
+}  // namespace
+
+extern "C" int ss_gwc_volume_fwd(const float* ref, const float* tgt, float* out, int B, int C, int H, int W,
+                                 int maxdisp, int groups, int normalize, ss_stream_t stream) {
+    SS_REQUIRE(ref && tgt && out);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && maxdisp > 0 && groups > 0);
+    SS_REQUIRE(C % groups == 0);
+    SS_REQUIRE((long long)B * groups <= 65535);
+    hipStream_t st = ss::as_stream(stream);
+    const int Cg = C / groups, m = maxdisp;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(tgt) |
+                           reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (aligned && W % 4 == 0 && m % 4 == 0 && (size_t)Cg * RT * (XT + 2 * m) * 4 <= 64 * 1024) {
+        if (Cg == 8) return launch_v4<8>(ref, tgt, out, B, C, H, W, m, groups, normalize, st);
+        if (Cg == 4) return launch_v4<4>(ref, tgt, out, B, C, H, W, m, groups, normalize, st);
+    }
+    // generic path: shrink the tile until both normalised tiles fit in 64 KiB of LDS
+    int gx = 64, gr = 4;
+    auto bytes = [&](int x, int r) { return (size_t)Cg * r * (2 * x + 2 * m) * sizeof(float); };
+    while (gr > 1 && bytes(gx, gr) > 64 * 1024) gr >>= 1;
+    while (gx > 16 && bytes(gx, gr) > 64 * 1024) gx >>= 1;
+    if (bytes(gx, gr) > 64 * 1024) return SS_ERR_UNSUPPORTED;
+    dim3 grid(ss::ceil_div(W, gx), ss::ceil_div(H, gr), B * groups), block(gx, gr);
+    if (normalize)
+        hipLaunchKernelGGL(gwc_volume_generic<true>, grid, block, bytes(gx, gr), st, ref, tgt, out, C, H, W, m, groups);
+    else
+        hipLaunchKernelGGL(gwc_volume_generic<false>, grid, block, bytes(gx, gr), st, ref, tgt, out, C, H, W, m, groups);
+    return ss::check_launch();
+}
+
+extern "C" int ss_groupwise_correlation_fwd(const float* fea1, const float* fea2, float* out, int B, int C, int H,
+                                            int W, int groups, int normalize, ss_stream_t stream) {
+    SS_REQUIRE(fea1 && fea2 && out);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && groups > 0);
+    SS_REQUIRE(C % groups == 0);
+    const long long plane = (long long)H * W, total = (long long)B * groups * plane;
+    const int blocks = (int)std::min<long long>(ss::ceil_div_ll(total, 256), 256 * 16);
+    if (normalize)
+        hipLaunchKernelGGL(group_corr_kernel<true>, dim3(blocks), dim3(256), 0, ss::as_stream(stream), fea1, fea2, out, C, groups, plane, total);
+    else
+        hipLaunchKernelGGL(group_corr_kernel<false>, dim3(blocks), dim3(256), 0, ss::as_stream(stream), fea1, fea2, out, C, groups, plane, total);
+    return ss::check_launch();
+}
+
+extern "C" int ss_gwc_volume_bwd(const float* grad_out, const float* ref, const float* tgt, float* grad_ref,
+                                 float* grad_tgt, int B, int C, int H, int W, int maxdisp, int groups,
+                                 ss_stream_t stream) {
+    SS_REQUIRE(grad_out && ref && tgt && grad_ref && grad_tgt);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && maxdisp > 0 && groups > 0);
+    SS_REQUIRE(C % groups == 0);
+    const long long total = (long long)B * C * H * W;
+    const int blocks = (int)std::min<long long>(ss::ceil_div_ll(total, 256), 256 * 32);
+    hipLaunchKernelGGL(gwc_volume_bwd_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), grad_out, ref, tgt,
+                       grad_ref, grad_tgt, C, H, W, maxdisp, groups, total);
+    return ss::check_launch();
+}

@@ -1,0 +1,194 @@
+// Disparity-candidate warping of the right feature map (gfx950).
+//
+//   warp(y)[b,c,j,h,w] = bilinear( y[b,c], row ~ h, col ~ w - disp[b,j,h,w] )   zeros padding
+//
+// Replaces SpatialTransformer_grid (reference models/submodule.py:265-288) and two of its
+// consumers in SemStereo.forward: the sparse concat volume `att_topk * cat(left, warp(right))`
+// (models/SemStereo.py:241-244, 316-318) and the 5-sample matching-strength probe
+// `mean_c(left * warp(right))` (:291-292).  The reference materialises a [B,nd,H,W,2] grid, a
+// repeated copy of the left map, the cat and the product: four full passes over the volume; here
+// each output element is written exactly once, 16 B per lane along W.
+//
+// Coordinates follow the reference's fp32 round trip exactly: gx = (w - disp)/((W-1)/2) - 1,
+// then grid_sample's align_corners=True un-normalisation ix = (gx + 1) * ((W-1)/2) (the ATen
+// CPU form), floor, the four weights (1-fx)(1-fy).. and a nw+ne+sw+se sum with separate
+// roundings; taps outside the image contribute 0 * weight.  Because of the round trip ix, iy are
+// only approximately (w - disp, h): rows h-1..h+1 can carry ~1e-5 weights, which we keep.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+struct Taps {
+    int o_nw, o_ne, o_sw, o_se;     // element offsets into a [H][W] plane, -1 = outside (value 0)
+    float w_nw, w_ne, w_sw, w_se;
+};
+
+__device__ __forceinline__ Taps make_taps(float disp, int h, int w, int H, int W, float half_w, float half_h) {
+    const float gx = ((float)w - disp) / half_w - 1.0f;
+    const float gy = (float)h / half_h - 1.0f;
+    const float ix = ss::mul_rn(gx + 1.0f, half_w);
+    const float iy = ss::mul_rn(gy + 1.0f, half_h);
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float fw = ix - xw, fe = 1.0f - fw, fn = iy - yn, fs = 1.0f - fn;
+    const float xe = xw + 1.0f, ys = yn + 1.0f;
+    const bool mw = (xw > -1.0f) && (xw < (float)W), me = (xe > -1.0f) && (xe < (float)W);
+    const bool mn = (yn > -1.0f) && (yn < (float)H), ms = (ys > -1.0f) && (ys < (float)H);
+    const int ixw = (int)xw, iyn = (int)yn;
+    Taps t;
+    t.w_nw = ss::mul_rn(fs, fe); t.w_ne = ss::mul_rn(fs, fw);
+    t.w_sw = ss::mul_rn(fn, fe); t.w_se = ss::mul_rn(fn, fw);
+    t.o_nw = (mn && mw) ? iyn * W + ixw : -1;
+    t.o_ne = (mn && me) ? iyn * W + ixw + 1 : -1;
+    t.o_sw = (ms && mw) ? (iyn + 1) * W + ixw : -1;
+    t.o_se = (ms && me) ? (iyn + 1) * W + ixw + 1 : -1;
+    return t;
+}
+
+__device__ __forceinline__ float sample(const float* __restrict__ plane, const Taps& t) {
+    const float a = (t.o_nw >= 0) ? plane[t.o_nw] : 0.f;
+    const float b = (t.o_ne >= 0) ? plane[t.o_ne] : 0.f;
+    const float c = (t.o_sw >= 0) ? plane[t.o_sw] : 0.f;
+    const float d = (t.o_se >= 0) ? plane[t.o_se] : 0.f;
+    float r = ss::mul_rn(a, t.w_nw);
+    r = ss::add_rn(r, ss::mul_rn(b, t.w_ne));
+    r = ss::add_rn(r, ss::mul_rn(c, t.w_sw));
+    r = ss::add_rn(r, ss::mul_rn(d, t.w_se));
+    return r;
+}
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> { using type = float; };
+template <> struct Vec<4> { using type = float4; };
+
+template <int VEC> __device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]);
+template <> __device__ __forceinline__ void load_vec<1>(const float* p, float (&v)[1]) { v[0] = *p; }
+template <> __device__ __forceinline__ void load_vec<4>(const float* p, float (&v)[4]) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+template <int VEC> __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]);
+template <> __device__ __forceinline__ void store_vec<1>(float* p, const float (&v)[1]) { *p = v[0]; }
+template <> __device__ __forceinline__ void store_vec<4>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+enum { MODE_WARP = 0, MODE_CONCAT = 1, MODE_CORR = 2 };
+
+// One thread: VEC consecutive columns of one (b, j, h); loops over the C channels.
+//  MODE_WARP   out0 = y_warped [B,C,nd,H,W], out1 = x_warped (or null)
+//  MODE_CONCAT out0 = volume [B,2C,nd,H,W], gate = att [B,nd,H,W] (or null)
+//  MODE_CORR   out0 = [B,nd,H,W] = mean_c x * warp(y)
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                    const float* __restrict__ disp, const float* __restrict__ gate,
+                                                    float* __restrict__ out0, float* __restrict__ out1,
+                                                    int C, int H, int W, int nd, float half_w, float half_h,
+                                                    long long total) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int WQ = W / VEC;
+    const int wq = (int)(idx % WQ);
+    long long t = idx / WQ;
+    const int h = (int)(t % H); t /= H;
+    const int j = (int)(t % nd);
+    const long long b = t / nd;
+    const int w0 = wq * VEC;
+    const long long plane = (long long)H * W;
+    const long long pix = (long long)h * W + w0;
+
+    float dv[VEC];
+    load_vec<VEC>(disp + (b * nd + j) * plane + pix, dv);
+    Taps tp[VEC];
+#pragma unroll
+    for (int p = 0; p < VEC; ++p) tp[p] = make_taps(dv[p], h, w0 + p, H, W, half_w, half_h);
+
+    if (MODE == MODE_CORR) {
+        float acc[VEC];
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) acc[p] = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* yp = y + (b * C + c) * plane;
+            float xv[VEC];
+            load_vec<VEC>(x + (b * C + c) * plane + pix, xv);
+#pragma unroll
+            for (int p = 0; p < VEC; ++p) acc[p] = ss::add_rn(acc[p], ss::mul_rn(xv[p], sample(yp, tp[p])));
+        }
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) acc[p] = acc[p] / (float)C;
+        store_vec<VEC>(out0 + (b * nd + j) * plane + pix, acc);
+        return;
+    }
+
+    float g[VEC];
+    if (MODE == MODE_CONCAT && gate != nullptr) load_vec<VEC>(gate + (b * nd + j) * plane + pix, g);
+    const int CO = (MODE == MODE_CONCAT) ? 2 * C : C;
+    for (int c = 0; c < C; ++c) {
+        const float* yp = y + (b * C + c) * plane;
+        float wv[VEC];
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) wv[p] = sample(yp, tp[p]);
+        if (MODE == MODE_WARP) {
+            store_vec<VEC>(out0 + ((b * CO + c) * nd + j) * plane + pix, wv);
+            if (out1 != nullptr) {
+                float xv[VEC];
+                load_vec<VEC>(x + (b * C + c) * plane + pix, xv);
+                store_vec<VEC>(out1 + ((b * CO + c) * nd + j) * plane + pix, xv);
+            }
+        } else {
+            float xv[VEC];
+            load_vec<VEC>(x + (b * C + c) * plane + pix, xv);
+            if (gate != nullptr) {
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) { xv[p] = ss::mul_rn(g[p], xv[p]); wv[p] = ss::mul_rn(g[p], wv[p]); }
+            }
+            store_vec<VEC>(out0 + ((b * CO + c) * nd + j) * plane + pix, xv);
+            store_vec<VEC>(out0 + ((b * CO + C + c) * nd + j) * plane + pix, wv);
+        }
+    }
+}
+
+template <int MODE>
+int launch(const float* x, const float* y, const float* disp, const float* gate, float* out0, float* out1, int B,
+           int C, int H, int W, int nd, hipStream_t st) {
+    // the reference divides by the Python float (W-1)/2 computed in double; cast once to fp32
+    const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
+    uintptr_t bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(disp) |
+                     reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1) |
+                     reinterpret_cast<uintptr_t>(gate);
+    const bool v4 = (W % 4 == 0) && ((bits & 15) == 0);
+    const long long total = (long long)B * nd * H * (v4 ? W / 4 : W);
+    const long long blocks = ss::ceil_div_ll(total, 256);
+    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    if (v4)
+        hipLaunchKernelGGL((warp_kernel<MODE, 4>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, disp, gate, out0,
+                           out1, C, H, W, nd, half_w, half_h, total);
+    else
+        hipLaunchKernelGGL((warp_kernel<MODE, 1>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, disp, gate, out0,
+                           out1, C, H, W, nd, half_w, half_h, total);
+    return ss::check_launch();
+}
+
+}  // namespace
+
+extern "C" int ss_warp_sampled_fwd(const float* x, const float* y, const float* disp, float* y_warped,
+                                   float* x_warped, int B, int C, int H, int W, int nd, ss_stream_t stream) {
+    SS_REQUIRE(x && y && disp && y_warped);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nd > 0);
+    return launch<MODE_WARP>(x, y, disp, nullptr, y_warped, x_warped, B, C, H, W, nd, ss::as_stream(stream));
+}
+
+extern "C" int ss_concat_sampled_fwd(const float* left, const float* right, const float* disp, const float* att,
+                                     float* out, int B, int C, int H, int W, int nd, ss_stream_t stream) {
+    SS_REQUIRE(left && right && disp && out);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nd > 0);
+    return launch<MODE_CONCAT>(left, right, disp, att, out, nullptr, B, C, H, W, nd, ss::as_stream(stream));
+}
+
+extern "C" int ss_warp_correlation_fwd(const float* x, const float* y, const float* disp, float* out, int B, int C,
+                                       int H, int W, int nd, ss_stream_t stream) {
+    SS_REQUIRE(x && y && disp && out);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nd > 0);
+    return launch<MODE_CORR>(x, y, disp, nullptr, out, nullptr, B, C, H, W, nd, ss::as_stream(stream));
+}

@@ -1,0 +1,219 @@
+// Windowed multi-head self-attention of the hourglass bottleneck (gfx950).
+//
+// Replaces attention_block.forward (reference models/submodule_other.py:790-837): zero-pad H, W
+// to window multiples, partition [B,C,D,H,W] into (bd,bh,bw) windows of T tokens, qkv =
+// Linear(C -> 3C), 16 heads x 8 dims, softmax(q k^T / sqrt(8) [+ pad mask]) v, un-partition, crop,
+// 1x1x1 conv C -> C with bias.  The reference does this with 8-D permute copies, a batched GEMM
+// per step and a materialised [windows, heads, T, T] logits tensor.
+//
+// Here one workgroup owns one window and never leaves the CU: the window's tokens are parked
+// channel-major in LDS ([C][T], the natural NCDHW order); per group of 4 heads the q/k/v slab
+// [96][T] is produced by fp32 MFMA (M = features, weights streamed from L2, N = tokens from LDS),
+// the 4 heads' attention runs on the VALU with one (head, query) pair per lane and the softmax
+// row in registers, and the output projection is accumulated across head groups directly in MFMA
+// accumulators (out += Wout[:, group] * y_group), so the attended tokens never go back to HBM.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int HD = 8;      // head dim (C / heads)
+constexpr int HG = 4;      // heads per group -> 32 channels = one MFMA M-tile per q / k / v
+
+template <int T, int C>
+struct ACfg {
+    static constexpr int NTL = (T + 31) / 32;     // 32-token N tiles
+    static constexpr int TP = NTL * 32;           // padded token count
+    static constexpr int XS = C * TP;             // window tokens, channel-major
+    static constexpr int QKV = 3 * 32 * TP;       // q,k,v slab of one head group
+    static constexpr int YG = 32 * TP;            // attended channels of one head group
+    static constexpr int FLAGS = TP;              // pad flag per token
+    static constexpr size_t LDS_BYTES = (size_t)(XS + QKV + YG + FLAGS) * 4;
+};
+
+template <int T, int C>
+__global__ __launch_bounds__(256) void window_attention_kernel(
+    const float* __restrict__ x, const float* __restrict__ wqkv_t, const float* __restrict__ bqkv,
+    const float* __restrict__ wout_t, const float* __restrict__ bout, float* __restrict__ out, int D, int H, int W,
+    int bd, int bh, int bw, int nwh, int nww, int use_mask) {
+    using A = ACfg<T, C>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                 // [C][TP]
+    float* qkv = xs + A::XS;         // [3*32][TP]   rows 0-31 q, 32-63 k, 64-95 v of the current head group
+    float* yg = qkv + A::QKV;        // [32][TP]
+    float* flag = yg + A::YG;        // [TP]  1 = padded position (reference mask semantics)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    int wi = blockIdx.x;
+    const int ww = wi % nww; wi /= nww;
+    const int wh = wi % nwh; wi /= nwh;
+    const int wd = wi;
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    const float* xb = x + (size_t)b * C * vol;
+
+    // ---- phase 0: window tokens -> LDS (zeros at padded positions and in the N-tile tail) ----
+    for (int e = tid; e < C * A::TP; e += 256) {
+        const int t = e % A::TP, c = e / A::TP;
+        float v = 0.f;
+        if (t < T) {
+            const int iw = t % bw, ih = (t / bw) % bh, id = t / (bw * bh);
+            const int gw = ww * bw + iw, gh = wh * bh + ih, gd = wd * bd + id;
+            if (gh < H && gw < W) v = xb[(size_t)c * vol + (size_t)gd * plane + (size_t)gh * W + gw];
+        }
+        xs[e] = v;
+    }
+    for (int t = tid; t < A::TP; t += 256) {
+        float f = 0.f;
+        if (t < T) {
+            const int iw = t % bw, ih = (t / bw) % bh;
+            f = ((wh * bh + ih >= H) || (ww * bw + iw >= W)) ? 1.f : 0.f;
+        }
+        flag[t] = f;
+    }
+    __syncthreads();
+
+    // output-projection accumulators: this wave owns output channels [32*wave, 32*wave+32), all tokens
+    static_assert(C == 128, "4 waves x 32 output channels");
+    f32x16 oacc[A::NTL];
+#pragma unroll
+    for (int n = 0; n < A::NTL; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[n][r] = 0.f;
+
+    const float scale = 0.35355339059327379f;    // 8 ** -0.5, rounded to fp32 like the reference's Python float
+    constexpr int NGROUPS = C / (HG * HD);
+
+    for (int g = 0; g < NGROUPS; ++g) {
+        // ---- phase 1: q/k/v slab of this head group = W[rows] * X + bias, by MFMA ----
+        for (int u = wave; u < 3 * A::NTL; u += 4) {
+            const int mt = u / A::NTL, nt = u % A::NTL;        // mt: 0 = q, 1 = k, 2 = v
+            const int f0 = mt * C + g * 32;                    // first feature row of this tile
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = wqkv_t + (size_t)half * 3 * C + f0 + l31;
+            const float* bp = xs + half * A::TP + nt * 32 + l31;
+#pragma unroll 8
+            for (int kk = 0; kk < C; kk += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)kk * 3 * C], bp[kk * A::TP], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                qkv[(mt * 32 + row) * A::TP + nt * 32 + l31] = ss::add_rn(acc[r], bqkv[f0 + row]);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: attention of the group's 4 heads, one (head, query) pair per lane ----
+        for (int p = tid; p < HG * T; p += 256) {
+            const int h = p / T, i = p % T;
+            float q[HD];
+#pragma unroll
+            for (int e = 0; e < HD; ++e) q[e] = qkv[(h * HD + e) * A::TP + i];
+            const float fi = flag[i];
+            float s[T];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) d = fmaf(q[e], qkv[(32 + h * HD + e) * A::TP + j], d);
+                d = ss::mul_rn(d, scale);
+                if (use_mask && flag[j] != fi) d = ss::add_rn(d, -1000.0f);
+                s[j] = d;
+                mx = fmaxf(mx, d);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < T; ++j) { s[j] = expf(s[j] - mx); sum = ss::add_rn(sum, s[j]); }
+            float y[HD];
+#pragma unroll
+            for (int e = 0; e < HD; ++e) y[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const float pj = s[j] / sum;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) y[e] = fmaf(pj, qkv[(64 + h * HD + e) * A::TP + j], y[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < HD; ++e) yg[(h * HD + e) * A::TP + i] = y[e];
+        }
+        if (A::TP > T) {   // keep the N-tile tail finite (its columns are never stored)
+            for (int e = tid; e < 32 * (A::TP - T); e += 256) yg[(e / (A::TP - T)) * A::TP + T + e % (A::TP - T)] = 0.f;
+        }
+        __syncthreads();
+
+        // ---- phase 3: out += Wout[:, group channels] * y_group ----
+        {
+            const float* ap = wout_t + (size_t)(g * 32 + half) * C + wave * 32 + l31;
+            const float* bp = yg + half * A::TP + l31;
+#pragma unroll
+            for (int kk = 0; kk < 32; kk += 2) {
+                const float a = ap[(size_t)kk * C];
+#pragma unroll
+                for (int n = 0; n < A::NTL; ++n)
+                    oacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * A::TP + n * 32], oacc[n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias, un-partition, crop ----
+    float* ob = out + (size_t)b * C * vol;
+#pragma unroll
+    for (int n = 0; n < A::NTL; ++n) {
+        const int t = n * 32 + l31;
+        if (t >= T) continue;
+        const int iw = t % bw, ih = (t / bw) % bh, id = t / (bw * bh);
+        const int gw = ww * bw + iw, gh = wh * bh + ih, gd = wd * bd + id;
+        if (gh >= H || gw >= W) continue;
+        const size_t pos = (size_t)gd * plane + (size_t)gh * W + gw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            ob[(size_t)co * vol + pos] = ss::add_rn(oacc[n][r], bout[co]);
+        }
+    }
+}
+
+template <int T>
+int launch_attn(const float* x, const float* wqkv_t, const float* bqkv, const float* wout_t, const float* bout,
+                float* out, int B, int D, int H, int W, int bd, int bh, int bw, hipStream_t st) {
+    using A = ACfg<T, 128>;
+    const int nwd = D / bd, nwh = ss::ceil_div(H, bh), nww = ss::ceil_div(W, bw);
+    // reference quirk (models/submodule_other.py:822-823): the mask only separates pad from real
+    // tokens when BOTH H and W need padding ("-0:" selects everything otherwise).
+    const int use_mask = (H % bh != 0) && (W % bw != 0);
+    auto kern = window_attention_kernel<T, 128>;
+    if (A::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)A::LDS_BYTES);
+        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+    }
+    const long long nwin = (long long)nwd * nwh * nww;
+    if (nwin > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwin, B), dim3(256), A::LDS_BYTES, st, x, wqkv_t, bqkv, wout_t, bout, out, D,
+                       H, W, bd, bh, bw, nwh, nww, use_mask);
+    return ss::check_launch();
+}
+
+}  // namespace
+
+extern "C" int ss_window_attention_fwd(const float* x, const float* wqkv_t, const float* bqkv, const float* wout_t,
+                                       const float* bout, float* out, int B, int C, int D, int H, int W, int heads,
+                                       int bd, int bh, int bw, ss_stream_t stream) {
+    SS_REQUIRE(x && wqkv_t && bqkv && wout_t && bout && out);
+    SS_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && heads > 0 && bd > 0 && bh > 0 && bw > 0);
+    SS_REQUIRE(D % bd == 0);
+    if (C != 128 || heads != 16) return SS_ERR_UNSUPPORTED;
+    const int T = bd * bh * bw;
+    hipStream_t st = ss::as_stream(stream);
+    if (T == 64) return launch_attn<64>(x, wqkv_t, bqkv, wout_t, bout, out, B, D, H, W, bd, bh, bw, st);
+    if (T == 96) return launch_attn<96>(x, wqkv_t, bqkv, wout_t, bout, out, B, D, H, W, bd, bh, bw, st);
+    return SS_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,442 @@
+"""nn.Module replacements for the 3-D aggregation stack on the hot path, with the SAME
+attribute structure and state_dict keys/shapes as the reference, so its checkpoints load:
+
+  convbn_3d          models/submodule_other.py:845-848
+  attention_block    models/submodule_other.py:790-837
+  BasicConv          models/submodule.py:89-116
+  hourglass          models/SemStereo.py:106-143      (window (4,4,4))
+  hourglass2         models/SemStereo.py:145-182      (window (6,4,4))
+  channelAtt         models/SemStereo.py:89-103
+  Classifier         the nn.Sequential(convbn_3d, ReLU, Conv3d) heads, models/SemStereo.py:228-234
+  DepthwisePatch     the `patch` nn.Conv3d, models/SemStereo.py:219
+
+The torch layers inside (nn.Conv3d, nn.BatchNorm3d, ...) are parameter containers: in inference
+(`eval()` and no autograd) forward() runs the gfx950 kernels with BatchNorm folded into the
+accumulator epilogue.  In training (batch statistics, autograd) forward() uses the stock PyTorch
+layers on the GPU -- the HIP stack is an inference path; PATH_COUNTS records which one ran.
+`X.adopt(ref_module)` wraps an instance built by the REFERENCE's own classes, sharing its
+parameters (this is what `semstereo_amd.install.accelerate` uses).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import call, ptr
+
+PATH_COUNTS = {"hip": 0, "torch": 0}
+
+
+def _inference(module, *tensors):
+    """True when the folded-BN HIP path is valid: eval mode and nothing needs autograd."""
+    if module.training:
+        return False
+    if torch.is_grad_enabled():
+        if any(t is not None and t.requires_grad for t in tensors):
+            return False
+        if any(p.requires_grad for p in module.parameters()):
+            return False
+    return True
+
+
+class _ParamCache:
+    """Derived device tensors (packed weights, folded affines), rebuilt when a source tensor changes."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, sources, build):
+        stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in sources)
+        hit = self._store.get(key)
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                hit = (stamp, build())
+            self._store[key] = hit
+        return hit[1]
+
+
+def _cache(module):
+    c = module.__dict__.get("_ss_cache")
+    if c is None:
+        c = module.__dict__["_ss_cache"] = _ParamCache()
+    return c
+
+
+def fold_bn(bn):
+    """eval-mode BatchNorm as y = x*scale + shift (the same two-step form ATen's inference path uses)."""
+    invstd = 1.0 / torch.sqrt(bn.running_var + bn.eps)
+    scale = (bn.weight * invstd) if bn.weight is not None else invstd
+    shift = (bn.bias if bn.bias is not None else 0.0) - bn.running_mean * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+def pack_conv_weight(w, transposed=False):
+    """[Cout,Cin,k,k,k] (or ConvTranspose3d's [Cin,Cout,k,k,k]) -> [Cin][k^3][Cout] on the device."""
+    w = w.detach().float().contiguous()
+    _lib.require_device(w)
+    if transposed:
+        Cin, Cout, k = w.shape[0], w.shape[1], w.shape[2]
+    else:
+        Cout, Cin, k = w.shape[0], w.shape[1], w.shape[2]
+    assert w.shape[2] == w.shape[3] == w.shape[4], "cubic kernels only"
+    out = torch.empty((Cin, k * k * k, Cout), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        call("ss_pack_conv3d_weights", ptr(w), ptr(out), Cout, Cin, k, int(transposed))
+    return out
+
+
+def conv3d_hip(x, wpack, scale, shift, k, stride, relu, residual=None):
+    """Conv3d(bias=False, pad=k//2) + per-channel affine + optional residual + optional ReLU."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, wpack, scale, shift, residual)
+    B, Cin, D, H, W = x.shape
+    assert wpack.shape[0] == Cin and wpack.shape[1] == k ** 3
+    Cout = wpack.shape[2]
+    pad = k // 2
+    Do, Ho, Wo = [(n + 2 * pad - k) // stride + 1 for n in (D, H, W)]
+    out = torch.empty((B, Cout, Do, Ho, Wo), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    with torch.cuda.device(dev):
+        call("ss_conv3d_fwd", ptr(x), ptr(wpack), ptr(scale), ptr(shift), ptr(residual), ptr(out),
+             B, Cin, D, H, W, Cout, k, stride, int(relu))
+    return out
+
+
+def deconv3d_hip(x, wpack, shift, relu, skip=None, skip_wpack=None):
+    """ConvTranspose3d(k3,s2,p1,op1) [+ 1x1x1 projection of `skip`] + shift + optional ReLU.
+    Per-branch BN scales are expected to be folded into the packed weights already."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, wpack, shift, skip, skip_wpack)
+    B, Cin, D, H, W = x.shape
+    Cout = wpack.shape[2]
+    out = torch.empty((B, Cout, 2 * D, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+    Cs = 0
+    if skip is not None:
+        skip = skip if skip.is_contiguous() else skip.contiguous()
+        Cs = skip.shape[1]
+        assert skip.shape == (B, Cs, 2 * D, 2 * H, 2 * W) and skip_wpack.shape == (Cs, Cout)
+    with torch.cuda.device(dev):
+        call("ss_deconv3d_fwd", ptr(x), ptr(wpack), None, ptr(shift), ptr(skip), ptr(skip_wpack), None, None,
+             ptr(out), B, Cin, D, H, W, Cout, Cs, int(relu))
+    return out
+
+
+def _convbn_params(owner, key, conv, bn):
+    """(wpack, scale, shift) of a Conv3d(+BN) pair, cached on `owner`."""
+    srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+    def build():
+        wp = pack_conv_weight(conv.weight)
+        if bn is None:
+            return wp, None, None
+        s, b = fold_bn(bn)
+        return wp, s, b
+    return _cache(owner).get(key, srcs, build)
+
+
+def _conv_geometry(conv):
+    k, s, p = conv.kernel_size, conv.stride, conv.padding
+    assert k[0] == k[1] == k[2] and s[0] == s[1] == s[2] and p[0] == p[1] == p[2] == k[0] // 2
+    assert conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1, 1)
+    return k[0], s[0]
+
+
+def run_convbn(owner, key, conv, bn, x, relu, residual=None):
+    """Fused Conv3d -> BN(eval) [-> +residual] [-> ReLU] through ss_conv3d_fwd."""
+    k, s = _conv_geometry(conv)
+    wp, scale, shift = _convbn_params(owner, key, conv, bn)
+    return conv3d_hip(x, wp, scale, shift, k, s, relu, residual)
+
+
+# --------------------------------------------------------------------------------------
+# building blocks with the reference's names
+# --------------------------------------------------------------------------------------
+
+class _ConvBN3d(nn.Sequential):
+    """nn.Sequential(Conv3d(bias=False), BatchNorm3d): keys `0.weight`, `1.*`."""
+
+    def forward(self, x):
+        if _inference(self, x):
+            PATH_COUNTS["hip"] += 1
+            return run_convbn(self, "cb", self[0], self[1], x, relu=False)
+        PATH_COUNTS["torch"] += 1
+        return super().forward(x)
+
+
+def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
+    """Same factory signature as the reference's convbn_3d."""
+    return _ConvBN3d(nn.Conv3d(in_planes, out_planes, kernel_size=kernel_size, padding=pad, stride=stride, bias=False),
+                     nn.BatchNorm3d(out_planes))
+
+
+class BasicConv(nn.Module):
+    """conv (no bias) -> BN -> ReLU, 2-D or 3-D, optional deconv; keys `conv.weight`, `bn.*`.
+    Only the 3-D, non-transposed form is on the hot path (concat_stem) and runs the HIP kernel; the
+    2-D forms (channelAtt, concat_feature) stay on PyTorch/MIOpen as in the reference."""
+
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, bn=True, relu=True, **kwargs):
+        super().__init__()
+        self.relu = relu
+        self.use_bn = bn
+        self.is_3d = is_3d
+        self.deconv = deconv
+        if is_3d:
+            layer = nn.ConvTranspose3d if deconv else nn.Conv3d
+            self.conv = layer(in_channels, out_channels, bias=False, **kwargs)
+            self.bn = nn.BatchNorm3d(out_channels)
+        else:
+            layer = nn.ConvTranspose2d if deconv else nn.Conv2d
+            self.conv = layer(in_channels, out_channels, bias=False, **kwargs)
+            self.bn = nn.BatchNorm2d(out_channels)
+
+    @classmethod
+    def adopt(cls, ref):
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.relu, self.use_bn = ref.relu, ref.use_bn
+        self.conv, self.bn = ref.conv, ref.bn
+        self.is_3d = isinstance(ref.conv, (nn.Conv3d, nn.ConvTranspose3d))
+        self.deconv = isinstance(ref.conv, (nn.ConvTranspose2d, nn.ConvTranspose3d))
+        self.train(ref.training)
+        return self
+
+    def forward(self, x):
+        if self.is_3d and not self.deconv and _inference(self, x):
+            PATH_COUNTS["hip"] += 1
+            return run_convbn(self, "bc", self.conv, self.bn if self.use_bn else None, x, relu=bool(self.relu))
+        if self.is_3d:
+            PATH_COUNTS["torch"] += 1
+        x = self.conv(x)
+        if self.use_bn:
+            x = self.bn(x)
+        if self.relu:
+            x = F.relu(x)
+        return x
+
+
+class attention_block(nn.Module):
+    """Windowed multi-head self-attention + 1x1x1 conv; keys `qkv_3d.*`, `final1x1.*`."""
+
+    def __init__(self, channels_3d, num_heads=8, block=4):
+        super().__init__()
+        self.block = block
+        self.dim_3d = channels_3d
+        self.num_heads = num_heads
+        self.scale_3d = (channels_3d // num_heads) ** -0.5
+        self.qkv_3d = nn.Linear(channels_3d, channels_3d * 3, bias=True)
+        self.final1x1 = nn.Conv3d(channels_3d, channels_3d, 1)
+
+    @classmethod
+    def adopt(cls, ref):
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.block, self.dim_3d, self.num_heads, self.scale_3d = ref.block, ref.dim_3d, ref.num_heads, ref.scale_3d
+        self.qkv_3d, self.final1x1 = ref.qkv_3d, ref.final1x1
+        self.train(ref.training)
+        return self
+
+    def _params(self):
+        srcs = [self.qkv_3d.weight, self.qkv_3d.bias, self.final1x1.weight, self.final1x1.bias]
+
+        def build():
+            C = self.dim_3d
+            return (self.qkv_3d.weight.detach().float().t().contiguous(),            # [C][3C]
+                    self.qkv_3d.bias.detach().float().contiguous(),
+                    self.final1x1.weight.detach().float().reshape(C, C).t().contiguous(),  # [Cin][Cout]
+                    self.final1x1.bias.detach().float().contiguous())
+        return _cache(self).get("attn", srcs, build)
+
+    def forward(self, x):
+        if _inference(self, x):
+            PATH_COUNTS["hip"] += 1
+            x = x if x.is_contiguous() else x.contiguous()
+            dev = _lib.require_device(x)
+            B, C, D, H, W = x.shape
+            assert C == self.dim_3d and D % self.block[0] == 0
+            wq, bq, wo, bo = self._params()
+            out = torch.empty_like(x)
+            with torch.cuda.device(dev):
+                call("ss_window_attention_fwd", ptr(x), ptr(wq), ptr(bq), ptr(wo), ptr(bo), ptr(out),
+                     B, C, D, H, W, self.num_heads, self.block[0], self.block[1], self.block[2])
+            return out
+        PATH_COUNTS["torch"] += 1
+        return self._forward_torch(x)
+
+    def _forward_torch(self, x):
+        """Training path: the same computation with autograd-visible PyTorch ops."""
+        B, C, D, H0, W0 = x.shape
+        bd, bh, bw = self.block
+        pad_r, pad_b = (bw - W0 % bw) % bw, (bh - H0 % bh) % bh
+        x = F.pad(x, (0, pad_r, 0, pad_b))
+        H, W = H0 + pad_b, W0 + pad_r
+        nd, nh, nw = D // bd, H // bh, W // bw
+        T, hd = bd * bh * bw, C // self.num_heads
+        tok = x.reshape(B, C, nd, bd, nh, bh, nw, bw).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(B, nd * nh * nw, T, C)
+        qkv = self.qkv_3d(tok).reshape(B, nd * nh * nw, T, 3, self.num_heads, hd).permute(3, 0, 1, 4, 2, 5)
+        logits = (qkv[0] @ qkv[1].transpose(-2, -1)) * self.scale_3d
+        if pad_r > 0 and pad_b > 0:      # see window_attention.hip for why both are required
+            hh = torch.arange(H, device=x.device).reshape(H, 1) >= H0
+            wwf = torch.arange(W, device=x.device).reshape(1, W) >= W0
+            flag = (hh | wwf).reshape(nh, bh, nw, bw).permute(0, 2, 1, 3).reshape(nh * nw, bh * bw)
+            differs = (flag.unsqueeze(1) != flag.unsqueeze(2)).to(x.dtype) * -1000.0
+            logits = logits + differs.repeat(nd, bd, bd).reshape(1, nd * nh * nw, 1, T, T)
+        y = torch.softmax(logits, dim=-1) @ qkv[2]
+        y = y.reshape(B, nd, nh, nw, self.num_heads, bd, bh, bw, hd).permute(0, 4, 8, 1, 5, 2, 6, 3, 7)
+        y = y.reshape(B, C, D, H, W)[:, :, :, :H0, :W0]
+        return self.final1x1(y)
+
+
+class hourglass(nn.Module):
+    """Two stride-2 conv stages, windowed attention, two transposed-conv stages with 1x1x1 skips."""
+    BLOCK = (4, 4, 4)
+
+    def __init__(self, in_channels):
+        super().__init__()
+        c = in_channels
+        self.conv1 = nn.Sequential(convbn_3d(c, c * 2, 3, 2, 1), nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(convbn_3d(c * 2, c * 2, 3, 1, 1), nn.ReLU(inplace=True))
+        self.conv3 = nn.Sequential(convbn_3d(c * 2, c * 4, 3, 2, 1), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(convbn_3d(c * 4, c * 4, 3, 1, 1), nn.ReLU(inplace=True))
+        self.attention_block = attention_block(channels_3d=c * 4, num_heads=16, block=self.BLOCK)
+        self.conv5 = nn.Sequential(
+            nn.ConvTranspose3d(c * 4, c * 2, 3, padding=1, output_padding=1, stride=2, bias=False), nn.BatchNorm3d(c * 2))
+        self.conv6 = nn.Sequential(
+            nn.ConvTranspose3d(c * 2, c, 3, padding=1, output_padding=1, stride=2, bias=False), nn.BatchNorm3d(c))
+        self.redir1 = convbn_3d(c, c, kernel_size=1, stride=1, pad=0)
+        self.redir2 = convbn_3d(c * 2, c * 2, kernel_size=1, stride=1, pad=0)
+
+    @classmethod
+    def adopt(cls, ref):
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        for name in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "redir1", "redir2"):
+            setattr(self, name, getattr(ref, name))
+        self.attention_block = attention_block.adopt(ref.attention_block)
+        self.train(ref.training)
+        return self
+
+    def _up_params(self, key, deconv_seq, redir_seq):
+        """Transposed conv + BN and the 1x1x1 skip conv + BN share one accumulator, so both BN scales
+        are folded into the packed weights and the shifts are summed."""
+        dc, dbn, rc, rbn = deconv_seq[0], deconv_seq[1], redir_seq[0], redir_seq[1]
+        srcs = [dc.weight, dbn.weight, dbn.bias, dbn.running_mean, dbn.running_var,
+                rc.weight, rbn.weight, rbn.bias, rbn.running_mean, rbn.running_var]
+
+        def build():
+            ds, db = fold_bn(dbn)
+            rs, rb = fold_bn(rbn)
+            wd = pack_conv_weight(dc.weight, transposed=True) * ds.reshape(1, 1, -1)
+            wr = pack_conv_weight(rc.weight).reshape(rc.weight.shape[1], rc.weight.shape[0]) * rs.reshape(1, -1)
+            return wd.contiguous(), wr.contiguous(), (db + rb).contiguous()
+        return _cache(self).get(key, srcs, build)
+
+    def forward(self, x):
+        if not _inference(self, x):
+            PATH_COUNTS["torch"] += 1
+            conv1 = self.conv1(x)
+            conv2 = self.conv2(conv1)
+            conv3 = self.conv3(conv2)
+            conv4 = self.attention_block(self.conv4(conv3))
+            conv5 = F.relu(self.conv5(conv4) + self.redir2(conv2))
+            return F.relu(self.conv6(conv5) + self.redir1(x))
+        PATH_COUNTS["hip"] += 1
+        c1 = run_convbn(self, "c1", self.conv1[0][0], self.conv1[0][1], x, relu=True)
+        c2 = run_convbn(self, "c2", self.conv2[0][0], self.conv2[0][1], c1, relu=True)
+        c3 = run_convbn(self, "c3", self.conv3[0][0], self.conv3[0][1], c2, relu=True)
+        c4 = run_convbn(self, "c4", self.conv4[0][0], self.conv4[0][1], c3, relu=True)
+        c4 = self.attention_block(c4)
+        w5, r2, s5 = self._up_params("u5", self.conv5, self.redir2)
+        c5 = deconv3d_hip(c4, w5, s5, relu=True, skip=c2, skip_wpack=r2)
+        w6, r1, s6 = self._up_params("u6", self.conv6, self.redir1)
+        return deconv3d_hip(c5, w6, s6, relu=True, skip=x, skip_wpack=r1)
+
+
+class hourglass2(hourglass):
+    """models/SemStereo.py:145-182: identical topology, attention window (6,4,4)."""
+    BLOCK = (6, 4, 4)
+
+
+class Classifier(nn.Sequential):
+    """nn.Sequential(convbn_3d(c,c,3,1,1), ReLU, Conv3d(c,1,3,p1,bias=False)): keys `0.0.weight`,
+    `0.1.*`, `2.weight` (the `classif` / `classif_att_` heads)."""
+
+    def __init__(self, channels=32):
+        super().__init__(convbn_3d(channels, channels, 3, 1, 1), nn.ReLU(inplace=True),
+                         nn.Conv3d(channels, 1, kernel_size=3, padding=1, stride=1, bias=False))
+
+    @classmethod
+    def adopt(cls, ref):
+        self = cls.__new__(cls)
+        nn.Sequential.__init__(self, ref[0], ref[1], ref[2])
+        self.train(ref.training)
+        return self
+
+    def forward(self, x):
+        if _inference(self, x):
+            PATH_COUNTS["hip"] += 1
+            y = run_convbn(self, "h0", self[0][0], self[0][1], x, relu=True)
+            return run_convbn(self, "h2", self[2], None, y, relu=False)
+        PATH_COUNTS["torch"] += 1
+        return super().forward(x)
+
+
+class DepthwisePatch(nn.Conv3d):
+    """`patch`: depthwise Conv3d kernel (1,3,3), pad (0,1,1), no bias; key `weight` [C,1,1,3,3]."""
+
+    def __init__(self, channels):
+        super().__init__(channels, channels, kernel_size=(1, 3, 3), stride=1, dilation=1, groups=channels,
+                         padding=(0, 1, 1), bias=False)
+
+    @classmethod
+    def adopt(cls, ref):
+        assert ref.kernel_size == (1, 3, 3) and ref.groups == ref.in_channels and ref.bias is None
+        self = cls.__new__(cls)
+        self.__dict__.update(ref.__dict__)          # same Parameter objects, same hyper-parameters
+        return self
+
+    def forward(self, x, gate_logits=None):
+        """gate_logits [B,C,H,W]: fuses the channelAtt gate that follows `patch` in the model."""
+        if _inference(self, x, gate_logits):
+            PATH_COUNTS["hip"] += 1
+            x = x if x.is_contiguous() else x.contiguous()
+            dev = _lib.require_device(x, gate_logits)
+            B, C, D, H, W = x.shape
+            w = self.weight.detach()
+            out = torch.empty_like(x)
+            g = None if gate_logits is None else gate_logits.contiguous()
+            with torch.cuda.device(dev):
+                call("ss_depthwise_patch_fwd", ptr(x), ptr(w), ptr(g), ptr(out), B, C, D, H, W)
+            return out
+        PATH_COUNTS["torch"] += 1
+        y = super().forward(x)
+        return y if gate_logits is None else torch.sigmoid(gate_logits).unsqueeze(2) * y
+
+
+class channelAtt(nn.Module):
+    """sigmoid(conv1x1(BN-ReLU(conv1x1(im)))) broadcast over D, times the volume; keys `im_att.*`.
+    The two 1x1 2-D convs on the image features stay on PyTorch; the volume gating is the HIP kernel."""
+
+    def __init__(self, cv_chan, im_chan):
+        super().__init__()
+        self.im_att = nn.Sequential(BasicConv(im_chan, im_chan // 2, kernel_size=1, stride=1, padding=0),
+                                    nn.Conv2d(im_chan // 2, cv_chan, 1))
+
+    @classmethod
+    def adopt(cls, ref):
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.im_att = ref.im_att
+        self.train(ref.training)
+        return self
+
+    def logits(self, im):
+        return self.im_att(im)
+
+    def forward(self, cv, im):
+        att = self.im_att(im)
+        if _inference(self, cv, im):
+            PATH_COUNTS["hip"] += 1
+            return ops.channel_gate(att, cv)
+        PATH_COUNTS["torch"] += 1
+        return torch.sigmoid(att.unsqueeze(2)) * cv

@@ -1,0 +1,371 @@
+"""Drop-in replacements for the hot-path callables of the reference's op library
+(/root/reference/models/submodule.py), same names and positional signatures,
+backed by the gfx950 kernels of libsemstereo_hip.so.
+
+Each public function documents the reference callable it replaces.  Inputs must
+be fp32 tensors on an MI355X; CPU tensors raise (there is no fallback path).
+Preconditions the reference asserts raise AssertionError here too.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import call, ptr
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+# --------------------------------------------------------------------------------------
+# group-wise correlation volume
+# --------------------------------------------------------------------------------------
+
+def _gwc_forward(ref, tgt, maxdisp, groups, normalize):
+    dev = _lib.require_device(ref, tgt)
+    B, C, H, W = ref.shape
+    out = torch.empty((B, groups, 2 * maxdisp, H, W), dtype=ref.dtype, device=ref.device)
+    if out.numel():
+        with torch.cuda.device(dev):
+            call("ss_gwc_volume_fwd", ptr(ref), ptr(tgt), ptr(out), B, C, H, W, maxdisp, groups, int(normalize))
+    return out
+
+
+class _GwcVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref, tgt, maxdisp, groups):
+        ref, tgt = _c(ref), _c(tgt)
+        ctx.save_for_backward(ref, tgt)
+        ctx.cfg = (maxdisp, groups)
+        return _gwc_forward(ref, tgt, maxdisp, groups, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        ref, tgt = ctx.saved_tensors
+        maxdisp, groups = ctx.cfg
+        g = _c(g)
+        B, C, H, W = ref.shape
+        gref, gtgt = torch.empty_like(ref), torch.empty_like(tgt)
+        with torch.cuda.device(ref.device):
+            call("ss_gwc_volume_bwd", ptr(g), ptr(ref), ptr(tgt), ptr(gref), ptr(gtgt), B, C, H, W, maxdisp, groups)
+        return gref, gtgt, None, None
+
+
+def _check_pair(a, b, groups=None):
+    assert a.dim() == 4 and a.shape == b.shape, "feature maps must be [B,C,H,W] of equal shape"
+    if groups is not None:
+        assert a.shape[1] % groups == 0
+
+
+def _group_normalise(x, groups):
+    """x / (||x||_2 over each group's channels + 1e-5) with differentiable torch ops (training path)."""
+    B, C, H, W = x.shape
+    v = x.reshape(B, groups, C // groups, H, W)
+    return (v / (torch.linalg.vector_norm(v, 2, dim=2, keepdim=True) + 1e-05)).reshape(B, C, H, W)
+
+
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """models/submodule.py:198-211 -> [B, G, 2*maxdisp, H, W] (signed disparity range)."""
+    _check_pair(refimg_fea, targetimg_fea, num_groups)
+    if _needs_grad(refimg_fea, targetimg_fea):
+        return _GwcVolume.apply(refimg_fea, targetimg_fea, int(maxdisp), int(num_groups))
+    return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), int(maxdisp), int(num_groups), False)
+
+
+def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """models/submodule.py:224-238 (the live call, models/SemStereo.py:273)."""
+    _check_pair(refimg_fea, targetimg_fea, num_groups)
+    if _needs_grad(refimg_fea, targetimg_fea):
+        # normalise once with autograd-visible ops, then the volume kernel with its HIP backward
+        return _GwcVolume.apply(_group_normalise(refimg_fea, num_groups), _group_normalise(targetimg_fea, num_groups),
+                                int(maxdisp), int(num_groups))
+    return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), int(maxdisp), int(num_groups), True)
+
+
+def _group_corr(fea1, fea2, groups, normalize):
+    _check_pair(fea1, fea2, groups)
+    if _needs_grad(fea1, fea2):
+        if normalize:
+            fea1, fea2 = _group_normalise(fea1, groups), _group_normalise(fea2, groups)
+        B, C, H, W = fea1.shape
+        return (fea1 * fea2).reshape(B, groups, C // groups, H, W).mean(dim=2)
+    fea1, fea2 = _c(fea1), _c(fea2)
+    dev = _lib.require_device(fea1, fea2)
+    B, C, H, W = fea1.shape
+    out = torch.empty((B, groups, H, W), dtype=fea1.dtype, device=fea1.device)
+    if out.numel():
+        with torch.cuda.device(dev):
+            call("ss_groupwise_correlation_fwd", ptr(fea1), ptr(fea2), ptr(out), B, C, H, W, groups, int(normalize))
+    return out
+
+
+def groupwise_correlation(fea1, fea2, num_groups):
+    """models/submodule.py:190-196 -> [B, G, H, W]."""
+    return _group_corr(fea1, fea2, int(num_groups), False)
+
+
+def groupwise_correlation_norm(fea1, fea2, num_groups):
+    """models/submodule.py:213-221 -> [B, G, H, W]."""
+    return _group_corr(fea1, fea2, int(num_groups), True)
+
+
+# --------------------------------------------------------------------------------------
+# dense concat volume
+# --------------------------------------------------------------------------------------
+
+class _ConcatVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref, tgt, maxdisp):
+        ref, tgt = _c(ref), _c(tgt)
+        dev = _lib.require_device(ref, tgt)
+        B, C, H, W = ref.shape
+        ctx.cfg = (B, C, H, W, maxdisp)
+        out = torch.empty((B, 2 * C, 2 * maxdisp, H, W), dtype=ref.dtype, device=ref.device)
+        if out.numel():
+            with torch.cuda.device(dev):
+                call("ss_concat_volume_fwd", ptr(ref), ptr(tgt), ptr(out), B, C, H, W, maxdisp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W, maxdisp = ctx.cfg
+        g = _c(g)
+        gref = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device)
+        gtgt = torch.empty_like(gref)
+        with torch.cuda.device(g.device):
+            call("ss_concat_volume_bwd", ptr(g), ptr(gref), ptr(gtgt), B, C, H, W, maxdisp)
+        return gref, gtgt, None
+
+
+def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
+    """models/submodule.py:173-187 -> [B, 2C, 2*maxdisp, H, W]."""
+    _check_pair(refimg_fea, targetimg_fea)
+    return _ConcatVolume.apply(refimg_fea, targetimg_fea, int(maxdisp))
+
+
+# --------------------------------------------------------------------------------------
+# regressions
+# --------------------------------------------------------------------------------------
+
+class _DisparityRegression(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, maxdisp):
+        x = _c(x)
+        dev = _lib.require_device(x)
+        B, D, H, W = x.shape
+        ctx.cfg = (B, H, W, maxdisp)
+        out = torch.empty((B, H, W), dtype=x.dtype, device=x.device)
+        if out.numel():
+            with torch.cuda.device(dev):
+                call("ss_disparity_regression_fwd", ptr(x), ptr(out), B, maxdisp, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, maxdisp = ctx.cfg
+        g = _c(g)
+        gx = torch.empty((B, 2 * maxdisp, H, W), dtype=g.dtype, device=g.device)
+        with torch.cuda.device(g.device):
+            call("ss_disparity_regression_bwd", ptr(g), ptr(gx), B, maxdisp, H, W)
+        return gx, None
+
+
+def disparity_regression(x, maxdisp):
+    """models/submodule.py:164-170: [B, 2*maxdisp, H, W] -> [B, H, W]."""
+    assert len(x.shape) == 4
+    assert x.shape[1] == 2 * maxdisp, "the disparity axis must span [-maxdisp, maxdisp)"
+    return _DisparityRegression.apply(x, int(maxdisp))
+
+
+class _DisparityVariance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, disparity, maxdisp):
+        x, disparity = _c(x), _c(disparity)
+        dev = _lib.require_device(x, disparity)
+        B, D, H, W = x.shape
+        ctx.save_for_backward(x, disparity)
+        ctx.maxdisp = maxdisp
+        out = torch.empty((B, 1, H, W), dtype=x.dtype, device=x.device)
+        if out.numel():
+            with torch.cuda.device(dev):
+                call("ss_disparity_variance_fwd", ptr(x), ptr(disparity), ptr(out), B, maxdisp, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, disparity = ctx.saved_tensors
+        m = ctx.maxdisp
+        dv = torch.arange(-m, m, dtype=x.dtype, device=x.device).reshape(1, 2 * m, 1, 1) - disparity
+        gx = g * dv * dv
+        gd = (g * (x * dv).sum(dim=1, keepdim=True)) * -2.0
+        return gx, gd, None
+
+
+def disparity_variance(x, maxdisp, disparity):
+    """models/submodule.py:257-263: x [B,2m,H,W], disparity [B,1,H,W] -> [B,1,H,W]."""
+    assert len(x.shape) == 4
+    assert x.shape[1] == 2 * maxdisp and disparity.shape == (x.shape[0], 1, x.shape[2], x.shape[3])
+    return _DisparityVariance.apply(x, disparity, int(maxdisp))
+
+
+def softmax_regression(logits, maxdisp, want_prob=False):
+    """Fused models/SemStereo.py:281-285: softmax over the disparity axis, its expectation and its
+    variance in one kernel.  logits [B,2m,H,W] -> (disp [B,H,W], var [B,1,H,W], prob or None).
+    Inference only."""
+    logits = _c(logits)
+    dev = _lib.require_device(logits)
+    B, D, H, W = logits.shape
+    assert D == 2 * maxdisp
+    disp = torch.empty((B, H, W), dtype=logits.dtype, device=logits.device)
+    var = torch.empty((B, 1, H, W), dtype=logits.dtype, device=logits.device)
+    prob = torch.empty_like(logits) if want_prob else None
+    with torch.cuda.device(dev):
+        call("ss_softmax_regression_fwd", ptr(logits), ptr(prob), ptr(disp), ptr(var), B, int(maxdisp), H, W)
+    return disp, var, prob
+
+
+def _topk_reference_math(cost, disparity_samples, k):
+    _, ind = cost.sort(1, True, stable=True)
+    pool = ind[:, :k]
+    prob = F.softmax(torch.gather(cost, 1, pool), 1)
+    return torch.sum(torch.gather(disparity_samples, 1, pool) * prob, dim=1, keepdim=True)
+
+
+class _RegressionTopk(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, samples, k):
+        cost, samples = _c(cost), _c(samples)
+        dev = _lib.require_device(cost, samples)
+        B, nd, H, W = cost.shape
+        ctx.save_for_backward(cost, samples)
+        ctx.k = k
+        out = torch.empty((B, 1, H, W), dtype=cost.dtype, device=cost.device)
+        if out.numel():
+            with torch.cuda.device(dev):
+                call("ss_regression_topk_fwd", ptr(cost), ptr(samples), ptr(out), B, nd, H, W, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cost, samples = ctx.saved_tensors
+        with torch.enable_grad():
+            c = cost.detach().requires_grad_(True)
+            s = samples.detach().requires_grad_(True)
+            y = _topk_reference_math(c, s, ctx.k)
+            gc, gs = torch.autograd.grad(y, (c, s), g)
+        return gc, gs, None
+
+
+def regression_topk(cost, disparity_samples, k):
+    """models/submodule.py:434-442: cost, samples [B,nd,H,W] -> [B,1,H,W].  Ties between equal
+    costs resolve to the lower candidate index (the reference's unstable sort leaves them open)."""
+    assert cost.dim() == 4 and cost.shape == disparity_samples.shape
+    k = int(k)
+    assert 1 <= k <= cost.shape[1]
+    if k > 32:
+        raise NotImplementedError("regression_topk: k > 32 is not built (the model uses k = 2)")
+    return _RegressionTopk.apply(cost, disparity_samples, k)
+
+
+# --------------------------------------------------------------------------------------
+# candidate warping
+# --------------------------------------------------------------------------------------
+
+def _warp_reference_math(x, y, disp):
+    """The reference's composition (meshgrid -> normalise -> grid_sample), used for BACKWARD only."""
+    B, C, H, W = y.shape
+    nd = disp.shape[1]
+    rows = torch.arange(H, dtype=x.dtype, device=x.device).reshape(1, 1, H, 1).expand(B, nd, H, W)
+    cols = torch.arange(W, dtype=x.dtype, device=x.device).reshape(1, 1, 1, W).expand(B, nd, H, W)
+    gx = (cols - disp) / ((W - 1.0) / 2.0) - 1.0
+    gy = rows / ((H - 1.0) / 2.0) - 1.0
+    grid = torch.stack([gx, gy], dim=4).reshape(B, nd * H, W, 2)
+    yw = F.grid_sample(y, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    return yw.reshape(B, C, nd, H, W)
+
+
+class _WarpSampled(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, disp):
+        x, y, disp = _c(x), _c(y), _c(disp)
+        dev = _lib.require_device(x, y, disp)
+        B, C, H, W = y.shape
+        nd = disp.shape[1]
+        ctx.save_for_backward(x, y, disp)
+        yw = torch.empty((B, C, nd, H, W), dtype=y.dtype, device=y.device)
+        xw = torch.empty_like(yw)
+        if yw.numel():
+            with torch.cuda.device(dev):
+                call("ss_warp_sampled_fwd", ptr(x), ptr(y), ptr(disp), ptr(yw), ptr(xw), B, C, H, W, nd)
+        return yw, xw
+
+    @staticmethod
+    def backward(ctx, gyw, gxw):
+        x, y, disp = ctx.saved_tensors
+        with torch.enable_grad():
+            yy = y.detach().requires_grad_(True)
+            dd = disp.detach().requires_grad_(True)
+            out = _warp_reference_math(x, yy, dd)
+            gy, gd = torch.autograd.grad(out, (yy, dd), gyw)
+        return gxw.sum(dim=2), gy, gd
+
+
+def SpatialTransformer_grid(x, y, disp_range_samples):
+    """models/submodule.py:265-288: x, y [B,C,H,W], disp [B,nd,H,W] -> (y_warped, x_warped), both
+    [B,C,nd,H,W]."""
+    assert x.dim() == 4 and x.shape == y.shape and disp_range_samples.dim() == 4
+    assert disp_range_samples.shape[0] == y.shape[0] and disp_range_samples.shape[2:] == y.shape[2:]
+    return _WarpSampled.apply(x, y, disp_range_samples)
+
+
+def concat_volume_sampled(left, right, disparity_samples, att=None):
+    """Fused SemStereo.concat_volume_generator + `att_topk * volume` (models/SemStereo.py:241-244,
+    316-318): -> [B, 2C, nd, H, W] = att * cat(left broadcast, warp(right)).  att is [B,1,nd,H,W],
+    [B,nd,H,W] or None.  Inference only."""
+    left, right, disp = _c(left), _c(right), _c(disparity_samples)
+    if att is not None:
+        att = _c(att.reshape(att.shape[0], att.shape[-3], att.shape[-2], att.shape[-1]))
+    dev = _lib.require_device(left, right, disp, att)
+    B, C, H, W = left.shape
+    nd = disp.shape[1]
+    out = torch.empty((B, 2 * C, nd, H, W), dtype=left.dtype, device=left.device)
+    with torch.cuda.device(dev):
+        call("ss_concat_sampled_fwd", ptr(left), ptr(right), ptr(disp), ptr(att), ptr(out), B, C, H, W, nd)
+    return out
+
+
+def warp_correlation(x, y, disparity_samples):
+    """Fused models/SemStereo.py:291-292: mean over channels of x * warp(y) -> [B, nd, H, W].
+    Inference only."""
+    x, y, disp = _c(x), _c(y), _c(disparity_samples)
+    dev = _lib.require_device(x, y, disp)
+    B, C, H, W = x.shape
+    nd = disp.shape[1]
+    out = torch.empty((B, nd, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(dev):
+        call("ss_warp_correlation_fwd", ptr(x), ptr(y), ptr(disp), ptr(out), B, C, H, W, nd)
+    return out
+
+
+def channel_gate(att_logits, cv):
+    """channelAtt's gating (models/SemStereo.py:101-102): sigmoid(att)[:, :, None] * cv.  Inference only."""
+    att_logits, cv = _c(att_logits), _c(cv)
+    dev = _lib.require_device(att_logits, cv)
+    B, C, D, H, W = cv.shape
+    assert att_logits.shape == (B, C, H, W)
+    out = torch.empty_like(cv)
+    with torch.cuda.device(dev):
+        call("ss_channel_gate_fwd", ptr(att_logits), ptr(cv), ptr(out), B, C, D, H, W)
+    return out
+
+
+#: names the reference model module resolves by bare global
+REFERENCE_NAMES = (
+    "build_gwc_volume", "build_gwc_volume_norm", "groupwise_correlation", "groupwise_correlation_norm",
+    "build_concat_volume", "disparity_regression", "disparity_variance", "SpatialTransformer_grid",
+    "regression_topk",
+)

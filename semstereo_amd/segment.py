@@ -1,0 +1,127 @@
+"""The hot segment of SemStereo.forward (reference models/SemStereo.py:273-323) as one module:
+1/8- and 1/4-scale feature maps (after the chal_* projections) -> 1/4-scale disparities.
+
+Attribute names equal the reference model's (patch, corr_feature_att_8, hourglass_att,
+classif_att_, gamma, beta, concat_feature, concat_stem, concat_feature_att_4, hourglass, classif),
+so the matching slice of a reference checkpoint loads with `load_reference_state_dict`.
+In inference the volume builders, the whole 3-D stack and the regressions are HIP kernels, with
+the fusions SURVEY.md section 8(f) asks for (patch+gate, softmax+regression+variance,
+warp+correlation, warp+concat+gate); the remaining glue (trilinear upsampling, softmax, sort /
+top-24 / gather, the 5-tap propagation) is PyTorch-on-GPU as in the reference.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import modules as M
+from . import ops
+
+TOPK = 24                                   # models/SemStereo.py:301
+_PROP_TAPS = ((-1, -1), (0, 0), (1, 1), (1, -1), (-1, 1))    # models/submodule.py:295-300 / 367-372
+
+OWNED_PREFIXES = ("patch", "corr_feature_att_8", "hourglass_att", "classif_att_", "gamma", "beta",
+                  "concat_feature", "concat_stem", "concat_feature_att_4", "hourglass", "classif")
+
+
+def propagation(x):
+    """Propagation.forward (models/submodule.py:290-307): [B,1,H,W] -> [B,5,H,W], the five diagonal
+    neighbours with replicate padding (the reference's one-hot 3x3 convolution, as plain shifts)."""
+    H, W = x.shape[-2:]
+    p = F.pad(x, (1, 1, 1, 1), mode="replicate")
+    return torch.cat([p[..., 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in _PROP_TAPS], dim=1)
+
+
+def propagation_prob(v):
+    """Propagation_prob.forward (models/submodule.py:361-377): [B,1,D,H,W] -> [B,5,D,H,W]."""
+    H, W = v.shape[-2:]
+    p = F.pad(v, (1, 1, 1, 1, 0, 0), mode="replicate")
+    return torch.cat([p[..., 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in _PROP_TAPS], dim=1)
+
+
+class HotSegment(nn.Module):
+    def __init__(self, maxdisp, c8=256, c4=128):
+        super().__init__()
+        assert maxdisp % 64 == 0, "the reference graph needs maxdisp % 64 == 0 (SURVEY.md section 0.4)"
+        self.maxdisp = maxdisp
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.beta = nn.Parameter(2 * torch.ones(1))
+        self.patch = M.DepthwisePatch(c8 // 8)
+        self.concat_feature = nn.Sequential(
+            M.BasicConv(c4, c4 // 2, kernel_size=3, stride=1, padding=1),
+            nn.Conv2d(c4 // 2, c4 // 4, 3, 1, 1, bias=False))
+        self.corr_feature_att_8 = M.channelAtt(c4 // 4, c8)
+        self.concat_feature_att_4 = M.channelAtt(c4 // 4, c4)
+        self.hourglass_att = M.hourglass(32)
+        self.classif_att_ = M.Classifier(32)
+        self.hourglass = M.hourglass2(32)
+        self.classif = M.Classifier(32)
+        self.concat_stem = M.BasicConv(c4 // 2, c4 // 4, is_3d=True, kernel_size=3, stride=1, padding=1)
+
+    def load_reference_state_dict(self, state_dict, strict=True):
+        """Load the slice of a reference SemStereo state_dict (optionally `module.`-prefixed, as
+        nn.DataParallel checkpoints are) that belongs to the hot segment."""
+        sd = {}
+        for k, v in state_dict.items():
+            k = k[7:] if k.startswith("module.") else k
+            if k.split(".")[0] in OWNED_PREFIXES:
+                sd[k] = v
+        return self.load_state_dict(sd, strict=strict)
+
+    # ---- models/SemStereo.py:273-310 ---------------------------------------------------
+    def attention_branch(self, fl4, fr4, fl8, fr8):
+        m8, m4 = self.maxdisp // 8, self.maxdisp // 4
+        H4, W4 = fl4.shape[-2:]
+        fast = M._inference(self, fl4, fr4, fl8, fr8)
+        corr = ops.build_gwc_volume_norm(fl8, fr8, m8, fl8.shape[1] // 8)                      # :273
+        if fast:
+            cost_att = self.patch(corr, self.corr_feature_att_8.logits(fl8))                   # :274 + :276 fused
+        else:
+            cost_att = self.corr_feature_att_8(self.patch(corr), fl8)
+        cost_att = self.classif_att_(self.hourglass_att(cost_att))                             # :277-278
+        att_weights = F.interpolate(cost_att, [m4 * 2, H4, W4], mode="trilinear")              # :279
+        if fast:
+            pred0, var, _ = ops.softmax_regression(att_weights.squeeze(1), m4)                 # :281-285 fused
+        else:
+            prob0 = F.softmax(att_weights.squeeze(1), dim=1)
+            pred0 = ops.disparity_regression(prob0, m4)
+            var = ops.disparity_variance(prob0, m4, pred0.unsqueeze(1))
+        var = torch.sigmoid(self.beta + self.gamma * var)                                      # :286-287
+        var_samples = propagation(var)                                                         # :288
+        disp_samples = propagation(pred0.unsqueeze(1))                                         # :289
+        if fast:
+            strength = ops.warp_correlation(fl4, fr4, disp_samples)                            # :291-292 fused
+        else:
+            right_w, left_b = ops.SpatialTransformer_grid(fl4, fr4, disp_samples)
+            strength = (left_b * right_w).mean(dim=1)
+        strength = torch.softmax(strength * var_samples, dim=1)                                # :293
+        aw = (propagation_prob(att_weights) * strength.unsqueeze(2)).sum(dim=1, keepdim=True)  # :295-297
+        aw_prob = F.softmax(aw, dim=2)                                                         # :298
+        _, ind = aw_prob.sort(2, True, stable=True)                                            # :299
+        ind_k = ind[:, :, :TOPK].sort(2, False)[0]                                             # :302-303
+        att_topk = torch.gather(aw_prob, 2, ind_k)                                             # :304
+        samples = ind_k.squeeze(1).float() - m4                                                # :305
+        att_prob = F.softmax(torch.gather(aw, 2, ind_k).squeeze(1), dim=1)                     # :307-308
+        pred_att = (att_prob * samples).sum(dim=1)                                             # :309-310
+        return att_topk, samples, pred_att, pred0
+
+    # ---- models/SemStereo.py:314-323 ---------------------------------------------------
+    def matching_branch(self, fl4, fr4, att_topk, samples):
+        fast = M._inference(self, fl4, fr4, att_topk)
+        cl = self.concat_feature(fl4)                                                          # :314
+        cr = self.concat_feature(fr4)                                                          # :315
+        if fast:
+            volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                      # :316 + :318 fused
+        else:
+            right_w, left_b = ops.SpatialTransformer_grid(cl, cr, samples)
+            volume = att_topk * torch.cat((left_b, right_w), dim=1)
+        volume = self.concat_stem(volume)                                                      # :319
+        volume = self.concat_feature_att_4(volume, fl4)                                        # :320
+        cost = self.classif(self.hourglass(volume))                                            # :321-322
+        return ops.regression_topk(cost.squeeze(1), samples, 2)                                # :323
+
+    def forward(self, fl4, fr4, fl8, fr8):
+        """features_left[1], features_right[1] [B,128,H/4,W/4]; features_left[2], features_right[2]
+        [B,256,H/8,W/8]  ->  dict(pred [B,1,H/4,W/4], pred_att [B,H/4,W/4], samples, att_topk, pred_att0)."""
+        att_topk, samples, pred_att, pred0 = self.attention_branch(fl4, fr4, fl8, fr8)
+        pred = self.matching_branch(fl4, fr4, att_topk, samples)
+        return dict(pred=pred, pred_att=pred_att, samples=samples, att_topk=att_topk, pred_att0=pred0)

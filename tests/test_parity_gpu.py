@@ -1,0 +1,351 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs and
+against the golden fixtures produced by the reference.  Run on the MI355X box: pytest -m gpu.
+
+Tolerances (fp32 everywhere):
+  * un-normalised gwc volume, dense concat volume: BIT-EXACT (same products, same summation order);
+  * normalised gwc, regressions, top-k regression, warps: <= 2e-6 absolute on O(1) values
+    (sqrt/div/exp rounding differences between host libm and the GPU);
+  * 3-D stack modules: <= 2e-4 absolute on O(1) activations (different fp32 summation order over
+    K = 864..3456 products);
+  * hot segment: candidate indices identical, pred / pred_att within 1e-3 px (the EPE target of
+    BASELINE.json) of the reference fixture.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden import cases
+from oracle import hot_segment as oseg
+from oracle import ops as oops
+from oracle import stack as ostack
+
+pytestmark = pytest.mark.gpu
+
+REPORT = {}
+
+
+def dev(t):
+    return t.cuda()
+
+
+def maxerr(a, ref):
+    a = a.detach().float().cpu()
+    ref = torch.as_tensor(ref).float()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    both_nan = torch.isnan(a) & torch.isnan(ref)
+    d = (a - ref).abs()
+    d[both_nan] = 0
+    return float(d.max()) if d.numel() else 0.0
+
+
+def check(name, a, ref, atol):
+    e = maxerr(a, ref)
+    REPORT[name] = e
+    assert e <= atol, f"{name}: max abs err {e:.3e} > {atol:.1e}"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_report():
+    yield
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.json", "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import semstereo_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    semstereo_amd._lib.load()
+    return semstereo_amd
+
+
+@pytest.mark.parametrize("name", sorted(cases.GWC))
+def test_gwc(sa, golden, name):
+    a, b, m, G = cases.gwc_inputs(name)
+    g = golden["ops"]
+    check(f"gwc/{name}", sa.ops.build_gwc_volume(dev(a), dev(b), m, G), g[f"gwc/{name}"], 0.0)
+    check(f"gwc_norm/{name}", sa.ops.build_gwc_volume_norm(dev(a), dev(b), m, G), g[f"gwc_norm/{name}"], 2e-6)
+    check(f"gcorr/{name}", sa.ops.groupwise_correlation(dev(a), dev(b), G), g[f"gcorr/{name}"], 0.0)
+    check(f"gcorr_norm/{name}", sa.ops.groupwise_correlation_norm(dev(a), dev(b), G), g[f"gcorr_norm/{name}"], 2e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 24, 128, 16, 32), (1, 64, 9, 256, 24, 8), (1, 32, 5, 260, 8, 8)])
+def test_gwc_vs_oracle_fast_path(sa, shape):
+    """The float4/LDS kernel (W % 4 == 0, maxdisp % 4 == 0, Cg in {4, 8}) incl. multi-tile W."""
+    from oracle import detdata as dd
+    B, C, H, W, m, G = shape
+    a, b = dd.t_normalish((B, C, H, W), 11), dd.t_normalish((B, C, H, W), 12)
+    check(f"gwc_fast/{shape}", sa.ops.build_gwc_volume(dev(a), dev(b), m, G), oops.build_gwc_volume(a, b, m, G), 0.0)
+    check(f"gwc_norm_fast/{shape}", sa.ops.build_gwc_volume_norm(dev(a), dev(b), m, G),
+          oops.build_gwc_volume_norm(a, b, m, G), 2e-6)
+
+
+@pytest.mark.parametrize("name", sorted(cases.CONCAT))
+def test_concat(sa, golden, name):
+    a, b, m = cases.concat_inputs(name)
+    check(f"concat/{name}", sa.ops.build_concat_volume(dev(a), dev(b), m), golden["ops"][f"concat/{name}"], 0.0)
+
+
+def test_concat_fast_path(sa):
+    from oracle import detdata as dd
+    a, b = dd.t_normalish((2, 5, 11, 256, ), 21), dd.t_normalish((2, 5, 11, 256), 22)
+    check("concat_fast", sa.ops.build_concat_volume(dev(a), dev(b), 12), oops.build_concat_volume(a, b, 12), 0.0)
+
+
+@pytest.mark.parametrize("name", sorted(cases.REGRESSION))
+def test_regression(sa, golden, name):
+    p, m, d = cases.regression_inputs(name)
+    check(f"regression/{name}", sa.ops.disparity_regression(dev(p), m), golden["ops"][f"regression/{name}"], 2e-6)
+    check(f"variance/{name}", sa.ops.disparity_variance(dev(p), m, dev(d)), golden["ops"][f"variance/{name}"], 2e-5)
+    with pytest.raises(AssertionError):
+        sa.ops.disparity_regression(dev(p).unsqueeze(0), m)
+
+
+def test_softmax_regression_fused(sa):
+    from oracle import detdata as dd
+    m = 32
+    logits = dd.t_normalish((2, 2 * m, 12, 20), 31) * 4.0
+    prob = torch.softmax(logits, dim=1)
+    mean = oops.disparity_regression(prob, m)
+    var = oops.disparity_variance(prob, m, mean.unsqueeze(1))
+    d, v, p = sa.ops.softmax_regression(dev(logits), m, want_prob=True)
+    check("fused_softmax/prob", p, prob, 2e-6)
+    check("fused_softmax/mean", d, mean, 2e-5)
+    check("fused_softmax/var", v, var, 2e-3)
+
+
+@pytest.mark.parametrize("name", sorted(cases.WARP))
+def test_warp(sa, golden, name):
+    x, y, d = cases.warp_inputs(name)
+    yw, xw = sa.ops.SpatialTransformer_grid(dev(x), dev(y), dev(d))
+    check(f"warp_y/{name}", yw, golden["ops"][f"warp_y/{name}"], 2e-6)
+    check(f"warp_x/{name}", xw, golden["ops"][f"warp_x/{name}"], 0.0)
+
+
+def test_warp_fused_forms(sa):
+    from oracle import detdata as dd
+    B, C, H, W, nd = 2, 16, 12, 40, 6
+    x, y = dd.t_normalish((B, C, H, W), 41), dd.t_normalish((B, C, H, W), 42)
+    disp = dd.distinct_sorted_candidates(B, nd, H, W, 16, 43)
+    att = dd.t_uniform((B, 1, nd, H, W), 44, 0.0, 1.0)
+    yw, xw = oops.SpatialTransformer_grid(x, y, disp)
+    check("concat_sampled", sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp), dev(att)),
+          att * torch.cat((xw, yw), dim=1), 2e-6)
+    check("concat_sampled_nogate", sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp)),
+          torch.cat((xw, yw), dim=1), 2e-6)
+    check("warp_correlation", sa.ops.warp_correlation(dev(x), dev(y), dev(disp)), (xw * yw).mean(dim=1), 2e-6)
+
+
+@pytest.mark.parametrize("name", sorted(cases.TOPK))
+def test_topk(sa, golden, name):
+    c, s, k = cases.topk_inputs(name)
+    check(f"topk/{name}", sa.ops.regression_topk(dev(c), dev(s), k), golden["ops"][f"topk/{name}"], 1e-5)
+
+
+def test_topk_generic_k_and_ties(sa):
+    from oracle import detdata as dd
+    c = dd.t_normalish((1, 12, 5, 7), 51)
+    s = dd.distinct_sorted_candidates(1, 12, 5, 7, 16, 52)
+    check("topk/k6", sa.ops.regression_topk(dev(c), dev(s), 6), oops.regression_topk(c, s, 6), 1e-5)
+    c[:, 3] = c[:, 1]           # exact ties: lower index first, like the oracle's stable sort
+    check("topk/ties", sa.ops.regression_topk(dev(c), dev(s), 2), oops.regression_topk(c, s, 2), 1e-5)
+
+
+def test_channel_gate(sa):
+    from oracle import detdata as dd
+    att, cv = dd.t_normalish((2, 8, 6, 12), 61), dd.t_normalish((2, 8, 5, 6, 12), 62)
+    check("channel_gate", sa.ops.channel_gate(dev(att), dev(cv)), torch.sigmoid(att).unsqueeze(2) * cv, 2e-6)
+
+
+def test_cpu_tensor_is_an_error_not_a_fallback(sa):
+    a, b, m, G = cases.gwc_inputs("odd")
+    with pytest.raises(sa._lib.SemStereoHipError):
+        sa.ops.build_gwc_volume(a, b, m, G)
+
+
+def test_assertions_match_reference(sa):
+    a, b, m, G = cases.gwc_inputs("odd")
+    with pytest.raises(AssertionError):
+        sa.ops.build_gwc_volume(dev(a), dev(b), m, 5)      # C % G != 0
+    with pytest.raises(AssertionError):
+        sa.ops.groupwise_correlation(dev(a), dev(b), 5)
+
+
+# --------------------------------------------------------------------------------------
+# backward of the volume builders / regressions (autograd.Function) vs the oracle's autograd
+# --------------------------------------------------------------------------------------
+
+def _grads(fn, inputs, seed_like):
+    xs = [t.clone().requires_grad_(True) for t in inputs]
+    y = fn(*xs)
+    y.backward(seed_like(y))
+    return [x.grad for x in xs]
+
+
+def test_backward_gwc_concat_regression(sa):
+    from oracle import detdata as dd
+    a, b = dd.t_normalish((2, 16, 5, 12), 71), dd.t_normalish((2, 16, 5, 12), 72)
+    for norm in (False, True):
+        hip = sa.ops.build_gwc_volume_norm if norm else sa.ops.build_gwc_volume
+        orc = oops.build_gwc_volume_norm if norm else oops.build_gwc_volume
+        seed = dd.t_normalish((2, 4, 8, 5, 12), 73)
+        gh = _grads(lambda p, q: hip(p, q, 4, 4), [dev(a), dev(b)], lambda y: dev(seed))
+        go = _grads(lambda p, q: orc(p, q, 4, 4), [a, b], lambda y: seed)
+        for i, (x, r) in enumerate(zip(gh, go)):
+            check(f"bwd/gwc{'_norm' if norm else ''}/{i}", x, r, 2e-5)
+    seed = dd.t_normalish((2, 32, 8, 5, 12), 74)
+    gh = _grads(lambda p, q: sa.ops.build_concat_volume(p, q, 4), [dev(a), dev(b)], lambda y: dev(seed))
+    go = _grads(lambda p, q: oops.build_concat_volume(p, q, 4), [a, b], lambda y: seed)
+    for i, (x, r) in enumerate(zip(gh, go)):
+        check(f"bwd/concat/{i}", x, r, 1e-5)
+    p = torch.softmax(dd.t_normalish((2, 8, 5, 12), 75), dim=1)
+    seed = dd.t_normalish((2, 5, 12), 76)
+    gh = _grads(lambda q: sa.ops.disparity_regression(q, 4), [dev(p)], lambda y: dev(seed))
+    go = _grads(lambda q: oops.disparity_regression(q, 4), [p], lambda y: seed)
+    check("bwd/regression", gh[0], go[0], 1e-6)
+
+
+# --------------------------------------------------------------------------------------
+# 3-D stack
+# --------------------------------------------------------------------------------------
+
+def _segment(sa, maxdisp=64):
+    seg = sa.HotSegment(maxdisp)
+    P = oseg.deterministic_params()
+    res = seg.load_state_dict(P, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.endswith("num_batches_tracked") for k in res.missing_keys), res.missing_keys
+    return seg.cuda().eval(), P
+
+
+def _run_stack_module(seg, name, x):
+    kind, shape, block = cases.STACK[name]
+    mod = seg
+    for part in kind.split("."):
+        mod = getattr(mod, part)
+    return mod(x)
+
+
+@pytest.mark.parametrize("name", sorted(cases.STACK))
+def test_stack_modules(sa, golden, name):
+    seg, P = _segment(sa)
+    before = dict(sa.modules.PATH_COUNTS)
+    with torch.no_grad():
+        y = _run_stack_module(seg, name, dev(cases.stack_input(name)))
+    assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "the PyTorch training path ran in inference"
+    assert sa.modules.PATH_COUNTS["hip"] > before["hip"]
+    check(f"stack/{name}", y, golden["stack"][f"stack/{name}"], 2e-4)
+
+
+CONV_CASES = [
+    # (Cin, Cout, D, H, W, k, stride, relu, residual)
+    (32, 32, 5, 9, 37, 3, 1, True, False),
+    (32, 64, 6, 10, 34, 3, 2, True, False),
+    (64, 64, 3, 8, 33, 3, 1, True, True),
+    (64, 128, 4, 7, 40, 3, 2, False, False),
+    (128, 128, 2, 5, 8, 3, 1, True, False),
+    (64, 32, 3, 9, 66, 3, 1, True, False),
+    (32, 32, 2, 6, 35, 1, 1, False, False),
+    (64, 64, 2, 4, 32, 1, 1, False, True),
+    (32, 1, 5, 9, 37, 3, 1, False, False),
+    (6, 40, 3, 4, 9, 3, 1, False, False),       # odd channel counts: zero-filled chunk tails
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_kernel(sa, case):
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin, Cout, D, H, W, k, stride, relu, use_res = case
+    x = dd.t_normalish((2, Cin, D, H, W), 81)
+    w = dd.t_uniform((Cout, Cin, k, k, k), 82, -1, 1) * (3.0 / (Cin * k ** 3)) ** 0.5
+    scale, shift = dd.t_uniform((Cout,), 83, 0.5, 1.5), dd.t_uniform((Cout,), 84, -0.2, 0.2)
+    ref = F.conv3d(x, w, None, stride, k // 2) * scale.reshape(1, -1, 1, 1, 1) + shift.reshape(1, -1, 1, 1, 1)
+    res = dd.t_normalish(tuple(ref.shape), 85) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    wp = sa.modules.pack_conv_weight(dev(w))
+    y = sa.modules.conv3d_hip(dev(x), wp, dev(scale), dev(shift), k, stride, relu, None if res is None else dev(res))
+    check(f"conv3d/{case}", y, ref, 2e-4)
+
+
+@pytest.mark.parametrize("case", [(128, 64, 2, 3, 5, 64), (64, 32, 3, 9, 33, 32), (32, 32, 2, 4, 40, 0), (8, 24, 2, 3, 6, 6)])
+def test_deconv3d_kernel(sa, case):
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin, Cout, D, H, W, Cs = case
+    x = dd.t_normalish((2, Cin, D, H, W), 91)
+    w = dd.t_uniform((Cin, Cout, 3, 3, 3), 92, -1, 1) * (3.0 / (Cin * 27 / 8)) ** 0.5
+    shift = dd.t_uniform((Cout,), 93, -0.2, 0.2)
+    ref = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1) + shift.reshape(1, -1, 1, 1, 1)
+    skip = ws = None
+    if Cs:
+        skip = dd.t_normalish((2, Cs, 2 * D, 2 * H, 2 * W), 94)
+        ws = dd.t_uniform((Cout, Cs, 1, 1, 1), 95, -1, 1) * (3.0 / Cs) ** 0.5
+        ref = ref + F.conv3d(skip, ws)
+    ref = F.relu(ref)
+    wp = sa.modules.pack_conv_weight(dev(w), transposed=True)
+    wsp = None if ws is None else sa.modules.pack_conv_weight(dev(ws)).reshape(Cs, Cout).contiguous()
+    y = sa.modules.deconv3d_hip(dev(x), wp, dev(shift), True, None if skip is None else dev(skip), wsp)
+    check(f"deconv3d/{case}", y, ref, 2e-4)
+
+
+def test_patch_and_gate_fusion(sa):
+    from oracle import detdata as dd
+    P = oseg.deterministic_params()
+    cv = dd.t_normalish((2, 32, 4, 7, 13), 101)
+    gate = dd.t_normalish((2, 32, 7, 13), 102)
+    mod = sa.modules.DepthwisePatch(32)
+    mod.load_state_dict({"weight": P["patch.weight"]})
+    mod = mod.cuda().eval()
+    ref = ostack.patch_conv(P, cv)
+    with torch.no_grad():
+        check("patch", mod(dev(cv)), ref, 2e-6)
+        check("patch_gate", mod(dev(cv), dev(gate)), torch.sigmoid(gate).unsqueeze(2) * ref, 2e-6)
+
+
+# --------------------------------------------------------------------------------------
+# hot segment: features -> pred, against the REFERENCE's fixture and against the oracle
+# --------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", sorted(cases.SEGMENT))
+def test_hot_segment_vs_reference_fixture(sa, golden, name):
+    seg, P = _segment(sa, cases.SEGMENT[name][3])
+    fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
+    before = dict(sa.modules.PATH_COUNTS)
+    with torch.no_grad():
+        r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
+    assert sa.modules.PATH_COUNTS["torch"] == before["torch"]
+    g = golden["segment"]
+    check(f"segment/{name}/pred_att0", r["pred_att0"], g[f"{name}/pred_att0"], 1e-3)
+    same = (r["samples"].cpu().numpy().astype(np.int16) == g[f"{name}/samples"]).mean()
+    REPORT[f"segment/{name}/samples_equal_fraction"] = float(same)
+    assert same == 1.0, f"top-24 candidate sets differ from the reference on {100 * (1 - same):.3f}% of entries"
+    check(f"segment/{name}/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
+    check(f"segment/{name}/pred", r["pred"], g[f"{name}/pred"], 1e-3)
+    REPORT[f"segment/{name}/epe_vs_ref"] = oops.epe(r["pred"].cpu(), torch.as_tensor(g[f"{name}/pred"]))
+
+
+def test_drop_in_accelerate_keeps_state_dict_and_matches_fused_segment(sa):
+    """`accelerate()` on a module tree built from plain torch layers with the reference's structure
+    (what the reference's classes produce) swaps in HIP twins that share parameters."""
+    import torch.nn as nn
+    ref_like = nn.Sequential()          # stands in for a reference hourglass: same attribute tree
+    hg = sa.modules.hourglass(32)
+    plain = nn.Module()
+    for n in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "redir1", "redir2"):
+        setattr(plain, n, getattr(hg, n))
+    plain.attention_block = hg.attention_block
+    holder = nn.Module()
+    holder.hourglass_att = plain
+    keys = list(holder.state_dict().keys())
+    done = sa.accelerate(holder)
+    assert done == ["hourglass_att"] and list(holder.state_dict().keys()) == keys
+    assert isinstance(holder.hourglass_att, sa.modules.hourglass)
+    del ref_like
