@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Benchmark of the SemStereo hot segment (cost volumes + 3-D aggregation + soft-argmax) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch PAIRS_PER_GPU]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path (1/4- and 1/8-scale features -> 1/4-scale disparity,
+reference models/SemStereo.py:273-323) over this rank's batch of synthetic 1024x1024, maxdisp=128
+pairs, inputs resident in HBM.  Pairs are sharded over ranks (weak scaling, no collective inside
+the forward); the timed region is bracketed by barrier + synchronize and the MAX over ranks is
+reported.  Rank 0 prints ONE JSON line with pairs/s, the roofline of the dominant kernel (fp32-MFMA
+conv of concat_stem) and of the cost-volume build kernel (HBM), EPE against the CPU oracle, and
+the oracle's own pairs/s on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import semstereo_amd  # noqa: E402
+from semstereo_amd import dist as sdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def synth_features(B, C, H, W, max_shift, seed, device):
+    """Left features ~ N(0,1); right = left shifted per row by a smooth signed integer disparity
+    plus 5 % noise, so the volumes carry a real correlation peak."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    left = torch.randn(B, C, H, W, generator=g, device=device)
+    ys = torch.arange(H, device=device, dtype=torch.float32)
+    shift = torch.round(max_shift * torch.sin(2 * torch.pi * ys / H + 0.3)).long()
+    cols = (torch.arange(W, device=device).reshape(1, W) + shift.reshape(H, 1)) % W      # right[x] = left[x + d]
+    right = torch.gather(left, 3, cols.reshape(1, 1, H, W).expand(B, C, H, W))
+    right = right + 0.05 * torch.randn(B, C, H, W, generator=g, device=device)
+    return left.contiguous(), right.contiguous()
+
+
+class KernelTimer:
+    """HIP-event timing of selected launches on the stream they are launched on (torch's current
+    stream, which is what semstereo_amd passes through the C ABI)."""
+
+    def __init__(self):
+        self.events = {}
+        self.enabled = False
+
+    def wrap(self, name, fn):
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.events.setdefault(name, []).append((e0, e1))
+            return r
+        return timed
+
+    def mean_ms(self, name):
+        ev = self.events.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--maxdisp", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = sdist.init_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    semstereo_amd._lib.load()
+
+    H, W, maxdisp, B = args.height, args.width, args.maxdisp, args.batch
+    torch.manual_seed(1234)                      # same random-init weights on every rank
+    seg = semstereo_amd.HotSegment(maxdisp).to(device).eval()
+    sdist.broadcast_module(seg, src=0)
+    fl8, fr8 = synth_features(B, 256, H // 8, W // 8, 6, 100 + rank, device)
+    fl4, fr4 = synth_features(B, 128, H // 4, W // 4, 12, 200 + rank, device)
+    feats = (fl4, fr4, fl8, fr8)
+
+    timer = KernelTimer()
+    if not args.no_kernel_timers:
+        seg.concat_stem.forward = timer.wrap("concat_stem", seg.concat_stem.forward)
+        semstereo_amd.segment.ops.build_gwc_volume_norm = timer.wrap("gwc", semstereo_amd.ops.build_gwc_volume_norm)
+
+    def step():
+        with torch.no_grad():
+            return seg(*feats)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer.enabled = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    assert semstereo_amd.modules.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside the timed region"
+
+    pairs, _, _, tmax = sdist.reduce_metrics(B * args.steps, 0.0, 0, elapsed, device)
+
+    if rank != 0:
+        return
+    D8, D4, k = 2 * (maxdisp // 8), 2 * (maxdisp // 4), 24
+    H8, W8, H4, W4 = H // 8, W // 8, H // 4, W // 4
+    res = {
+        "metric": "stereo pairs/sec, hot segment (gwc+concat volumes, 3-D hourglass stack, soft-argmax), "
+                  f"{H}x{W} maxdisp={maxdisp}",
+        "value": pairs / tmax, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: {H}x{W} tile, maxdisp={maxdisp}, batch={B} per GPU, "
+                               "features [B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity [B,1,H/4,W/4]",
+                   "pairs_per_gpu_per_step": B, "parallelism": f"pairs sharded over {world} rank(s), no collective in the forward",
+                   "weights": "random init (torch default), BatchNorm eval"},
+    }
+    ms = timer.mean_ms("concat_stem")
+    if ms:
+        flops = 2.0 * 32 * 64 * 27 * k * H4 * W4 * B          # concat_stem: Conv3d 64->32 k3 on [B,64,24,H4,W4]
+        ach = flops / (ms * 1e-3) / 1e12
+        res["roofline"] = {"kernel": "conv3d_mfma<3,1,1,4,2,8,8> (concat_stem, 64->32 k3 on [B,64,24,H/4,W/4])",
+                           "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
+                           "algorithmic_flop_per_launch": flops}
+    ms = timer.mean_ms("gwc")
+    if ms:
+        nbytes = 4.0 * (2 * 256 * H8 * W8 + 32 * D8 * H8 * W8) * B
+        ach = nbytes / (ms * 1e-3) / 1e9
+        res["roofline_cost_volume"] = {"kernel": "gwc_volume_v4<8,true> (build_gwc_volume_norm, live shape)",
+                                       "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms,
+                                       "algorithmic_bytes_per_launch": nbytes}
+    if not args.no_cpu_baseline:
+        from oracle import hot_segment as oseg
+        from oracle import ops as oops
+        P = {k_: v.detach().cpu() for k_, v in seg.state_dict().items()}
+        cpu_in = [t[:1].cpu() for t in feats]
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        c0 = time.perf_counter()
+        ref = oseg.hot_segment(P, cpu_in[0], cpu_in[1], cpu_in[2], cpu_in[3], maxdisp)
+        cdt = time.perf_counter() - c0
+        res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "pairs/s", "cores": ncores, "kind": "port",
+                               "sample": f"1 pair {H}x{W} maxdisp={maxdisp} through oracle.hot_segment "
+                                         f"(PyTorch CPU fp32 restatement of the reference), {cdt:.1f} s"}
+        res["epe_vs_oracle_px"] = oops.epe(out["pred"][:1].cpu(), ref["pred"])
+        res["pred_att_epe_vs_oracle_px"] = oops.epe(out["pred_att"][:1].cpu(), ref["pred_att"])
+        res["candidate_agreement"] = (out["samples"][:1].cpu() == ref["samples"]).float().mean().item()
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -229,7 +229,7 @@ def softmax_regression(logits, maxdisp, want_prob=False):
 
 
 def _topk_reference_math(cost, disparity_samples, k):
-    _, ind = cost.sort(1, True, stable=True)
+    _, ind = cost.sort(dim=1, descending=True, stable=True)
     pool = ind[:, :k]
     prob = F.softmax(torch.gather(cost, 1, pool), 1)
     return torch.sum(torch.gather(disparity_samples, 1, pool) * prob, dim=1, keepdim=True)

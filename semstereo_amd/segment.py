@@ -96,7 +96,7 @@ class HotSegment(nn.Module):
         strength = torch.softmax(strength * var_samples, dim=1)                                # :293
         aw = (propagation_prob(att_weights) * strength.unsqueeze(2)).sum(dim=1, keepdim=True)  # :295-297
         aw_prob = F.softmax(aw, dim=2)                                                         # :298
-        _, ind = aw_prob.sort(2, True, stable=True)                                            # :299
+        _, ind = aw_prob.sort(dim=2, descending=True, stable=True)                                            # :299
         ind_k = ind[:, :, :TOPK].sort(2, False)[0]                                             # :302-303
         att_topk = torch.gather(aw_prob, 2, ind_k)                                             # :304
         samples = ind_k.squeeze(1).float() - m4                                                # :305

@@ -2,9 +2,10 @@
 against the golden fixtures produced by the reference.  Run on the MI355X box: pytest -m gpu.
 
 Tolerances (fp32 everywhere):
-  * un-normalised gwc volume, dense concat volume: BIT-EXACT (same products, same summation order);
-  * normalised gwc, regressions, top-k regression, warps: <= 2e-6 absolute on O(1) values
-    (sqrt/div/exp rounding differences between host libm and the GPU);
+  * dense concat volume, broadcast halves, propagation, depthwise patch: BIT-EXACT (pure data movement);
+  * gwc volumes, regressions, top-k regression, warps: <= 1e-6 absolute + 1e-6 relative to the
+    largest reference value (fp32 summation order / sqrt / div / exp rounding differ between the
+    host's vectorised ATen kernels and the GPU; measured 6e-8 .. 4e-7 on O(1) values);
   * 3-D stack modules: <= 2e-4 absolute on O(1) activations (different fp32 summation order over
     K = 864..3456 products);
   * hot segment: candidate indices identical, pred / pred_att within 1e-3 px (the EPE target of
@@ -41,10 +42,11 @@ def maxerr(a, ref):
     return float(d.max()) if d.numel() else 0.0
 
 
-def check(name, a, ref, atol):
+def check(name, a, ref, atol, rtol=0.0):
     e = maxerr(a, ref)
     REPORT[name] = e
-    assert e <= atol, f"{name}: max abs err {e:.3e} > {atol:.1e}"
+    scale = float(torch.as_tensor(ref).float().abs().nan_to_num(0.0).max()) if rtol else 0.0
+    assert e <= atol + rtol * scale, f"{name}: max abs err {e:.3e} > {atol:.1e} + {rtol:.1e}*{scale:.3g}"
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -67,9 +69,9 @@ def sa():
 def test_gwc(sa, golden, name):
     a, b, m, G = cases.gwc_inputs(name)
     g = golden["ops"]
-    check(f"gwc/{name}", sa.ops.build_gwc_volume(dev(a), dev(b), m, G), g[f"gwc/{name}"], 0.0)
+    check(f"gwc/{name}", sa.ops.build_gwc_volume(dev(a), dev(b), m, G), g[f"gwc/{name}"], 1e-6)
     check(f"gwc_norm/{name}", sa.ops.build_gwc_volume_norm(dev(a), dev(b), m, G), g[f"gwc_norm/{name}"], 2e-6)
-    check(f"gcorr/{name}", sa.ops.groupwise_correlation(dev(a), dev(b), G), g[f"gcorr/{name}"], 0.0)
+    check(f"gcorr/{name}", sa.ops.groupwise_correlation(dev(a), dev(b), G), g[f"gcorr/{name}"], 1e-6)
     check(f"gcorr_norm/{name}", sa.ops.groupwise_correlation_norm(dev(a), dev(b), G), g[f"gcorr_norm/{name}"], 2e-6)
 
 
@@ -79,7 +81,7 @@ def test_gwc_vs_oracle_fast_path(sa, shape):
     from oracle import detdata as dd
     B, C, H, W, m, G = shape
     a, b = dd.t_normalish((B, C, H, W), 11), dd.t_normalish((B, C, H, W), 12)
-    check(f"gwc_fast/{shape}", sa.ops.build_gwc_volume(dev(a), dev(b), m, G), oops.build_gwc_volume(a, b, m, G), 0.0)
+    check(f"gwc_fast/{shape}", sa.ops.build_gwc_volume(dev(a), dev(b), m, G), oops.build_gwc_volume(a, b, m, G), 1e-6)
     check(f"gwc_norm_fast/{shape}", sa.ops.build_gwc_volume_norm(dev(a), dev(b), m, G),
           oops.build_gwc_volume_norm(a, b, m, G), 2e-6)
 
@@ -99,8 +101,8 @@ def test_concat_fast_path(sa):
 @pytest.mark.parametrize("name", sorted(cases.REGRESSION))
 def test_regression(sa, golden, name):
     p, m, d = cases.regression_inputs(name)
-    check(f"regression/{name}", sa.ops.disparity_regression(dev(p), m), golden["ops"][f"regression/{name}"], 2e-6)
-    check(f"variance/{name}", sa.ops.disparity_variance(dev(p), m, dev(d)), golden["ops"][f"variance/{name}"], 2e-5)
+    check(f"regression/{name}", sa.ops.disparity_regression(dev(p), m), golden["ops"][f"regression/{name}"], 1e-6, 1e-6)
+    check(f"variance/{name}", sa.ops.disparity_variance(dev(p), m, dev(d)), golden["ops"][f"variance/{name}"], 1e-6, 1e-6)
     with pytest.raises(AssertionError):
         sa.ops.disparity_regression(dev(p).unsqueeze(0), m)
 
@@ -113,16 +115,16 @@ def test_softmax_regression_fused(sa):
     mean = oops.disparity_regression(prob, m)
     var = oops.disparity_variance(prob, m, mean.unsqueeze(1))
     d, v, p = sa.ops.softmax_regression(dev(logits), m, want_prob=True)
-    check("fused_softmax/prob", p, prob, 2e-6)
-    check("fused_softmax/mean", d, mean, 2e-5)
-    check("fused_softmax/var", v, var, 2e-3)
+    check("fused_softmax/prob", p, prob, 1e-6)
+    check("fused_softmax/mean", d, mean, 1e-6, 1e-6)
+    check("fused_softmax/var", v, var, 1e-6, 2e-6)
 
 
 @pytest.mark.parametrize("name", sorted(cases.WARP))
 def test_warp(sa, golden, name):
     x, y, d = cases.warp_inputs(name)
     yw, xw = sa.ops.SpatialTransformer_grid(dev(x), dev(y), dev(d))
-    check(f"warp_y/{name}", yw, golden["ops"][f"warp_y/{name}"], 2e-6)
+    check(f"warp_y/{name}", yw, golden["ops"][f"warp_y/{name}"], 1e-6, 1e-6)
     check(f"warp_x/{name}", xw, golden["ops"][f"warp_x/{name}"], 0.0)
 
 
@@ -134,16 +136,16 @@ def test_warp_fused_forms(sa):
     att = dd.t_uniform((B, 1, nd, H, W), 44, 0.0, 1.0)
     yw, xw = oops.SpatialTransformer_grid(x, y, disp)
     check("concat_sampled", sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp), dev(att)),
-          att * torch.cat((xw, yw), dim=1), 2e-6)
+          att * torch.cat((xw, yw), dim=1), 1e-6, 2e-6)
     check("concat_sampled_nogate", sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp)),
-          torch.cat((xw, yw), dim=1), 2e-6)
-    check("warp_correlation", sa.ops.warp_correlation(dev(x), dev(y), dev(disp)), (xw * yw).mean(dim=1), 2e-6)
+          torch.cat((xw, yw), dim=1), 1e-6, 2e-6)
+    check("warp_correlation", sa.ops.warp_correlation(dev(x), dev(y), dev(disp)), (xw * yw).mean(dim=1), 1e-6, 2e-6)
 
 
 @pytest.mark.parametrize("name", sorted(cases.TOPK))
 def test_topk(sa, golden, name):
     c, s, k = cases.topk_inputs(name)
-    check(f"topk/{name}", sa.ops.regression_topk(dev(c), dev(s), k), golden["ops"][f"topk/{name}"], 1e-5)
+    check(f"topk/{name}", sa.ops.regression_topk(dev(c), dev(s), k), golden["ops"][f"topk/{name}"], 1e-6, 1e-6)
 
 
 def test_topk_generic_k_and_ties(sa):
