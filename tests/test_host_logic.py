@@ -1,0 +1,141 @@
+"""CPU: host-side logic of the drop-in boundary -- name rebinding, module adoption, state_dict
+keys, error behaviour, the PyTorch training path of the module twins, batch sharding maths."""
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+
+import semstereo_amd as sa
+from golden import cases
+from oracle import hot_segment as oseg
+from oracle import stack as ostack
+
+
+def test_install_rebinds_and_uninstall_restores():
+    fake = types.ModuleType("fake_model_module")
+    sentinel = object()
+    fake.build_gwc_volume_norm = sentinel
+    prev = sa.install(fake)
+    for name in sa.ops.REFERENCE_NAMES:
+        assert getattr(fake, name) is getattr(sa.ops, name)
+    sa.uninstall(fake, prev)
+    assert fake.build_gwc_volume_norm is sentinel and not hasattr(fake, "regression_topk")
+
+
+def test_reference_signatures():
+    import inspect
+    want = {
+        "build_gwc_volume": ["refimg_fea", "targetimg_fea", "maxdisp", "num_groups"],
+        "build_gwc_volume_norm": ["refimg_fea", "targetimg_fea", "maxdisp", "num_groups"],
+        "groupwise_correlation": ["fea1", "fea2", "num_groups"],
+        "build_concat_volume": ["refimg_fea", "targetimg_fea", "maxdisp"],
+        "disparity_regression": ["x", "maxdisp"],
+        "disparity_variance": ["x", "maxdisp", "disparity"],
+        "SpatialTransformer_grid": ["x", "y", "disp_range_samples"],
+        "regression_topk": ["cost", "disparity_samples", "k"],
+    }
+    for name, params in want.items():
+        assert list(inspect.signature(getattr(sa.ops, name)).parameters) == params
+
+
+def test_cpu_tensors_raise_instead_of_falling_back():
+    a, b, m, G = cases.gwc_inputs("odd")
+    for call in (lambda: sa.ops.build_gwc_volume(a, b, m, G), lambda: sa.ops.build_concat_volume(a, b, m),
+                 lambda: sa.ops.disparity_regression(torch.rand(1, 2 * m, 3, 3), m)):
+        with pytest.raises(sa._lib.SemStereoHipError):
+            call()
+
+
+def test_reference_assertions():
+    a, b, m, G = cases.gwc_inputs("odd")
+    with pytest.raises(AssertionError):
+        sa.ops.build_gwc_volume(a, b, m, 5)
+    with pytest.raises(AssertionError):
+        sa.ops.disparity_regression(torch.rand(1, 1, 6, 3, 3), 3)
+    with pytest.raises(AssertionError):
+        sa.ops.disparity_variance(torch.rand(6, 3, 3), 3, torch.rand(1, 1, 3, 3))
+
+
+def test_segment_state_dict_keys_are_the_references():
+    seg = sa.HotSegment(64)
+    ours = {k for k in seg.state_dict() if not k.endswith("num_batches_tracked")}
+    table = oseg.segment_param_shapes()          # validated against the reference in make_golden.py
+    assert ours == set(table)
+    for k, v in seg.state_dict().items():
+        if k in table:
+            assert tuple(v.shape) == tuple(table[k]), k
+
+
+def test_load_reference_state_dict_with_dataparallel_prefix():
+    seg = sa.HotSegment(64)
+    P = oseg.deterministic_params()
+    sd = {"module." + k: v for k, v in P.items()}
+    sd["module.feature.conv_stem.weight"] = torch.zeros(1)       # a key outside the segment is ignored
+    res = seg.load_reference_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    assert torch.equal(seg.hourglass_att.conv5[0].weight, P["hourglass_att.conv5.0.weight"])
+
+
+def test_accelerate_shares_parameters_and_keeps_keys():
+    class RefLikeHourglass(nn.Module):       # attribute tree of the reference's hourglass class
+        def __init__(self):
+            super().__init__()
+            hg = sa.modules.hourglass(32)
+            for n in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "redir1", "redir2"):
+                setattr(self, n, getattr(hg, n))
+            ab = nn.Module()
+            ab.block, ab.dim_3d, ab.num_heads, ab.scale_3d = (4, 4, 4), 128, 16, 8 ** -0.5
+            ab.qkv_3d, ab.final1x1 = hg.attention_block.qkv_3d, hg.attention_block.final1x1
+            self.attention_block = ab
+
+    holder = nn.Module()
+    holder.hourglass_att = RefLikeHourglass()
+    holder.patch = nn.Conv3d(32, 32, kernel_size=(1, 3, 3), groups=32, padding=(0, 1, 1), bias=False)
+    keys = list(holder.state_dict().keys())
+    w = holder.hourglass_att.conv1[0][0].weight
+    done = sa.accelerate(holder)
+    assert sorted(done) == ["hourglass_att", "patch"]
+    assert list(holder.state_dict().keys()) == keys
+    assert isinstance(holder.hourglass_att, sa.modules.hourglass) and isinstance(holder.patch, sa.modules.DepthwisePatch)
+    assert holder.hourglass_att.conv1[0][0].weight is w            # shared Parameter, not a copy
+    assert sa.accelerate(holder) == []                              # idempotent
+
+
+@pytest.mark.parametrize("name", ["attn_pad", "attn_pad_w", "hourglass_att"])
+def test_training_path_of_module_twins_matches_oracle(golden, name):
+    """With autograd on, the twins run stock PyTorch layers (BatchNorm in eval here): same numbers
+    as the oracle, on CPU."""
+    seg = sa.HotSegment(64)
+    seg.load_state_dict(oseg.deterministic_params(), strict=False)
+    seg.eval()
+    kind, shape, block = cases.STACK[name]
+    mod = seg
+    for part in kind.split("."):
+        mod = getattr(mod, part)
+    before = sa.modules.PATH_COUNTS["torch"]
+    y = mod(cases.stack_input(name).requires_grad_(True))
+    assert sa.modules.PATH_COUNTS["torch"] > before
+    ref = torch.as_tensor(golden["stack"][f"stack/{name}"])
+    assert torch.allclose(y.detach(), ref, atol=2e-5, rtol=1e-5)
+    y.sum().backward()
+
+
+def test_fold_bn_matches_batch_norm():
+    bn = nn.BatchNorm3d(7).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-1, 1)
+        bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+    x = torch.randn(2, 7, 3, 4, 5)
+    s, b = sa.modules.fold_bn(bn)
+    assert torch.allclose(x * s.reshape(1, -1, 1, 1, 1) + b.reshape(1, -1, 1, 1, 1), bn(x), atol=1e-6)
+
+
+def test_shard_bounds_cover_the_batch_exactly_once():
+    for n in (1, 7, 8, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [sa.dist.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

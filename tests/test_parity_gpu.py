@@ -332,22 +332,3 @@ def test_hot_segment_vs_reference_fixture(sa, golden, name):
     check(f"segment/{name}/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
     check(f"segment/{name}/pred", r["pred"], g[f"{name}/pred"], 1e-3)
     REPORT[f"segment/{name}/epe_vs_ref"] = oops.epe(r["pred"].cpu(), torch.as_tensor(g[f"{name}/pred"]))
-
-
-def test_drop_in_accelerate_keeps_state_dict_and_matches_fused_segment(sa):
-    """`accelerate()` on a module tree built from plain torch layers with the reference's structure
-    (what the reference's classes produce) swaps in HIP twins that share parameters."""
-    import torch.nn as nn
-    ref_like = nn.Sequential()          # stands in for a reference hourglass: same attribute tree
-    hg = sa.modules.hourglass(32)
-    plain = nn.Module()
-    for n in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "redir1", "redir2"):
-        setattr(plain, n, getattr(hg, n))
-    plain.attention_block = hg.attention_block
-    holder = nn.Module()
-    holder.hourglass_att = plain
-    keys = list(holder.state_dict().keys())
-    done = sa.accelerate(holder)
-    assert done == ["hourglass_att"] and list(holder.state_dict().keys()) == keys
-    assert isinstance(holder.hourglass_att, sa.modules.hourglass)
-    del ref_like
