@@ -105,7 +105,24 @@ int ss_disparity_variance_fwd(const float* prob, const float* disparity, float* 
 int ss_softmax_regression_fwd(const float* logits, float* prob, float* disp, float* var,
                               int B, int maxdisp, int H, int W, ss_stream_t stream);
 
-/* regression_topk(cost, disparity_samples, k)          models/submodule.py:434-442
+/* Fused models/SemStereo.py:286-293 (variance gate, Propagation x2 [models/submodule.py:290-307],
+ * 5-sample SpatialTransformer_grid, channel-mean correlation, softmax over the 5 samples):
+ *   strength[b,t,y,x] = softmax_t( mean_c left[b,c,y,x] * warp(right, pred0[b,nb_t(y,x)])[c]
+ *                                  * sigmoid(beta + gamma * var[b,0,nb_t(y,x)]) )
+ * with nb_t the five replicate-padded diagonal neighbours.  left,right [B,C,H,W]; pred0 [B,H,W];
+ * var [B,1,H,W]; gamma, beta: 1-element device arrays -> strength [B,5,H,W] */
+int ss_sample_strength_fwd(const float* left, const float* right, const float* pred0, const float* var,
+                           const float* gamma, const float* beta, float* strength,
+                           int B, int C, int H, int W, ss_stream_t stream);
+/* Fused models/SemStereo.py:295-310 (Propagation_prob [models/submodule.py:361-377] weighted by
+ * strength, softmax over D, descending stable sort, top-k, ascending re-sort, gathers, softmax over
+ * the k, expectation):  logits [B,1,2m,H,W], strength [B,5,H,W] ->
+ *   samples [B,k,H,W] (candidate disparities, ascending, as floats), att_topk [B,1,k,H,W] (their
+ *   probabilities), pred_att [B,H,W].  2m <= 128. */
+int ss_topk_candidates_fwd(const float* logits, const float* strength, float* samples, float* att_topk,
+                           float* pred_att, int B, int maxdisp, int H, int W, int k, ss_stream_t stream);
+
+/* regression_topk(cost, disparity_samples, k)         models/submodule.py:434-442
  * per pixel: the k largest costs (ties: lower index first), softmax over them, expectation of
  * the matching candidates.  cost, samples [B,nd,H,W] -> [B,1,H,W].  1 <= k <= min(nd, 32). */
 int ss_regression_topk_fwd(const float* cost, const float* samples, float* out,

@@ -31,6 +31,8 @@ _SIGNATURES = {
     "ss_disparity_variance_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ss_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_regression_topk_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_sample_strength_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ss_topk_candidates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_channel_gate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

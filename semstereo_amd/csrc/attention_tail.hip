@@ -1,0 +1,419 @@
+// The "attention tail" of SemStereo.forward between the two cost volumes (reference
+// models/SemStereo.py:286-310), fused into two kernels:
+//
+//  ss_sample_strength_fwd   :286-293  variance gate, the two 5-tap propagations, the 5-candidate
+//                                     warp of the 1/4-scale right features, their channel-mean
+//                                     correlation with the left features, softmax over the 5
+//  ss_topk_candidates_fwd   :295-310  5-tap propagation of the logits volume weighted by that
+//                                     strength, softmax over D, the 24 most probable disparities
+//                                     (descending sort, stable), re-sorted ascending, their
+//                                     probabilities, and the soft-argmax over them
+//
+// The reference runs ~25 ATen kernels here, materialises a [B,5,D,H,W] volume and fully sorts D
+// values per pixel to keep 24.  Both kernels are one thread per pixel with lanes along W (every
+// plane access is a coalesced row segment); the candidate kernel parks the pixel's D logits and
+// probabilities in LDS ([D][threads], conflict-free) and ranks them by counting.
+#include <algorithm>
+#include <limits.h>
+
+#include "common.h"
+
+namespace {
+
+// (dy, dx) of the five propagation taps, models/submodule.py:295-300 / 367-372
+__device__ __constant__ int kTapDy[5] = {-1, 0, 1, 1, -1};
+__device__ __constant__ int kTapDx[5] = {-1, 0, 1, -1, 1};
+
+struct Taps4 {
+    int o_nw, o_ne, o_sw, o_se;
+    float w_nw, w_ne, w_sw, w_se;
+};
+
+// identical arithmetic to warp.hip::make_taps (kept in sync by tests/test_parity_gpu.py)
+__device__ __forceinline__ Taps4 bilinear_taps(float disp, int h, int w, int H, int W, float half_w, float half_h) {
+    const float gx = ((float)w - disp) / half_w - 1.0f;
+    const float gy = (float)h / half_h - 1.0f;
+    const float ix = ss::mul_rn(gx + 1.0f, half_w);
+    const float iy = ss::mul_rn(gy + 1.0f, half_h);
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float fw = ix - xw, fe = 1.0f - fw, fn = iy - yn, fs = 1.0f - fn;
+    const float xe = xw + 1.0f, ys = yn + 1.0f;
+    const bool mw = (xw > -1.0f) && (xw < (float)W), me = (xe > -1.0f) && (xe < (float)W);
+    const bool mn = (yn > -1.0f) && (yn < (float)H), ms = (ys > -1.0f) && (ys < (float)H);
+    const int ixw = (int)xw, iyn = (int)yn;
+    Taps4 t;
+    t.w_nw = ss::mul_rn(fs, fe); t.w_ne = ss::mul_rn(fs, fw);
+    t.w_sw = ss::mul_rn(fn, fe); t.w_se = ss::mul_rn(fn, fw);
+    t.o_nw = (mn && mw) ? iyn * W + ixw : -1;
+    t.o_ne = (mn && me) ? iyn * W + ixw + 1 : -1;
+    t.o_sw = (ms && mw) ? (iyn + 1) * W + ixw : -1;
+    t.o_se = (ms && me) ? (iyn + 1) * W + ixw + 1 : -1;
+    return t;
+}
+
+__device__ __forceinline__ float bilinear(const float* __restrict__ plane, const Taps4& t) {
+    const float a = (t.o_nw >= 0) ? plane[t.o_nw] : 0.f;
+    const float b = (t.o_ne >= 0) ? plane[t.o_ne] : 0.f;
+    const float c = (t.o_sw >= 0) ? plane[t.o_sw] : 0.f;
+    const float d = (t.o_se >= 0) ? plane[t.o_se] : 0.f;
+    float r = ss::mul_rn(a, t.w_nw);
+    r = ss::add_rn(r, ss::mul_rn(b, t.w_ne));
+    r = ss::add_rn(r, ss::mul_rn(c, t.w_sw));
+    r = ss::add_rn(r, ss::mul_rn(d, t.w_se));
+    return r;
+}
+
+// strength[b,t,y,x] = softmax_t( mean_c left[c] * warp(right, pred0[nb_t])[c]  *  sigmoid(beta + gamma * var[nb_t]) )
+__global__ __launch_bounds__(256) void sample_strength_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                               const float* __restrict__ pred0, const float* __restrict__ var,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ strength, int C, int H, int W,
+                                                               float half_w, float half_h, long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long plane = (long long)H * W;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long b = i / plane;
+    const float g = gamma[0], bt = beta[0];
+    Taps4 tp[5];
+    float gate[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);   // replicate pad
+        const long long nb = b * plane + (long long)yy * W + xx;
+        const float v = ss::add_rn(bt, ss::mul_rn(g, var[nb]));
+        gate[t] = 1.0f / (1.0f + expf(-v));
+        tp[t] = bilinear_taps(pred0[nb], y, x, H, W, half_w, half_h);
+    }
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long pix = (long long)y * W + x;
+    for (int c = 0; c < C; ++c) {
+        const float l = left[(b * C + c) * plane + pix];
+        const float* rp = right + (b * C + c) * plane;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc[t] = ss::add_rn(acc[t], ss::mul_rn(l, bilinear(rp, tp[t])));
+    }
+    float z[5], mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { z[t] = ss::mul_rn(acc[t] / (float)C, gate[t]); mx = fmaxf(mx, z[t]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { z[t] = expf(z[t] - mx); sum = ss::add_rn(sum, z[t]); }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) strength[(b * 5 + t) * plane + pix] = z[t] / sum;
+}
+
+// One thread per pixel; LDS: aw[D][T] and p[D][T] (T = blockDim.x threads).
+__global__ void topk_candidates_kernel(const float* __restrict__ logits, const float* __restrict__ strength,
+                                       float* __restrict__ samples, float* __restrict__ att_topk,
+                                       float* __restrict__ pred_att, int D, int H, int W, int K, int m,
+                                       long long total) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = blockDim.x, tid = threadIdx.x;
+    float* aw = lds;                    // [D][T]
+    float* pr = lds + (size_t)D * T;    // [D][T]
+    const long long i = blockIdx.x * (long long)T + tid;
+    if (i >= total) return;             // no barriers below: threads are independent
+    const long long plane = (long long)H * W;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long b = i / plane;
+    const long long pix = (long long)y * W + x;
+    int nb[5];
+    float st[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);
+        nb[t] = yy * W + xx;
+        st[t] = strength[(b * 5 + t) * plane + pix];
+    }
+    // aw[d] = sum_t logits[d, nb_t] * strength[t]   (:295-297), running max for the softmax (:298)
+    const float* lb = logits + b * D * plane;
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) {
+        const float* lp = lb + d * plane;
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) a = ss::add_rn(a, ss::mul_rn(lp[nb[t]], st[t]));
+        aw[d * T + tid] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+    for (int d = 0; d < D; ++d) { const float e = expf(aw[d * T + tid] - mx); pr[d * T + tid] = e; sum = ss::add_rn(sum, e); }
+    for (int d = 0; d < D; ++d) pr[d * T + tid] = pr[d * T + tid] / sum;
+
+    // rank by probability, descending, ties to the lower index (stable sort): selected iff rank < K.
+    // Pass 1 finds the max logit among the selected (for the :308 softmax); passes 2, 3 emit in
+    // ascending index order, which is exactly ind_k.sort(2, False) of :303.
+    float smax = -INFINITY;
+    unsigned long long sel_lo = 0ull, sel_hi = 0ull;     // D <= 128
+    for (int c = 0; c < D; ++c) {
+        const float v = pr[c * T + tid];
+        int rank = 0;
+        for (int j = 0; j < D; ++j) {
+            const float u = pr[j * T + tid];
+            rank += (u > v) || (u == v && j < c);
+        }
+        if (rank < K) {
+            if (c < 64) sel_lo |= 1ull << c; else sel_hi |= 1ull << (c - 64);
+            smax = fmaxf(smax, aw[c * T + tid]);
+        }
+    }
+    float esum = 0.f;
+    int cnt = 0;
+    for (int c = 0; c < D; ++c) {
+        const bool s = (c < 64) ? ((sel_lo >> c) & 1ull) : ((sel_hi >> (c - 64)) & 1ull);
+        if (!s) continue;
+        samples[(b * K + cnt) * plane + pix] = (float)(c - m);
+        att_topk[(b * K + cnt) * plane + pix] = pr[c * T + tid];
+        esum = ss::add_rn(esum, expf(aw[c * T + tid] - smax));
+        ++cnt;
+    }
+    float acc = 0.f;
+    for (int c = 0; c < D; ++c) {
+        const bool s = (c < 64) ? ((sel_lo >> c) & 1ull) : ((sel_hi >> (c - 64)) & 1ull);
+        if (!s) continue;
+        acc = ss::add_rn(acc, ss::mul_rn(expf(aw[c * T + tid] - smax) / esum, (float)(c - m)));
+    }
+    pred_att[b * plane + pix] = acc;
+}
+
+// Same contract, D known at compile time: the pixel's D probabilities live in registers and the
+// ranking is a count of strictly greater values (2 VALU ops per pair, no LDS traffic).  Stable-sort
+// semantics from the counts alone: values of one tie group share their count G and occupy ranks
+// G .. G+E-1 in index order; with g* = max{G < K} every group with G < g* is selected whole and the
+// group G == g* contributes its first K - g* members in index order.
+template <int D>
+__global__ __launch_bounds__(128) void topk_candidates_reg(const float* __restrict__ logits, const float* __restrict__ strength,
+                                                            float* __restrict__ samples, float* __restrict__ att_topk,
+                                                            float* __restrict__ pred_att, int H, int W, int K, int m,
+                                                            long long total) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = 128;
+    const int tid = threadIdx.x;
+    float* aw = lds;                                            // [D][T] logits after propagation
+    int* gl = reinterpret_cast<int*>(lds + (size_t)D * T);      // [D][T] strictly-greater counts
+    const long long i = blockIdx.x * (long long)T + tid;
+    if (i >= total) return;
+    const long long plane = (long long)H * W;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long b = i / plane;
+    const long long pix = (long long)y * W + x;
+    int nb[5];
+    float st[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);
+        nb[t] = yy * W + xx;
+        st[t] = strength[(b * 5 + t) * plane + pix];
+    }
+    const float* lb = logits + b * D * plane;
+    float p[D];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float* lp = lb + d * plane;
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) a = ss::add_rn(a, ss::mul_rn(lp[nb[t]], st[t]));
+        p[d] = a;
+        aw[d * T + tid] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { p[d] = expf(p[d] - mx); sum = ss::add_rn(sum, p[d]); }
+#pragma unroll
+    for (int d = 0; d < D; ++d) p[d] = p[d] / sum;
+
+#pragma unroll
+    for (int d = 0; d < D; ++d) gl[d * T + tid] = __float_as_int(p[d]);   // slot c holds p[c] until its count replaces it
+
+    int gstar = -1;
+#pragma unroll 2
+    for (int c = 0; c < D; ++c) {
+        const float v = __int_as_float(gl[c * T + tid]);
+        int g = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) g += (p[j] > v) ? 1 : 0;
+        gl[c * T + tid] = g;
+        if (g < K) gstar = max(gstar, g);
+    }
+    int quota = K - gstar;               // members of the boundary tie group still to take
+    float smax = -INFINITY;
+    unsigned long long sel[(D + 63) / 64];
+#pragma unroll
+    for (int w = 0; w < (D + 63) / 64; ++w) sel[w] = 0ull;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const int g = gl[c * T + tid];
+        bool s = g < gstar;
+        if (g == gstar && quota > 0) { s = true; --quota; }
+        if (s) { sel[c / 64] |= 1ull << (c % 64); smax = fmaxf(smax, aw[c * T + tid]); }
+    }
+    float esum = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        if (!((sel[c / 64] >> (c % 64)) & 1ull)) continue;
+        samples[(b * K + cnt) * plane + pix] = (float)(c - m);
+        att_topk[(b * K + cnt) * plane + pix] = p[c];
+        esum = ss::add_rn(esum, expf(aw[c * T + tid] - smax));
+        ++cnt;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        if (!((sel[c / 64] >> (c % 64)) & 1ull)) continue;
+        acc = ss::add_rn(acc, ss::mul_rn(expf(aw[c * T + tid] - smax) / esum, (float)(c - m)));
+    }
+    pred_att[b * plane + pix] = acc;
+}
+
+// softmax over D + expectation + variance (models/SemStereo.py:281-285): 64 pixels x 4 waves, the
+// D axis split over the waves in 16-plane chunks whose exponentials stay in registers.
+template <int NCH>   // 16-plane chunks per wave: D <= 64*NCH
+__global__ __launch_bounds__(256) void softmax_regress_split(const float* __restrict__ logits, float* __restrict__ prob,
+                                                              float* __restrict__ disp, float* __restrict__ var,
+                                                              int D, int m, long long plane, long long total) {
+    __shared__ float red[4][64];
+    __shared__ float part[4 * NCH][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long i = blockIdx.x * 64LL + lane;
+    const bool active = i < total;
+    const long long pix = active ? i % plane : 0, b = active ? i / plane : 0;
+    const float* lp = logits + b * D * plane + pix;
+    float e[NCH][16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < NCH; ++n)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int d = (n * 4 + wave) * 16 + k;
+            e[n][k] = (active && d < D) ? lp[d * plane] : -INFINITY;
+            mx = fmaxf(mx, e[n][k]);
+        }
+    red[wave][lane] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+    __syncthreads();
+    // sum of exponentials in plane order d = 0..D-1 (sequential like ATen's softmax accumulation)
+#pragma unroll
+    for (int n = 0; n < NCH; ++n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int d = (n * 4 + wave) * 16 + k;
+            e[n][k] = (d < D) ? expf(e[n][k] - mx) : 0.f;
+            s = ss::add_rn(s, e[n][k]);
+        }
+        part[n * 4 + wave][lane] = s;
+    }
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4 * NCH; ++c) sum = ss::add_rn(sum, part[c][lane]);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NCH; ++n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int d = (n * 4 + wave) * 16 + k;
+            e[n][k] = e[n][k] / sum;
+            if (prob && active && d < D) prob[(b * D + d) * plane + pix] = e[n][k];
+            s = ss::add_rn(s, ss::mul_rn(e[n][k], (float)(d - m)));
+        }
+        part[n * 4 + wave][lane] = s;
+    }
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4 * NCH; ++c) mean = ss::add_rn(mean, part[c][lane]);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NCH; ++n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int d = (n * 4 + wave) * 16 + k;
+            const float t = (float)(d - m) - mean;
+            s = ss::add_rn(s, ss::mul_rn(e[n][k], ss::mul_rn(t, t)));
+        }
+        part[n * 4 + wave][lane] = s;
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4 * NCH; ++c) v = ss::add_rn(v, part[c][lane]);
+        disp[i] = mean;
+        var[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int ss_sample_strength_fwd(const float* left, const float* right, const float* pred0, const float* var,
+                                      const float* gamma, const float* beta, float* strength, int B, int C, int H, int W,
+                                      ss_stream_t stream) {
+    SS_REQUIRE(left && right && pred0 && var && gamma && beta && strength);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0);
+    const long long total = (long long)B * H * W;
+    const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
+    hipLaunchKernelGGL(sample_strength_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
+                       ss::as_stream(stream), left, right, pred0, var, gamma, beta, strength, C, H, W, half_w, half_h, total);
+    return ss::check_launch();
+}
+
+extern "C" int ss_topk_candidates_fwd(const float* logits, const float* strength, float* samples, float* att_topk,
+                                      float* pred_att, int B, int maxdisp, int H, int W, int k, ss_stream_t stream) {
+    SS_REQUIRE(logits && strength && samples && att_topk && pred_att);
+    SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0 && k > 0);
+    const int D = 2 * maxdisp;
+    SS_REQUIRE(k <= D);
+    if (D > 128) return SS_ERR_UNSUPPORTED;
+    const int T = 128;
+    const long long npix = (long long)B * H * W;
+#define SS_TOPK_REG(DD)                                                                                              \
+    if (D == DD) {                                                                                                   \
+        auto kr = topk_candidates_reg<DD>;                                                                           \
+        const size_t bytes = (size_t)2 * DD * T * sizeof(float);                                                     \
+        if (bytes > 64 * 1024) {                                                                                     \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr),                                    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);              \
+            if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }                                    \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kr, dim3((unsigned)ss::ceil_div_ll(npix, T)), dim3(T), bytes, ss::as_stream(stream),     \
+                           logits, strength, samples, att_topk, pred_att, H, W, k, maxdisp, npix);                   \
+        return ss::check_launch();                                                                                   \
+    }
+    SS_TOPK_REG(32)
+    SS_TOPK_REG(64)
+    SS_TOPK_REG(96)
+#undef SS_TOPK_REG
+    const size_t lds = (size_t)2 * D * T * sizeof(float);
+    auto kern = topk_candidates_kernel;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+    }
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(kern, dim3((unsigned)ss::ceil_div_ll(total, T)), dim3(T), lds, ss::as_stream(stream), logits,
+                       strength, samples, att_topk, pred_att, D, H, W, k, maxdisp, total);
+    return ss::check_launch();
+}
+
+// exported for regression.hip's ss_softmax_regression_fwd
+int ss_softmax_regress_split_launch(const float* logits, float* prob, float* disp, float* var, int B, int maxdisp, int H,
+                                    int W, hipStream_t st) {
+    const int D = 2 * maxdisp;
+    const long long plane = (long long)H * W, total = (long long)B * plane;
+    dim3 grid((unsigned)ss::ceil_div_ll(total, 64));
+    if (D <= 64)
+        hipLaunchKernelGGL(softmax_regress_split<1>, grid, dim3(256), 0, st, logits, prob, disp, var, D, maxdisp, plane, total);
+    else if (D <= 128)
+        hipLaunchKernelGGL(softmax_regress_split<2>, grid, dim3(256), 0, st, logits, prob, disp, var, D, maxdisp, plane, total);
+    else
+        return 1;   // caller falls back to the one-thread-per-pixel kernel
+    return 0;
+}

@@ -33,7 +33,11 @@ __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, 
 
 }  // namespace ss
 
-#define SS_REQUIRE(cond)                \
+// attention_tail.hip: wave-split softmax+regression+variance; returns non-zero if D is out of its range
+int ss_softmax_regress_split_launch(const float* logits, float* prob, float* disp, float* var, int B, int maxdisp, int H,
+                                    int W, hipStream_t st);
+
+#define SS_REQUIRE(cond)              \
     do {                                \
         if (!(cond)) return SS_ERR_INVALID; \
     } while (0)

@@ -18,6 +18,7 @@
 //
 // Roofline: 86-850 flop/byte => bound by the fp32 MFMA rate (157 TFLOP/s).
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -43,7 +44,7 @@ struct Cfg {
 };
 
 template <int KS, int S, int MT, int NT, int TD, int TH, int CIT>
-__global__ __launch_bounds__(256) void conv3d_mfma(const float* __restrict__ in, const float* __restrict__ wpack,
+__global__ __launch_bounds__(256, 2) void conv3d_mfma(const float* __restrict__ in, const float* __restrict__ wpack,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     const float* __restrict__ residual, float* __restrict__ out,
                                                     int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
@@ -82,41 +83,82 @@ __global__ __launch_bounds__(256) void conv3d_mfma(const float* __restrict__ in,
     const size_t in_plane = (size_t)H * W;
     const float* inb = in + (size_t)b * Cin * D * in_plane;
 
-    for (int ci0 = 0; ci0 < Cin; ci0 += CIT) {
-        // ---- stage the input halo tile (zero outside the volume / beyond Cin) ----
-        for (int e = tid; e < C::IN_FLOATS; e += 256) {
-            const int wx = e % C::IW;
-            int r = e / C::IW;
-            const int hy = r % C::IH; r /= C::IH;
-            const int dz = r % C::ID;
-            const int ci = r / C::ID;
-            const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz, gc = ci0 + ci;
-            float v = 0.f;
-            if (gc < Cin && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
-                v = inb[((size_t)gc * D + gd) * in_plane + (size_t)gh * W + gw];
-            ilds[e] = v;
+    // ---- per-thread staging plan, computed once: byte offsets (relative to the chunk base) of the
+    // NIN halo-tile elements and NWQ weight quads this thread moves per chunk, plus validity bits.
+    // Element e = tid + 256*i of the LDS image; out-of-volume elements load offset 0 and are zeroed.
+    constexpr int NIN = (C::IN_FLOATS + 255) / 256;
+    constexpr int NWQ = (C::W_FLOATS / 4 + 255) / 256;
+    static_assert(NIN <= 64 && NWQ <= 32, "validity masks are 64/32 bits");
+    unsigned ioff[NIN], woff[NWQ];
+    unsigned long long imask = 0ull;
+    unsigned wmask = 0u;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int e = tid + 256 * i;
+        const int wx = e % C::IW;
+        int r = e / C::IW;
+        const int hy = r % C::IH; r /= C::IH;
+        const int dz = r % C::ID;
+        const int ci = r / C::ID;
+        const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz;
+        const bool ok = (e < C::IN_FLOATS) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H &&
+                        (unsigned)gw < (unsigned)W;
+        ioff[i] = ok ? (unsigned)((((size_t)ci * D + gd) * in_plane + (size_t)gh * W + gw) * 4) : 0u;
+        imask |= (unsigned long long)ok << i;
+    }
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+        const int e = tid + 256 * j;
+        const int q = e % (C::CO_T / 4);
+        const int row = e / (C::CO_T / 4);              // ci * KT + tap
+        const int co = co0 + q * 4;
+        const bool ok = (e < C::W_FLOATS / 4) && (co + 3 < Cout);
+        woff[j] = ok ? (unsigned)(((size_t)row * Cout + co) * 4) : 0u;
+        wmask |= (unsigned)ok << j;
+    }
+
+    float rin[NIN];
+    float4 rw[NWQ];
+    unsigned long long ilive = imask;
+    unsigned wlive = wmask;
+    // issue the global loads of chunk ci0 into registers (they complete under the MFMA loop)
+    auto prefetch = [&](int ci0) {
+        ilive = imask;
+        wlive = wmask;
+        if (ci0 + CIT > Cin) {        // ragged last chunk: channels >= Cin are zero and must not be read
+#pragma unroll
+            for (int i = 0; i < NIN; ++i)
+                if (ci0 + (tid + 256 * i) / C::CS >= Cin) ilive &= ~(1ull << i);
+#pragma unroll
+            for (int j = 0; j < NWQ; ++j)
+                if (ci0 + (tid + 256 * j) / (C::KT * C::CO_T / 4) >= Cin) wlive &= ~(1u << j);
         }
-        // ---- stage the weight slab [CIT][KT][CO_T] (zero beyond Cin / Cout) ----
-        for (int e = tid; e < C::W_FLOATS / 4; e += 256) {
-            const int q = e % (C::CO_T / 4);
-            const int row = e / (C::CO_T / 4);          // ci * KT + tap
-            const int ci = row / C::KT;
-            const int co = co0 + q * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci0 + ci < Cin) {
-                const float* wp = wpack + ((size_t)(ci0 + ci) * C::KT + (row - ci * C::KT)) * Cout + co;
-                if (co + 3 < Cout && (Cout & 3) == 0) {
-                    v = *reinterpret_cast<const float4*>(wp);
-                } else {
-                    if (co + 0 < Cout) v.x = wp[0];
-                    if (co + 1 < Cout) v.y = wp[1];
-                    if (co + 2 < Cout) v.z = wp[2];
-                    if (co + 3 < Cout) v.w = wp[3];
-                }
-            }
-            *reinterpret_cast<float4*>(&wlds[e * 4]) = v;
+        const char* ib = reinterpret_cast<const char*>(inb + (size_t)ci0 * D * in_plane);
+        const char* wb = reinterpret_cast<const char*>(wpack + (size_t)ci0 * C::KT * Cout);
+#pragma unroll
+        for (int i = 0; i < NIN; ++i)
+            rin[i] = *reinterpret_cast<const float*>(ib + (((ilive >> i) & 1ull) ? ioff[i] : 0u));
+#pragma unroll
+        for (int j = 0; j < NWQ; ++j)
+            rw[j] = *reinterpret_cast<const float4*>(wb + (((wlive >> j) & 1u) ? woff[j] : 0u));
+    };
+
+    prefetch(0);
+    for (int ci0 = 0; ci0 < Cin; ci0 += CIT) {
+        // ---- registers -> LDS: halo tile [CIT][ID][IH][IW] and weight slab [CIT][KT][CO_T] ----
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int e = tid + 256 * i;
+            if (e < C::IN_FLOATS) ilds[e] = ((ilive >> i) & 1ull) ? rin[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NWQ; ++j) {
+            const int e = tid + 256 * j;
+            if (e < C::W_FLOATS / 4)
+                *reinterpret_cast<float4*>(&wlds[e * 4]) = ((wlive >> j) & 1u) ? rw[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        if (ci0 + CIT < Cin) prefetch(ci0 + CIT);
 
         // ---- CIT/2 x KT k-steps of 32x32x2 ----
 #pragma unroll 1
@@ -195,20 +237,47 @@ __global__ __launch_bounds__(256) void conv3d_k3_cout1(const float* __restrict__
     const size_t plane = (size_t)H * W;
     const float* inb = in + (size_t)b * Cin * D * plane;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // staging plan as in conv3d_mfma: offsets once, loads issued one chunk ahead into registers
+    constexpr int NIN = (CIT * CS + 255) / 256;
+    static_assert(NIN <= 64, "validity mask is 64 bits");
+    unsigned ioff[NIN];
+    unsigned long long imask = 0ull;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int e = tid + 256 * i;
+        const int wx = e % IW;
+        int r = e / IW;
+        const int y = r % IH; r /= IH;
+        const int z = r % ID;
+        const int ci = r / ID;
+        const int gw = ow0 - 1 + wx, gh = oh0 - 1 + y, gd = od0 - 1 + z;
+        const bool ok = (e < CIT * CS) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        ioff[i] = ok ? (unsigned)((((size_t)ci * D + gd) * plane + (size_t)gh * W + gw) * 4) : 0u;
+        imask |= (unsigned long long)ok << i;
+    }
+    float rin[NIN];
+    unsigned long long ilive = imask;
+    auto prefetch = [&](int ci0) {
+        ilive = imask;
+        if (ci0 + CIT > Cin) {
+#pragma unroll
+            for (int i = 0; i < NIN; ++i)
+                if (ci0 + (tid + 256 * i) / CS >= Cin) ilive &= ~(1ull << i);
+        }
+        const char* ib = reinterpret_cast<const char*>(inb + (size_t)ci0 * D * plane);
+#pragma unroll
+        for (int i = 0; i < NIN; ++i)
+            rin[i] = *reinterpret_cast<const float*>(ib + (((ilive >> i) & 1ull) ? ioff[i] : 0u));
+    };
+    prefetch(0);
     for (int ci0 = 0; ci0 < Cin; ci0 += CIT) {
-        for (int e = tid; e < CIT * CS; e += 256) {
-            const int wx = e % IW;
-            int r = e / IW;
-            const int y = r % IH; r /= IH;
-            const int z = r % ID;
-            const int ci = r / ID;
-            const int gw = ow0 - 1 + wx, gh = oh0 - 1 + y, gd = od0 - 1 + z, gc = ci0 + ci;
-            float v = 0.f;
-            if (gc < Cin && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
-                v = inb[((size_t)gc * D + gd) * plane + (size_t)gh * W + gw];
-            ilds[e] = v;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int e = tid + 256 * i;
+            if (e < CIT * CS) ilds[e] = ((ilive >> i) & 1ull) ? rin[i] : 0.f;
         }
         __syncthreads();
+        if (ci0 + CIT < Cin) prefetch(ci0 + CIT);
         const int nci = min(CIT, Cin - ci0);
         for (int ci = 0; ci < nci; ++ci) {
             const float* wp = wpack + (size_t)(ci0 + ci) * 27;      // [Cin][27][1]: uniform -> scalar loads
@@ -276,6 +345,50 @@ __global__ __launch_bounds__(256) void depthwise_patch_kernel(const float* __res
     out[i] = acc;
 }
 
+// W % 4 == 0 form: one thread = 4 consecutive columns (16-B loads/stores); the 3 x 6 input window
+// is read as float4 + the two neighbouring scalars per row.
+__global__ __launch_bounds__(256) void depthwise_patch_v4(const float* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ gate, float* __restrict__ out,
+                                                           int C, int D, int H, int W, long long nquads) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;    // over B*C*D*H*(W/4)
+    if (i >= nquads) return;
+    const int WQ = W / 4;
+    const int x0 = (int)(i % WQ) * 4;
+    long long t = i / WQ;
+    const int y = (int)(t % H); t /= H;
+    const long long bcd = t;
+    const long long bc = bcd / D;
+    const int c = (int)(bc % C);
+    const float* ip = in + bcd * H * W;
+    float wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = w[c * 9 + k];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        const float* rp = ip + (long long)yy * W + x0;
+        const float4 m = *reinterpret_cast<const float4*>(rp);
+        float x[6];
+        x[0] = (x0 > 0) ? rp[-1] : 0.f;
+        x[1] = m.x; x[2] = m.y; x[3] = m.z; x[4] = m.w;
+        x[5] = (x0 + 4 < W) ? rp[4] : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv[ky * 3 + kx], x[j + kx], acc[j]);
+    }
+    if (gate) {
+        const float4 g = *reinterpret_cast<const float4*>(gate + bc * H * W + (long long)y * W + x0);
+        acc[0] = ss::mul_rn(1.0f / (1.0f + expf(-g.x)), acc[0]);
+        acc[1] = ss::mul_rn(1.0f / (1.0f + expf(-g.y)), acc[1]);
+        acc[2] = ss::mul_rn(1.0f / (1.0f + expf(-g.z)), acc[2]);
+        acc[3] = ss::mul_rn(1.0f / (1.0f + expf(-g.w)), acc[3]);
+    }
+    *reinterpret_cast<float4*>(out + bcd * H * W + (long long)y * W + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpack, int Cout, int Cin, int KT,
                                     int transposed, long long total) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // over [Cin][KT][Cout]
@@ -326,19 +439,62 @@ extern "C" int ss_conv3d_fwd(const float* in, const float* wpack, const float* s
                            shift, out, Cin, D, H, W, tiles_w, tiles_h, relu);
         return ss::check_launch();
     }
-    const bool wide = Cout > 32;     // 64 output channels per workgroup when there are that many
+    if (Cout % 4 != 0) return SS_ERR_UNSUPPORTED;     // weight slabs are moved as float4
+    // Tile selection.  A workgroup covers MT*32 output channels x (TD x TH rows of 32 columns).
+    // Candidates are ordered from the biggest tile (most operand reuse) to the smallest; the first
+    // one that still gives every CU at least two workgroups wins (one resident workgroup cannot
+    // overlap its own staging with its MFMAs), otherwise the one with the most workgroups.
+    // SS_CONV_TILE=<index> forces a candidate (tuning aid; results are identical for every tile).
+    const int pad = k / 2;
+    const int Do = (D + 2 * pad - k) / stride + 1, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    struct Cand { int mt, nt, td, th; };
+    auto blocks_of = [&](const Cand& c) {
+        return (long long)ss::ceil_div(Wo, 32) * ss::ceil_div(Ho, c.th) * ss::ceil_div(Do, c.td) *
+               ss::ceil_div(Cout, c.mt * 32) * B;
+    };
+    auto pick = [&](const Cand* cands, int n) {
+        const char* forced = getenv("SS_CONV_TILE");
+        if (forced && forced[0] >= '0' && forced[0] - '0' < n) return forced[0] - '0';
+        int best = 0;
+        long long best_blocks = -1;
+        for (int i = 0; i < n; ++i) {
+            if (cands[i].mt * 32 > Cout && cands[i].mt > 1) continue;      // would waste MFMA rows
+            const long long nb = blocks_of(cands[i]);
+            if (nb >= 2 * 256) return i;
+            if (nb > best_blocks) { best_blocks = nb; best = i; }
+        }
+        return best;
+    };
+#define SS_CONV(KS, S, MT, NT, TD, TH, CIT) \
+    return launch_conv<KS, S, MT, NT, TD, TH, CIT>(in, wpack, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st)
     if (k == 3 && stride == 1) {
-        if (wide) return launch_conv<3, 1, 2, 2, 1, 8, 4>(in, wpack, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st);
-        return launch_conv<3, 1, 1, 4, 2, 8, 8>(in, wpack, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st);
+        static const Cand c[] = {{1, 4, 2, 8}, {2, 2, 1, 8}, {2, 1, 1, 4}, {1, 2, 1, 8}, {1, 1, 1, 4}};
+        switch (pick(c, 5)) {
+            case 0: SS_CONV(3, 1, 1, 4, 2, 8, 4);
+            case 1: SS_CONV(3, 1, 2, 2, 1, 8, 4);
+            case 2: SS_CONV(3, 1, 2, 1, 1, 4, 4);
+            case 3: SS_CONV(3, 1, 1, 2, 1, 8, 4);
+            default: SS_CONV(3, 1, 1, 1, 1, 4, 8);
+        }
     }
     if (k == 3 && stride == 2) {
-        if (wide) return launch_conv<3, 2, 2, 2, 1, 8, 2>(in, wpack, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st);
-        return launch_conv<3, 2, 1, 2, 1, 8, 4>(in, wpack, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st);
+        static const Cand c[] = {{2, 2, 1, 8}, {2, 1, 1, 4}, {1, 2, 1, 8}, {1, 1, 1, 4}};
+        switch (pick(c, 4)) {
+            case 0: SS_CONV(3, 2, 2, 2, 1, 8, 2);
+            case 1: SS_CONV(3, 2, 2, 1, 1, 4, 4);
+            case 2: SS_CONV(3, 2, 1, 2, 1, 8, 2);
+            default: SS_CONV(3, 2, 1, 1, 1, 4, 4);
+        }
     }
     if (k == 1 && stride == 1) {
-        if (wide) return launch_conv<1, 1, 2, 2, 1, 8, 16>(in, wpack, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st);
-        return launch_conv<1, 1, 1, 4, 2, 8, 16>(in, wpack, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st);
+        static const Cand c[] = {{2, 2, 1, 8}, {1, 4, 2, 8}, {1, 1, 1, 4}};
+        switch (pick(c, 3)) {
+            case 0: SS_CONV(1, 1, 2, 2, 1, 8, 16);
+            case 1: SS_CONV(1, 1, 1, 4, 2, 8, 8);
+            default: SS_CONV(1, 1, 1, 1, 1, 4, 16);
+        }
     }
+#undef SS_CONV
     return SS_ERR_UNSUPPORTED;
 }
 
@@ -357,6 +513,14 @@ extern "C" int ss_depthwise_patch_fwd(const float* in, const float* w, const flo
     SS_REQUIRE(in && w && out);
     SS_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
     const long long total = (long long)B * C * D * H * W;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gate);
+    if (W % 4 == 0 && (bits & 15) == 0) {
+        const long long nq = total / 4, qb = ss::ceil_div_ll(nq, 256);
+        if (qb > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(depthwise_patch_v4, dim3((unsigned)qb), dim3(256), 0, ss::as_stream(stream), in, w, gate, out, C,
+                           D, H, W, nq);
+        return ss::check_launch();
+    }
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(depthwise_patch_kernel, dim3((unsigned)blocks), dim3(256), 0, ss::as_stream(stream), in, w, gate,

@@ -262,8 +262,10 @@ extern "C" int ss_softmax_regression_fwd(const float* logits, float* prob, float
                                          int H, int W, ss_stream_t stream) {
     SS_REQUIRE(logits && disp && var);
     SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0);
+    if (ss_softmax_regress_split_launch(logits, prob, disp, var, B, maxdisp, H, W, ss::as_stream(stream)) == 0)
+        return ss::check_launch();
     const long long plane = (long long)H * W, total = (long long)B * plane;
-    hipLaunchKernelGGL(softmax_regress_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(softmax_regress_kernel,dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
                        ss::as_stream(stream), logits, prob, disp, var, 2 * maxdisp, maxdisp, plane, total);
     return ss::check_launch();
 }

@@ -351,6 +351,38 @@ def warp_correlation(x, y, disparity_samples):
     return out
 
 
+def sample_strength(left, right, pred0, var, gamma, beta):
+    """Fused models/SemStereo.py:286-293: -> disparity_sample_strength [B,5,H,W] (softmaxed over the five
+    propagated candidates).  left, right [B,C,H,W]; pred0 [B,H,W]; var [B,1,H,W]; gamma, beta 1-element
+    tensors.  Inference only."""
+    left, right, pred0, var = _c(left), _c(right), _c(pred0), _c(var)
+    gamma, beta = _c(gamma.detach().reshape(1)), _c(beta.detach().reshape(1))
+    dev = _lib.require_device(left, right, pred0, var, gamma, beta)
+    B, C, H, W = left.shape
+    assert pred0.shape == (B, H, W) and var.shape == (B, 1, H, W)
+    out = torch.empty((B, 5, H, W), dtype=left.dtype, device=left.device)
+    with torch.cuda.device(dev):
+        call("ss_sample_strength_fwd", ptr(left), ptr(right), ptr(pred0), ptr(var), ptr(gamma), ptr(beta), ptr(out),
+             B, C, H, W)
+    return out
+
+
+def topk_candidates(att_weights, strength, maxdisp, k):
+    """Fused models/SemStereo.py:295-310: att_weights [B,1,2m,H,W] (up-sampled logits), strength [B,5,H,W]
+    -> (att_topk [B,1,k,H,W], disparity_sample_topk [B,k,H,W], pred_att [B,H,W]).  Inference only."""
+    att_weights, strength = _c(att_weights), _c(strength)
+    dev = _lib.require_device(att_weights, strength)
+    B, one, D, H, W = att_weights.shape
+    assert one == 1 and D == 2 * maxdisp and strength.shape == (B, 5, H, W)
+    samples = torch.empty((B, k, H, W), dtype=att_weights.dtype, device=att_weights.device)
+    att_topk = torch.empty((B, 1, k, H, W), dtype=att_weights.dtype, device=att_weights.device)
+    pred_att = torch.empty((B, H, W), dtype=att_weights.dtype, device=att_weights.device)
+    with torch.cuda.device(dev):
+        call("ss_topk_candidates_fwd", ptr(att_weights), ptr(strength), ptr(samples), ptr(att_topk), ptr(pred_att),
+             B, int(maxdisp), H, W, int(k))
+    return att_topk, samples, pred_att
+
+
 def channel_gate(att_logits, cv):
     """channelAtt's gating (models/SemStereo.py:101-102): sigmoid(att)[:, :, None] * cv.  Inference only."""
     att_logits, cv = _c(att_logits), _c(cv)

@@ -85,14 +85,15 @@ class HotSegment(nn.Module):
             prob0 = F.softmax(att_weights.squeeze(1), dim=1)
             pred0 = ops.disparity_regression(prob0, m4)
             var = ops.disparity_variance(prob0, m4, pred0.unsqueeze(1))
+        if fast:
+            strength = ops.sample_strength(fl4, fr4, pred0, var, self.gamma, self.beta)        # :286-293 fused
+            att_topk, samples, pred_att = ops.topk_candidates(att_weights, strength, m4, TOPK)  # :295-310 fused
+            return att_topk, samples, pred_att, pred0
         var = torch.sigmoid(self.beta + self.gamma * var)                                      # :286-287
         var_samples = propagation(var)                                                         # :288
         disp_samples = propagation(pred0.unsqueeze(1))                                         # :289
-        if fast:
-            strength = ops.warp_correlation(fl4, fr4, disp_samples)                            # :291-292 fused
-        else:
-            right_w, left_b = ops.SpatialTransformer_grid(fl4, fr4, disp_samples)
-            strength = (left_b * right_w).mean(dim=1)
+        right_w, left_b = ops.SpatialTransformer_grid(fl4, fr4, disp_samples)                  # :291
+        strength = (left_b * right_w).mean(dim=1)                                              # :292
         strength = torch.softmax(strength * var_samples, dim=1)                                # :293
         aw = (propagation_prob(att_weights) * strength.unsqueeze(2)).sum(dim=1, keepdim=True)  # :295-297
         aw_prob = F.softmax(aw, dim=2)                                                         # :298
@@ -107,8 +108,11 @@ class HotSegment(nn.Module):
     # ---- models/SemStereo.py:314-323 ---------------------------------------------------
     def matching_branch(self, fl4, fr4, att_topk, samples):
         fast = M._inference(self, fl4, fr4, att_topk)
-        cl = self.concat_feature(fl4)                                                          # :314
-        cr = self.concat_feature(fr4)                                                          # :315
+        if fast:     # one MIOpen call for both views (the weights are shared): :314-315
+            cl, cr = self.concat_feature(torch.cat((fl4, fr4), dim=0)).split(fl4.shape[0], dim=0)
+        else:
+            cl = self.concat_feature(fl4)                                                      # :314
+            cr = self.concat_feature(fr4)                                                      # :315
         if fast:
             volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                      # :316 + :318 fused
         else:

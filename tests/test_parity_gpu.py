@@ -157,6 +157,45 @@ def test_topk_generic_k_and_ties(sa):
     check("topk/ties", sa.ops.regression_topk(dev(c), dev(s), 2), oops.regression_topk(c, s, 2), 1e-5)
 
 
+@pytest.mark.parametrize("m", [16, 20, 32])      # D = 32, 64: register kernel; D = 40: generic LDS kernel
+def test_attention_tail_fused_kernels(sa, m):
+    """ss_sample_strength_fwd (:286-293) and ss_topk_candidates_fwd (:295-310) against the oracle's
+    op-by-op composition of the same lines."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, C, H, W, K = 2, 24, 11, 20, 24
+    left, right = dd.stereo_features(B, C, H, W, 5, max_shift=4)
+    pred0 = dd.t_uniform((B, H, W), 111, -6.0, 6.0)
+    var = dd.t_uniform((B, 1, H, W), 112, 0.0, 30.0)
+    gamma, beta = torch.tensor([0.25]), torch.tensor([2.0])
+    v = torch.sigmoid(beta + gamma * var)
+    rw, lb = oops.SpatialTransformer_grid(left, right, oops.propagation(pred0.unsqueeze(1)))
+    strength = torch.softmax((lb * rw).mean(dim=1) * oops.propagation(v), dim=1)
+    got = sa.ops.sample_strength(dev(left), dev(right), dev(pred0), dev(var), dev(gamma), dev(beta))
+    check("sample_strength", got, strength, 1e-6, 1e-6)
+
+    logits = dd.t_normalish((B, 1, 2 * m, H, W), 113) * 3.0
+    aw = (oops.propagation_prob(logits) * strength.unsqueeze(2)).sum(dim=1, keepdim=True)
+    prob = F.softmax(aw, dim=2)
+    _, ind = prob.sort(dim=2, descending=True, stable=True)
+    ind_k = ind[:, :, :K].sort(2, False)[0]
+    att_topk = torch.gather(prob, 2, ind_k)
+    samples = ind_k.squeeze(1).float() - m
+    pred_att = (F.softmax(torch.gather(aw, 2, ind_k).squeeze(1), dim=1) * samples).sum(dim=1)
+    a, s, p = sa.ops.topk_candidates(dev(logits), dev(strength), m, K)
+    assert torch.equal(s.cpu(), samples), "candidate sets differ"
+    check("topk_candidates/att_topk", a, att_topk, 1e-6, 1e-6)
+    check("topk_candidates/pred_att", p, pred_att, 1e-5, 1e-6)
+    # exact ties in probability (two identical logit planes): lower index wins, as in a stable sort
+    logits[:, :, 7] = logits[:, :, 3]
+    aw = (oops.propagation_prob(logits) * strength.unsqueeze(2)).sum(dim=1, keepdim=True)
+    prob = F.softmax(aw, dim=2)
+    _, ind = prob.sort(dim=2, descending=True, stable=True)
+    samples = ind[:, :, :K].sort(2, False)[0].squeeze(1).float() - m
+    _, s, _ = sa.ops.topk_candidates(dev(logits), dev(strength), m, K)
+    assert torch.equal(s.cpu(), samples), "tie handling differs"
+
+
 def test_channel_gate(sa):
     from oracle import detdata as dd
     att, cv = dd.t_normalish((2, 8, 6, 12), 61), dd.t_normalish((2, 8, 5, 6, 12), 62)
