@@ -147,6 +147,19 @@ int ss_conv3d_fwd(const float* in, const float* wpack, const float* scale, const
                   const float* residual, float* out,
                   int B, int Cin, int D, int H, int W, int Cout, int k, int stride, int relu,
                   ss_stream_t stream);
+/* Same contract as ss_conv3d_fwd for k = 3, stride 1, computed on the bf16 matrix core with every fp32
+ * operand split exactly into three bf16 terms ("split-bf16"): nterms = 6 keeps all cross terms down to
+ * 2^-24 (measured error below the exact-fp32 MFMA's, tools/exp_split_bf16.hip), nterms = 3 keeps
+ * hi*hi + hi*mid + mid*hi.  wsplit comes from ss_pack_conv3d_weights_bf16s (16-byte aligned).
+ * stride 2 returns SS_ERR_UNSUPPORTED (use ss_conv3d_fwd). */
+int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                        const float* residual, float* out,
+                        int B, int Cin, int D, int H, int W, int Cout, int stride, int relu, int nterms,
+                        ss_stream_t stream);
+/* Conv3d weight [Cout,Cin,3,3,3] fp32 -> split/packed bf16 fragments
+ * [ceil(Cin/8)][14 tap pairs][3 terms][2 halves][Cout][8] (ceil(Cin/8)*14*3*2*Cout*16 bytes). */
+int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
+
 /* ConvTranspose3d(k3, s2, p1, output_padding 1, bias=False) [+BN] fused with the 1x1x1 skip
  * projection of hourglass.forward (models/SemStereo.py:141-142):
  *   out = relu?( scale*deconv(in) + shift + skip_scale*conv1x1(skip) + skip_shift )

@@ -1,0 +1,314 @@
+// 3x3x3 Conv3d (+ folded BatchNorm, residual, ReLU) with fp32 operands emulated on the bf16 matrix
+// core: "split-bf16" engine for the same layers as conv3d.hip (gfx950 v_mfma_f32_32x32x16_bf16).
+//
+// Every fp32 value is split exactly into three bf16 terms x = hi + mid + lo (24+ significand bits);
+// a product a*b is the sum of its cross terms.  Keeping the six terms down to 2^-24 relative
+// (hh, hm, mh, mm, hl, lh) on bf16 MFMAs with fp32 accumulation gives a GEMM whose measured error
+// (tools/exp_split_bf16.hip on MI355X: 1.1e-7 of sum|a*b| at K = 864..3456) is BELOW that of the exact
+// fp32 MFMA (1.8e-7), at 6/16 of its matrix-core time; the three-term form (hh, hm, mh: 3/16 of the
+// time) measures 3-6e-7.  NTERMS selects the form; products of bf16 are exact in fp32, so the only
+// rounding is the accumulation, as in any fp32 GEMM.
+//
+// GEMM mapping: M = 32 output channels, N = 32 consecutive output columns of one row (lanes),
+// K-step of 16 = lanes 0-31: 8 input channels of tap 2s, lanes 32-63: the same 8 channels of tap
+// 2s+1 (27 taps -> 14 steps, the 28th half is zero).  The bf16 B operand wants 8 consecutive k per
+// lane, so the LDS halo tile is CHANNEL-INNERMOST: [term][position][8 channels] bf16 = one 16-byte
+// slot per (term, position); a wave's fragment read is 64 consecutive slots (conflict-free
+// ds_read_b128).  The NCDHW fp32 input is transposed/split while it is staged: each thread owns
+// whole positions, loads their 8 channels (coalesced along W per channel, register-prefetched one
+// chunk ahead), splits them and writes three 16-byte slots.  Weights are pre-split and pre-packed in
+// fragment order by ss_pack_conv3d_weights_bf16s and streamed from L2 (every wave of a workgroup
+// reads the same 16 B per lane per term and step; LDS is left to the activations).
+#include <algorithm>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+
+constexpr int KSTEPS = 14;        // ceil(27 taps / 2)
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {       // finite inputs
+    unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_up(unsigned b) { return __uint_as_float(b << 16); }
+
+// x -> (hi, mid, lo) bf16 bit patterns with hi + mid + lo == x up to 2^-25 |x|
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = bf16_rne(x);
+    const float r1 = x - bf16_up(h);
+    m = bf16_rne(r1);
+    const float r2 = r1 - bf16_up(m);
+    l = bf16_rne(r2);
+}
+
+template <int S, int NT, int TD, int TH>
+struct BCfg {
+    static constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
+    static constexpr int CS = ID * IH * IW;                    // positions in the halo tile
+    static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
+    static constexpr int SLOTS = 3 * CS + 1;                   // + one all-zero slot (the 28th half-step)
+    static constexpr size_t LDS_BYTES = (size_t)SLOTS * 16;
+    static_assert(TD * TH == 4 * NT && TH % NT == 0, "4 waves x NT rows tile TD x TH");
+};
+
+template <int S, int NT, int TD, int TH, int NTERMS>
+__global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ residual, float* __restrict__ out,
+                                                        int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
+                                                        int tiles_w, int tiles_h, int relu) {
+    using C = BCfg<S, NT, TD, TH>;
+    constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [3][CS] slots + zero slot
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    int t = blockIdx.x;
+    const int tw = t % tiles_w; t /= tiles_w;
+    const int th = t % tiles_h; t /= tiles_h;
+    const int ow0 = tw * 32, oh0 = th * TH, od0 = t * TD;
+    const int co0 = blockIdx.y * 32;
+    const int b = blockIdx.z;
+    const int iw0 = ow0 * S - 1, ih0 = oh0 * S - 1, id0 = od0 * S - 1;
+    const int dzw = (wave * NT) / TH, hy0 = (wave * NT) % TH;
+    const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + l31 * S;     // slot of this lane's first row, tap (0,0,0)
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const size_t in_plane = (size_t)H * W, chan = (size_t)D * in_plane;
+    const float* inb = in + (size_t)b * Cin * chan;
+
+    // staging plan: this thread owns positions p = tid + 256*i of the halo tile, all 8 channels
+    unsigned poff[C::NPOS], pmask = 0u;
+#pragma unroll
+    for (int i = 0; i < C::NPOS; ++i) {
+        const int p = tid + 256 * i;
+        const int wx = p % C::IW;
+        int r = p / C::IW;
+        const int hy = r % C::IH;
+        const int dz = r / C::IH;
+        const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz;
+        const bool ok = (p < C::CS) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        poff[i] = ok ? (unsigned)(((size_t)gd * in_plane + (size_t)gh * W + gw) * 4) : 0u;
+        pmask |= (unsigned)ok << i;
+    }
+    // input prefetch registers, flattened q = c * NPOS + i, loaded in KSTEPS slices spread over the
+    // K-steps of the previous chunk so that a wait for a weight fragment never drains them all
+    constexpr int NQ = 8 * C::NPOS;
+    constexpr int QS = (NQ + KSTEPS - 1) / KSTEPS;
+    float rin[NQ];
+    int nlive = min(8, Cin), nlive_next = 8;                 // channels that exist in the staged / prefetched chunk
+    if (tid == 0) lds[3 * C::CS] = make_uint4(0u, 0u, 0u, 0u);
+
+    // weight fragments: [global K-step g = blk*14 + s][term][half][Cout][8 bf16] as uint4 slots; lanes of
+    // output channels beyond Cout read a clamped (valid) column and are dropped in the epilogue
+    // Both operands are fetched with buffer loads: wave-uniform base (SGPR descriptor) + uniform
+    // scalar offset + one 32-bit per-lane offset, so no 64-bit per-lane addresses are kept live.
+    const int wlane = (half * Cout + min(co0 + l31, Cout - 1)) * 16;          // byte offset of this lane's column
+    const int wstep = 3 * 2 * Cout * 16;                                      // bytes per K-step
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(wsplit), 0, (int)min((long long)((Cin + 7) / 8) * KSTEPS * wstep, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(inb), 0, (int)min((long long)Cin * (long long)chan * 4, 0x7fffffffLL), 0x00020000);
+    const int chan_b = (int)(chan * 4);                                       // bytes per input channel
+    auto load_a = [&](int g, int c) {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, wlane, g * wstep + c * 2 * Cout * 16, 0));
+    };
+    auto load_in = [&](int ch, int i) {                                       // channel ch (absolute), position slot i
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, 0));
+    };
+    const int G = ((Cin + 7) / 8) * KSTEPS;
+    uint4 aq[3][NC];                                           // aq[s % 3] = fragments of step s of the chunk
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        aq[0][c] = load_a(0, c);
+        aq[1][c] = load_a(1, c);
+    }
+    {   // first chunk: plain load of every slice
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rin[q] = load_in(min(q / C::NPOS, nlive - 1), q % C::NPOS);
+    }
+
+    for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
+        // ---- split + transpose: registers -> [term][position][8 ch] ----
+#pragma unroll
+        for (int i = 0; i < C::NPOS; ++i) {
+            const int p = tid + 256 * i;
+            if (p >= C::CS) continue;
+            unsigned hh[8], mm[8], ll[8];
+            const bool ok = (pmask >> i) & 1u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) split3((ok && c < nlive) ? rin[c * C::NPOS + i] : 0.f, hh[c], mm[c], ll[c]);
+            lds[0 * C::CS + p] = make_uint4(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16));
+            lds[1 * C::CS + p] = make_uint4(mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16));
+            if (NC == 3)
+                lds[2 * C::CS + p] = make_uint4(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16));
+        }
+        __syncthreads();
+        const bool more = ci0 + 8 < Cin;
+        nlive_next = min(8, Cin - ci0 - 8);
+
+        // B fragments are read one (step, row) ahead of their MFMAs
+        uint4 bcur[NC], bnxt[NC];
+        auto read_b = [&](uint4 (&dst)[NC], int s, int i) {
+            const int ta = 2 * s, tb = 2 * s + 1;
+            const int offa = ((ta / 9) * C::IH + (ta / 3) % 3) * C::IW + ta % 3;
+            const int offb = (tb < 27) ? ((tb / 9) * C::IH + (tb / 3) % 3) * C::IW + tb % 3 : 0;
+            const int slot = lane_pos + i * S * C::IW + (half ? offb : offa);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dst[c] = lds[(tb >= 27 && half) ? 3 * C::CS : c * C::CS + slot];
+        };
+        read_b(bcur, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            // weight fragments two steps ahead, then this step's slice of the next chunk's input
+            if (g0 + s + 2 < G) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) aq[(s + 2) % 3][c] = load_a(g0 + s + 2, c);
+            }
+            if (more) {
+#pragma unroll
+                for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q)
+                    rin[q] = load_in(ci0 + 8 + min(q / C::NPOS, nlive_next - 1), q % C::NPOS);
+            }
+            bf16x8 a[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) a[c] = __builtin_bit_cast(bf16x8, aq[s % 3][c]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                if (i + 1 < NT) read_b(bnxt, s, i + 1);
+                else if (s + 1 < KSTEPS) read_b(bnxt, s + 1, 0);
+                bf16x8 bq[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bq[c] = __builtin_bit_cast(bf16x8, bcur[c]);
+                if (NTERMS == 6) {     // smallest cross terms first
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[2], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[0], acc[i], 0, 0, 0);
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bcur[c] = bnxt[c];
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep each step's loads inside the step
+        }
+        // steps 14, 15 of this chunk are steps 0, 1 of the next: re-base the fragment ring
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const uint4 t0 = aq[0][c]; aq[0][c] = aq[KSTEPS % 3][c]; aq[1][c] = t0; }
+        nlive = nlive_next;
+        __syncthreads();
+    }
+
+    // ---- epilogue (identical to conv3d_mfma: the 32x32 D layout does not depend on the input type) ----
+    const int ow = ow0 + l31;
+    const int od = od0 + dzw;
+    if (ow >= Wo || od >= Do) return;
+    const size_t out_plane = (size_t)Ho * Wo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= Cout) continue;
+        const float sc = scale ? scale[co] : 1.0f;
+        const float sh = shift ? shift[co] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int oh = oh0 + hy0 + i;
+            if (oh >= Ho) continue;
+            const size_t o = (((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow;
+            float v = ss::add_rn(ss::mul_rn(acc[i][r], sc), sh);
+            if (residual) v = ss::add_rn(v, residual[o]);
+            if (relu) v = fmaxf(v, 0.f);
+            out[o] = v;
+        }
+    }
+}
+
+// [Cout,Cin,3,3,3] fp32 -> [ceil(Cin/8)][14 steps][3 terms][2 halves][Cout][8] bf16 (zero padded)
+__global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit, int Cout,
+                                          int Cin, long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % 8);
+    long long r = i / 8;
+    const int co = (int)(r % Cout); r /= Cout;
+    const int half = (int)(r % 2); r /= 2;
+    const int term = (int)(r % 3); r /= 3;
+    const int s = (int)(r % KSTEPS);
+    const int blk = (int)(r / KSTEPS);
+    const int tap = 2 * s + half, ci = blk * 8 + j;
+    float x = 0.f;
+    if (tap < 27 && ci < Cin) x = w[((long long)co * Cin + ci) * 27 + tap];
+    unsigned h, m, l;
+    split3(x, h, m, l);
+    wsplit[i] = (unsigned short)(term == 0 ? h : (term == 1 ? m : l));
+}
+
+template <int S, int NT, int TD, int TH, int NTERMS>
+int launch_b(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
+             float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
+    using C = BCfg<S, NT, TD, TH>;
+    const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+    const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
+    const long long nt = (long long)tiles_w * tiles_h * tiles_d;
+    if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
+    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS>;
+    if (C::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)C::LDS_BYTES);
+        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+    }
+    dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32), B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
+                       residual, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
+    return ss::check_launch();
+}
+
+}  // namespace
+
+extern "C" int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                   const float* residual, float* out, int B, int Cin, int D, int H, int W, int Cout,
+                                   int stride, int relu, int nterms, ss_stream_t stream) {
+    SS_REQUIRE(in && wsplit && out);
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0);
+    SS_REQUIRE((stride == 1 || stride == 2) && (nterms == 3 || nterms == 6));
+    SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
+    // operands are addressed through 32-bit buffer offsets: one batch element's input must stay below 2 GiB
+    if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipStream_t st = ss::as_stream(stream);
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    auto blocks = [&](int td, int th) {
+        return (long long)ss::ceil_div(Wo, 32) * ss::ceil_div(Ho, th) * ss::ceil_div(Do, td) * ss::ceil_div(Cout, 32) * B;
+    };
+    const char* forced = getenv("SS_CONV_TILE");
+    int tile = (blocks(2, 8) >= 512) ? 0 : ((blocks(1, 8) >= 512) ? 1 : 2);
+    if (forced && forced[0] >= '0' && forced[0] <= '2') tile = forced[0] - '0';
+#define SS_B(S, NT, TD, TH)                                                                                              \
+    return (nterms == 6) ? launch_b<S, NT, TD, TH, 6>(in, wsplit, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st) \
+                         : launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st)
+    // stride 2 would need a 65-column halo tile per row (> 80 KB of split operands): those layers
+    // (9 % of the FLOPs) stay on the exact-fp32 engine of conv3d.hip.
+    if (stride != 1) return SS_ERR_UNSUPPORTED;
+    if (tile == 0) { SS_B(1, 4, 2, 8); }
+    if (tile == 1) { SS_B(1, 2, 1, 8); }
+    SS_B(1, 1, 1, 4);
+#undef SS_B
+}
+
+extern "C" int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream) {
+    SS_REQUIRE(w && wsplit && Cout > 0 && Cin > 0);
+    const long long total = (long long)ss::ceil_div(Cin, 8) * KSTEPS * 3 * 2 * Cout * 8;
+    hipLaunchKernelGGL(pack_weights_bf16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
+                       ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), Cout, Cin, total);
+    return ss::check_launch();
+}

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gwc_volume_v4(const float* __restrict__ r
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = ss::add_rn(acc[i][j], ss::mul_rn(r[c][j], w[j + 8 - i]));
+                    acc[i][j] = fmaf(r[c][j], w[j + 8 - i], acc[i][j]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

@@ -17,6 +17,8 @@ layers on the GPU -- the HIP stack is an inference path; PATH_COUNTS records whi
 `X.adopt(ref_module)` wraps an instance built by the REFERENCE's own classes, sharing its
 parameters (this is what `semstereo_amd.install.accelerate` uses).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -122,6 +124,36 @@ def deconv3d_hip(x, wpack, shift, relu, skip=None, skip_wpack=None):
     return out
 
 
+#: matrix-core engine of the 3x3x3 stride-1 convolutions: "f32" = exact-fp32 MFMA (conv3d.hip);
+#: "bf16x6" / "bf16x3" = split-bf16 (conv3d_bf16s.hip, fp32 operands as 3 bf16 terms, 6 or 3 cross
+#: products).  Everything else (stride 2, 1x1x1, transposed, Cout = 1) always runs the fp32 engine.
+CONV_ENGINE = os.environ.get("SS_CONV_ENGINE", "f32")
+
+
+def pack_conv_weight_bf16s(w):
+    """[Cout,Cin,3,3,3] fp32 -> split-bf16 fragments for ss_conv3d_bf16s_fwd (int16 tensor, 16-B aligned)."""
+    w = w.detach().float().contiguous()
+    _lib.require_device(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3, 3)
+    out = torch.empty(((Cin + 7) // 8) * 14 * 3 * 2 * Cout * 8, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        call("ss_pack_conv3d_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
+    return out
+
+
+def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None):
+    """3x3x3 stride-1 Conv3d + affine + optional residual / ReLU on the split-bf16 engine."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, scale, shift, residual)
+    B, Cin, D, H, W = x.shape
+    out = torch.empty((B, Cout, D, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(dev):
+        call("ss_conv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(out),
+             B, Cin, D, H, W, Cout, 1, int(relu), int(nterms))
+    return out
+
+
 def _convbn_params(owner, key, conv, bn):
     """(wpack, scale, shift) of a Conv3d(+BN) pair, cached on `owner`."""
     srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
@@ -145,6 +177,15 @@ def _conv_geometry(conv):
 def run_convbn(owner, key, conv, bn, x, relu, residual=None):
     """Fused Conv3d -> BN(eval) [-> +residual] [-> ReLU] through ss_conv3d_fwd."""
     k, s = _conv_geometry(conv)
+    if CONV_ENGINE != "f32" and k == 3 and s == 1 and conv.out_channels > 1:
+        nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+        srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+        def build():
+            sc, sh = fold_bn(bn) if bn is not None else (None, None)
+            return pack_conv_weight_bf16s(conv.weight), sc, sh
+        ws, scale, shift = _cache(owner).get(key + "/bf16s", srcs, build)
+        return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual)
     wp, scale, shift = _convbn_params(owner, key, conv, bn)
     return conv3d_hip(x, wp, scale, shift, k, s, relu, residual)
 
@@ -310,9 +351,9 @@ class hourglass(nn.Module):
     def adopt(cls, ref):
         self = cls.__new__(cls)
         nn.Module.__init__(self)
-        for name in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "redir1", "redir2"):
-            setattr(self, name, getattr(ref, name))
-        self.attention_block = attention_block.adopt(ref.attention_block)
+        for name, child in ref.named_children():       # registration order = state_dict key order
+            setattr(self, name, attention_block.adopt(child) if name == "attention_block" else child)
+        self.BLOCK = tuple(self.attention_block.block)
         self.train(ref.training)
         return self
 

@@ -316,6 +316,68 @@ def test_conv3d_kernel(sa, case):
     check(f"conv3d/{case}", y, ref, 2e-4)
 
 
+BF16S_CASES = [
+    # (Cin, Cout, D, H, W, relu, residual)
+    (32, 32, 5, 9, 37, True, False),
+    (64, 32, 3, 17, 66, True, False),
+    (64, 64, 3, 8, 33, True, True),
+    (128, 128, 2, 5, 8, False, False),
+    (6, 40, 3, 4, 9, False, False),          # ragged channel block, Cout not a multiple of 32
+    (20, 8, 2, 3, 70, True, False),
+]
+
+
+@pytest.mark.parametrize("nterms", [6, 3])
+@pytest.mark.parametrize("case", BF16S_CASES)
+def test_conv3d_split_bf16_engine(sa, case, nterms):
+    """fp32 conv emulated with 3-term bf16 operands on the bf16 matrix core: the 6-product form must
+    be as close to the fp32 reference as the exact-fp32 MFMA kernel is, the 3-product form within 4x."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin, Cout, D, H, W, relu, use_res = case
+    x = dd.t_normalish((2, Cin, D, H, W), 181)
+    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 182, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    scale, shift = dd.t_uniform((Cout,), 183, 0.5, 1.5), dd.t_uniform((Cout,), 184, -0.2, 0.2)
+    ref = F.conv3d(x.double(), w.double(), None, 1, 1) * scale.double().reshape(1, -1, 1, 1, 1) + shift.double().reshape(1, -1, 1, 1, 1)
+    res = dd.t_normalish(tuple(ref.shape), 185) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    ws = sa.modules.pack_conv_weight_bf16s(dev(w))
+    y = sa.modules.conv3d_bf16s_hip(dev(x), ws, Cout, dev(scale), dev(shift), relu, nterms, None if res is None else dev(res))
+    wp = sa.modules.pack_conv_weight(dev(w))
+    y32 = sa.modules.conv3d_hip(dev(x), wp, dev(scale), dev(shift), 3, 1, relu, None if res is None else dev(res))
+    e_split = float((y.double().cpu() - ref).abs().max())
+    e_f32 = float((y32.double().cpu() - ref).abs().max())
+    REPORT[f"conv3d_bf16x{nterms}/{case}"] = e_split
+    REPORT[f"conv3d_f32mfma_vs_f64/{case}"] = e_f32
+    if nterms == 6:
+        assert e_split <= 1.5 * e_f32 + 1e-7, (e_split, e_f32)
+    else:       # 3 products drop terms of 2^-16 relative size: ~1e-5 absolute on O(1) outputs at small K
+        assert e_split <= 4e-5, (e_split, e_f32)
+
+
+@pytest.mark.parametrize("engine", ["bf16x6", "bf16x3"])
+def test_hot_segment_on_split_bf16_engine(sa, golden, engine):
+    name = "s128"
+    old = sa.modules.CONV_ENGINE
+    sa.modules.CONV_ENGINE = engine
+    try:
+        seg, P = _segment(sa, cases.SEGMENT[name][3])
+        fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
+        with torch.no_grad():
+            r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
+    finally:
+        sa.modules.CONV_ENGINE = old
+    g = golden["segment"]
+    same = (r["samples"].cpu().numpy().astype(np.int16) == g[f"{name}/samples"]).mean()
+    REPORT[f"segment_{engine}/samples_equal_fraction"] = float(same)
+    assert same == 1.0
+    check(f"segment_{engine}/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
+    check(f"segment_{engine}/pred", r["pred"], g[f"{name}/pred"], 1e-3)
+
+
 @pytest.mark.parametrize("case", [(128, 64, 2, 3, 5, 64), (64, 32, 3, 9, 33, 32), (32, 32, 2, 4, 40, 0), (8, 24, 2, 3, 6, 6)])
 def test_deconv3d_kernel(sa, case):
     import torch.nn.functional as F
@@ -371,3 +433,24 @@ def test_hot_segment_vs_reference_fixture(sa, golden, name):
     check(f"segment/{name}/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
     check(f"segment/{name}/pred", r["pred"], g[f"{name}/pred"], 1e-3)
     REPORT[f"segment/{name}/epe_vs_ref"] = oops.epe(r["pred"].cpu(), torch.as_tensor(g[f"{name}/pred"]))
+
+
+def test_reference_shaped_composition_on_gpu(sa, golden):
+    """The line-by-line composition the reference's forward() performs (reference-named ops:
+    build_gwc_volume_norm, disparity_regression, disparity_variance, SpatialTransformer_grid,
+    regression_topk + module calls), which HotSegment takes when autograd is on, reaches the same
+    disparities as the fixture and back-propagates through the HIP autograd.Functions."""
+    name = "s128"
+    seg, P = _segment(sa, cases.SEGMENT[name][3])
+    fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
+    ins = [dev(t).requires_grad_(True) for t in (fl4, fr4, fl8, fr8)]
+    before = dict(sa.modules.PATH_COUNTS)
+    r = seg(*ins)                                   # eval(), autograd on -> unfused reference-shaped path
+    assert sa.modules.PATH_COUNTS["torch"] > before["torch"]
+    g = golden["segment"]
+    same = (r["samples"].detach().cpu().numpy().astype(np.int16) == g[f"{name}/samples"]).mean()
+    assert same == 1.0
+    check("segment_unfused/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
+    check("segment_unfused/pred", r["pred"], g[f"{name}/pred"], 1e-3)
+    (r["pred"].sum() + r["pred_att"].sum()).backward()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in ins)

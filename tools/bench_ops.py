@@ -41,8 +41,11 @@ def main():
     ap.add_argument("--only", default="all")
     ap.add_argument("--json", default=None)
     ap.add_argument("--sweep", action="store_true", help="time every conv tile candidate (SS_CONV_TILE)")
+    ap.add_argument("--engine", default=None, help="f32 | bf16x6 | bf16x3 for the 3x3x3 stride-1 convs")
     args = ap.parse_args()
     B, S, md = args.batch, args.size, args.maxdisp
+    if args.engine:
+        M.CONV_ENGINE = args.engine
     dev = torch.device("cuda")
     rows = []
 
@@ -59,6 +62,12 @@ def main():
                 ms = timeit(lambda: M.conv3d_hip(x, wp, sc, sh, k, stride, True), args.iters)
                 rows.append(dict(name=f"{name} [tile {tile}]", ms=ms, gflop=gf, tflops=gf / ms, frac=gf / ms / PEAK_TF))
             os.environ.pop("SS_CONV_TILE", None)
+            return
+        if M.CONV_ENGINE != "f32" and k == 3 and stride == 1 and cout > 1:
+            ws = M.pack_conv_weight_bf16s(wt)
+            nterms = 6 if M.CONV_ENGINE == "bf16x6" else 3
+            ms = timeit(lambda: M.conv3d_bf16s_hip(x, ws, cout, sc, sh, True, nterms), args.iters)
+            rows.append(dict(name=f"{name} [{M.CONV_ENGINE}]", ms=ms, gflop=gf, tflops=gf / ms, frac=gf / ms / PEAK_TF))
             return
         ms = timeit(lambda: M.conv3d_hip(x, wp, sc, sh, k, stride, True), args.iters)
         rows.append(dict(name=name, ms=ms, gflop=gf, tflops=gf / ms, frac=gf / ms / PEAK_TF))
