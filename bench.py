@@ -28,7 +28,8 @@ import semstereo_amd  # noqa: E402
 from semstereo_amd import dist as sdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (spec)
 
 
 def synth_features(B, C, H, W, max_shift, seed, device):
@@ -110,6 +111,9 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--maxdisp", type=int, default=128)
+    ap.add_argument("--engine", default=None, help="conv engine of the timed run: f32 | bf16x6 | bf16x3 "
+                                                   "(default: semstereo_amd.modules.CONV_ENGINE)")
+    ap.add_argument("--no-other-engines", action="store_true", help="skip the extra timings of the other engines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the oracle run")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -121,6 +125,10 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     semstereo_amd._lib.load()
+    M = semstereo_amd.modules
+    if args.engine:
+        M.CONV_ENGINE = args.engine
+    engine = M.CONV_ENGINE
 
     H, W, maxdisp, B = args.height, args.width, args.maxdisp, args.batch
     seg = semstereo_amd.HotSegment(maxdisp).to(device).eval()
@@ -139,29 +147,48 @@ def main():
         with torch.no_grad():
             return seg(*feats)
 
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    timer.enabled = True
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    assert semstereo_amd.modules.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside the timed region"
+    def timed_run(nsteps, nwarm):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        for _ in range(nwarm):
+            o = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            o = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        pairs, _, _, tmax = sdist.reduce_metrics(B * nsteps, 0.0, 0, dt, device)
+        return o, pairs, tmax
 
-    pairs, _, _, tmax = sdist.reduce_metrics(B * args.steps, 0.0, 0, elapsed, device)
+    timer.enabled = True
+    out, pairs, tmax = timed_run(args.steps, args.warmup)
+    timer.enabled = False
+    assert M.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside the timed region"
+
+    by_engine, outs = {engine: pairs / tmax}, {engine: out}
+    if not args.no_other_engines:
+        for e in ("f32", "bf16x6", "bf16x3"):
+            if e != engine:
+                M.CONV_ENGINE = e
+                o, p_, t_ = timed_run(max(3, args.steps // 2), 2)
+                by_engine[e], outs[e] = p_ / t_, o
+        M.CONV_ENGINE = engine
 
     if rank != 0:
         return
-    D8, D4, k = 2 * (maxdisp // 8), 2 * (maxdisp // 4), 24
+    D8, k = 2 * (maxdisp // 8), 24
     H8, W8, H4, W4 = H // 8, W // 8, H // 4, W // 4
+    engine_note = {
+        "f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for every 3-D layer",
+        "bf16x6": "3x3x3 stride-1 convs: fp32 operands split into 3 bf16 terms, 6 cross products on v_mfma_f32_32x32x16_bf16, "
+                  "fp32 accumulate (measured error vs fp64 below the exact-fp32 MFMA's); other layers exact-fp32 MFMA",
+        "bf16x3": "as bf16x6 with 3 cross products (hi*hi + hi*mid + mid*hi)",
+    }[engine]
     res = {
         "metric": "stereo pairs/sec, hot segment (gwc+concat volumes, 3-D hourglass stack, soft-argmax), "
                   f"{H}x{W} maxdisp={maxdisp}",
@@ -171,16 +198,29 @@ def main():
         "config": {"workload": f"BASELINE.json configs[1]: {H}x{W} tile, maxdisp={maxdisp}, batch={B} per GPU, "
                                "features [B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity [B,1,H/4,W/4]",
                    "pairs_per_gpu_per_step": B, "parallelism": f"pairs sharded over {world} rank(s), no collective in the forward",
-                   "weights": "random init at unit gain (see init_unit_gain), BatchNorm eval"},
+                   "weights": "random init at unit gain (see init_unit_gain), BatchNorm eval",
+                   "conv_engine": engine, "conv_engine_note": engine_note},
+        "pairs_per_s_by_conv_engine": by_engine,
     }
     ms = timer.mean_ms("concat_stem")
     if ms:
         flops = 2.0 * 32 * 64 * 27 * k * H4 * W4 * B          # concat_stem: Conv3d 64->32 k3 on [B,64,24,H4,W4]
-        ach = flops / (ms * 1e-3) / 1e12
-        res["roofline"] = {"kernel": "conv3d_mfma<3,1,1,4,2,8,8> (concat_stem, 64->32 k3 on [B,64,24,H/4,W/4])",
-                           "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
-                           "algorithmic_flop_per_launch": flops}
+        eq = flops / (ms * 1e-3) / 1e12                        # fp32-equivalent (algorithmic) rate
+        if engine == "f32":
+            res["roofline"] = {"kernel": "conv3d_mfma<3,1,1,4,2,8,4> (concat_stem, 64->32 k3 on [B,64,24,H/4,W/4])",
+                               "bound": "mfma", "achieved": eq, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": eq / MFMA_F32_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
+                               "algorithmic_flop_per_launch": flops}
+        else:
+            nterms = 6 if engine == "bf16x6" else 3
+            ex = nterms * eq                                   # bf16 MFMA flops actually issued per second
+            res["roofline"] = {"kernel": f"conv3d_bf16s<1,4,2,8,{nterms}> (concat_stem, 64->32 k3 on [B,64,24,H/4,W/4])",
+                               "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ex / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
+                               "algorithmic_flop_per_launch": nterms * flops,
+                               "note": f"{nterms} bf16 products per fp32 product; fp32-equivalent rate {eq:.1f} TFLOP/s = "
+                                       f"{eq / MFMA_F32_PEAK_TFLOPS:.2f} x the {MFMA_F32_PEAK_TFLOPS} TFLOP/s fp32-MFMA peak",
+                               "fp32_equivalent_tflops": eq}
     ms = timer.mean_ms("gwc")
     if ms:
         nbytes = 4.0 * (2 * 256 * H8 * W8 + 32 * D8 * H8 * W8) * B
@@ -188,10 +228,12 @@ def main():
         res["roofline_cost_volume"] = {"kernel": "gwc_volume_v4<8,true> (build_gwc_volume_norm, live shape)",
                                        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms,
-                                       "algorithmic_bytes_per_launch": nbytes}
+                                       "algorithmic_bytes_per_launch": nbytes,
+                                       "note": "HIP-event time at this batch includes ~4 us of event overhead; the rocprof "
+                                               "kernel-trace average and the PMC traffic at B=8 are in profiles/"}
     if not args.no_cpu_baseline:
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the
-        # same workload: about 20-30 s of CPU work.  ATen's CPU kernels stop scaling (the slice
+        # same workload: about 10-30 s of CPU work.  ATen's CPU kernels stop scaling (the slice
         # loop of build_gwc_volume_norm anti-scales) beyond a few dozen threads, so cap them.
         from oracle import hot_segment as oseg
         from oracle import ops as oops
@@ -206,15 +248,20 @@ def main():
                                "sample": f"1 pair {H}x{W} maxdisp={maxdisp} through oracle.hot_segment "
                                          f"(PyTorch CPU fp32 restatement of the reference), {cdt:.1f} s, "
                                          f"{nthreads} of {os.cpu_count()} host threads"}
-        pred, rpred = out["pred"][:1].cpu(), ref["pred"]
-        same_px = (out["samples"][:1].cpu() == ref["samples"]).all(dim=1, keepdim=True)     # [1,1,H4,W4]
-        res["epe_vs_oracle_px"] = oops.epe(pred, rpred)
-        res["epe_vs_oracle_fullres_px"] = 4.0 * res["epe_vs_oracle_px"]      # disp = 4 * upsample(pred), SemStereo.py:346
-        res["pred_att_epe_vs_oracle_px"] = oops.epe(out["pred_att"][:1].cpu(), ref["pred_att"])
-        res["pixels_with_identical_top24_candidates"] = same_px.float().mean().item()
-        res["epe_vs_oracle_px_where_candidates_identical"] = (
-            (pred - rpred).abs()[same_px].double().mean().item() if same_px.any() else None)
-        res["pred_max_abs_err_px"] = (pred - rpred).abs().max().item()
+
+        def parity(o):
+            pred, rpred = o["pred"][:1].cpu(), ref["pred"]
+            err = (pred - rpred).abs()
+            same_px = (o["samples"][:1].cpu() == ref["samples"]).all(dim=1, keepdim=True)
+            return {"epe_px": oops.epe(pred, rpred), "epe_fullres_px": 4.0 * oops.epe(pred, rpred),
+                    "pred_att_epe_px": oops.epe(o["pred_att"][:1].cpu(), ref["pred_att"]),
+                    "median_abs_err_px": err.median().item(), "max_abs_err_px": err.max().item(),
+                    "pixels_abs_err_gt_1e-3": (err > 1e-3).float().mean().item(),
+                    "pixels_with_identical_top24_candidates": same_px.float().mean().item()}
+        par = parity(out)
+        res["epe_vs_oracle_px"] = par["epe_px"]
+        res["parity_vs_oracle"] = par
+        res["parity_vs_oracle_by_conv_engine"] = {e: parity(o) for e, o in outs.items() if e != engine}
     print(json.dumps(res))
 
 

@@ -140,11 +140,13 @@ int ss_channel_gate_fwd(const float* att_logits, const float* cv, float* out,
  *   wpack   weights re-laid out as [Cin][kd*kh*kw][Cout] (see ss_pack_conv3d_weights)
  *   scale, shift   per-Cout affine applied to the accumulator (folded BN; NULL = 1 / 0)
  *   residual       [B,Cout,Do,Ho,Wo] added after the affine (NULL = none)
- *   relu           != 0 -> max(.,0) last
+ *   relu           != 0 -> max(.,0)
+ *   gate           [B,Cout,Ho,Wo] channelAtt logits (models/SemStereo.py:101-102): the result is multiplied
+ *                  by sigmoid(gate) broadcast over D, last (NULL = none)
  *   kernel k in {1,3} (cubic), stride in {1,2}, pad = k/2.  out [B,Cout,Do,Ho,Wo],
  *   Do = (D + 2*pad - k)/stride + 1 ... */
 int ss_conv3d_fwd(const float* in, const float* wpack, const float* scale, const float* shift,
-                  const float* residual, float* out,
+                  const float* residual, const float* gate, float* out,
                   int B, int Cin, int D, int H, int W, int Cout, int k, int stride, int relu,
                   ss_stream_t stream);
 /* Same contract as ss_conv3d_fwd for k = 3, stride 1, computed on the bf16 matrix core with every fp32
@@ -153,7 +155,7 @@ int ss_conv3d_fwd(const float* in, const float* wpack, const float* scale, const
  * hi*hi + hi*mid + mid*hi.  wsplit comes from ss_pack_conv3d_weights_bf16s (16-byte aligned).
  * stride 2 returns SS_ERR_UNSUPPORTED (use ss_conv3d_fwd). */
 int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
-                        const float* residual, float* out,
+                        const float* residual, const float* gate, float* out,
                         int B, int Cin, int D, int H, int W, int Cout, int stride, int relu, int nterms,
                         ss_stream_t stream);
 /* Conv3d weight [Cout,Cin,3,3,3] fp32 -> split/packed bf16 fragments

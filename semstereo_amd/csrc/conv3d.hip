@@ -46,7 +46,8 @@ struct Cfg {
 template <int KS, int S, int MT, int NT, int TD, int TH, int CIT>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma(const float* __restrict__ in, const float* __restrict__ wpack,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    const float* __restrict__ residual, float* __restrict__ out,
+                                                    const float* __restrict__ residual, const float* __restrict__ gate,
+                                                    float* __restrict__ out,
                                                     int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
                                                     int tiles_w, int tiles_h, int relu) {
     using C = Cfg<KS, S, MT, NT, TD, TH, CIT>;
@@ -209,6 +210,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(const float* __restrict__ 
                 v = ss::add_rn(ss::mul_rn(v, sc), sh);
                 if (residual) v = ss::add_rn(v, residual[o]);
                 if (relu) v = fmaxf(v, 0.f);
+                if (gate) {      // channelAtt: sigmoid(gate[b,co,h,w]) broadcast over D
+                    const float gl = gate[(((size_t)b * Cout + co) * Ho + oh) * Wo + ow];
+                    v = ss::mul_rn(1.0f / (1.0f + expf(-gl)), v);
+                }
                 out[o] = v;
             }
         }
@@ -403,7 +408,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 template <int KS, int S, int MT, int NT, int TD, int TH, int CIT>
 int launch_conv(const float* in, const float* wpack, const float* scale, const float* shift, const float* residual,
-                float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
+                const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
     using C = Cfg<KS, S, MT, NT, TD, TH, CIT>;
     const int Do = (D + 2 * C::PAD - KS) / S + 1, Ho = (H + 2 * C::PAD - KS) / S + 1, Wo = (W + 2 * C::PAD - KS) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
@@ -416,7 +421,7 @@ int launch_conv(const float* in, const float* wpack, const float* scale, const f
         if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
     }
     dim3 grid((unsigned)nt, ss::ceil_div(Cout, C::CO_T), B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, wpack, scale, shift, residual, out, Cin, D, H, W,
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, wpack, scale, shift, residual, gate, out, Cin, D, H, W,
                        Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
     return ss::check_launch();
 }
@@ -424,13 +429,14 @@ int launch_conv(const float* in, const float* wpack, const float* scale, const f
 }  // namespace
 
 extern "C" int ss_conv3d_fwd(const float* in, const float* wpack, const float* scale, const float* shift,
-                             const float* residual, float* out, int B, int Cin, int D, int H, int W, int Cout, int k,
+                             const float* residual, const float* gate, float* out, int B, int Cin, int D, int H, int W,
+                             int Cout, int k,
                              int stride, int relu, ss_stream_t stream) {
     SS_REQUIRE(in && wpack && out);
     SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0);
     SS_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2));
     hipStream_t st = ss::as_stream(stream);
-    if (Cout == 1 && k == 3 && stride == 1 && residual == nullptr) {
+    if (Cout == 1 && k == 3 && stride == 1 && residual == nullptr && gate == nullptr) {
         constexpr int TD = 4, TH = 8;
         const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, TH), tiles_d = ss::ceil_div(D, TD);
         const long long nt = (long long)tiles_w * tiles_h * tiles_d;
@@ -466,7 +472,7 @@ extern "C" int ss_conv3d_fwd(const float* in, const float* wpack, const float* s
         return best;
     };
 #define SS_CONV(KS, S, MT, NT, TD, TH, CIT) \
-    return launch_conv<KS, S, MT, NT, TD, TH, CIT>(in, wpack, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st)
+    return launch_conv<KS, S, MT, NT, TD, TH, CIT>(in, wpack, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st)
     if (k == 3 && stride == 1) {
         static const Cand c[] = {{1, 4, 2, 8}, {2, 2, 1, 8}, {2, 1, 1, 4}, {1, 2, 1, 8}, {1, 1, 1, 4}};
         switch (pick(c, 5)) {

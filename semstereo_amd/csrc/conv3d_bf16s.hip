@@ -59,7 +59,8 @@ struct BCfg {
 template <int S, int NT, int TD, int TH, int NTERMS>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        const float* __restrict__ residual, float* __restrict__ out,
+                                                        const float* __restrict__ residual, const float* __restrict__ gate,
+                                                        float* __restrict__ out,
                                                         int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
                                                         int tiles_w, int tiles_h, int relu) {
     using C = BCfg<S, NT, TD, TH>;
@@ -229,6 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
             float v = ss::add_rn(ss::mul_rn(acc[i][r], sc), sh);
             if (residual) v = ss::add_rn(v, residual[o]);
             if (relu) v = fmaxf(v, 0.f);
+            if (gate) {      // channelAtt: sigmoid(gate[b,co,h,w]) broadcast over D
+                const float gl = gate[(((size_t)b * Cout + co) * Ho + oh) * Wo + ow];
+                v = ss::mul_rn(1.0f / (1.0f + expf(-gl)), v);
+            }
             out[o] = v;
         }
     }
@@ -256,7 +261,7 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned 
 
 template <int S, int NT, int TD, int TH, int NTERMS>
 int launch_b(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
-             float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
+             const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
     using C = BCfg<S, NT, TD, TH>;
     const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
@@ -270,15 +275,15 @@ int launch_b(const float* in, const void* wsplit, const float* scale, const floa
     }
     dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32), B);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
-                       residual, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
+                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
     return ss::check_launch();
 }
 
 }  // namespace
 
 extern "C" int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
-                                   const float* residual, float* out, int B, int Cin, int D, int H, int W, int Cout,
-                                   int stride, int relu, int nterms, ss_stream_t stream) {
+                                   const float* residual, const float* gate, float* out, int B, int Cin, int D, int H,
+                                   int W, int Cout, int stride, int relu, int nterms, ss_stream_t stream) {
     SS_REQUIRE(in && wsplit && out);
     SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0);
     SS_REQUIRE((stride == 1 || stride == 2) && (nterms == 3 || nterms == 6));
@@ -294,8 +299,8 @@ extern "C" int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const fl
     int tile = (blocks(2, 8) >= 512) ? 0 : ((blocks(1, 8) >= 512) ? 1 : 2);
     if (forced && forced[0] >= '0' && forced[0] <= '2') tile = forced[0] - '0';
 #define SS_B(S, NT, TD, TH)                                                                                              \
-    return (nterms == 6) ? launch_b<S, NT, TD, TH, 6>(in, wsplit, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st) \
-                         : launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, out, B, Cin, D, H, W, Cout, relu, st)
+    return (nterms == 6) ? launch_b<S, NT, TD, TH, 6>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st) \
+                         : launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st)
     // stride 2 would need a 65-column halo tile per row (> 80 KB of split operands): those layers
     // (9 % of the FLOPs) stay on the exact-fp32 engine of conv3d.hip.
     if (stride != 1) return SS_ERR_UNSUPPORTED;

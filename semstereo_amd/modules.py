@@ -87,10 +87,11 @@ def pack_conv_weight(w, transposed=False):
     return out
 
 
-def conv3d_hip(x, wpack, scale, shift, k, stride, relu, residual=None):
-    """Conv3d(bias=False, pad=k//2) + per-channel affine + optional residual + optional ReLU."""
+def conv3d_hip(x, wpack, scale, shift, k, stride, relu, residual=None, gate=None):
+    """Conv3d(bias=False, pad=k//2) + per-channel affine + optional residual + optional ReLU + optional
+    channelAtt gate (sigmoid(gate[b,co,h,w]) broadcast over D)."""
     x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, wpack, scale, shift, residual)
+    dev = _lib.require_device(x, wpack, scale, shift, residual, gate)
     B, Cin, D, H, W = x.shape
     assert wpack.shape[0] == Cin and wpack.shape[1] == k ** 3
     Cout = wpack.shape[2]
@@ -99,8 +100,10 @@ def conv3d_hip(x, wpack, scale, shift, k, stride, relu, residual=None):
     out = torch.empty((B, Cout, Do, Ho, Wo), dtype=x.dtype, device=x.device)
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
+    if gate is not None:
+        assert gate.shape == (B, Cout, Ho, Wo) and gate.is_contiguous()
     with torch.cuda.device(dev):
-        call("ss_conv3d_fwd", ptr(x), ptr(wpack), ptr(scale), ptr(shift), ptr(residual), ptr(out),
+        call("ss_conv3d_fwd", ptr(x), ptr(wpack), ptr(scale), ptr(shift), ptr(residual), ptr(gate), ptr(out),
              B, Cin, D, H, W, Cout, k, stride, int(relu))
     return out
 
@@ -127,7 +130,9 @@ def deconv3d_hip(x, wpack, shift, relu, skip=None, skip_wpack=None):
 #: matrix-core engine of the 3x3x3 stride-1 convolutions: "f32" = exact-fp32 MFMA (conv3d.hip);
 #: "bf16x6" / "bf16x3" = split-bf16 (conv3d_bf16s.hip, fp32 operands as 3 bf16 terms, 6 or 3 cross
 #: products).  Everything else (stride 2, 1x1x1, transposed, Cout = 1) always runs the fp32 engine.
-CONV_ENGINE = os.environ.get("SS_CONV_ENGINE", "f32")
+#: Default bf16x6: its measured error against fp64 is BELOW the exact-fp32 MFMA's (1.1e-7 vs 1.8e-7 of
+#: sum|a*b|, tools/exp_split_bf16.hip) at ~1.5x its speed; SS_CONV_ENGINE=f32 selects the exact engine.
+CONV_ENGINE = os.environ.get("SS_CONV_ENGINE", "bf16x6")
 
 
 def pack_conv_weight_bf16s(w):
@@ -142,14 +147,16 @@ def pack_conv_weight_bf16s(w):
     return out
 
 
-def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None):
+def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None, gate=None):
     """3x3x3 stride-1 Conv3d + affine + optional residual / ReLU on the split-bf16 engine."""
     x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, scale, shift, residual)
+    dev = _lib.require_device(x, scale, shift, residual, gate)
     B, Cin, D, H, W = x.shape
     out = torch.empty((B, Cout, D, H, W), dtype=x.dtype, device=x.device)
+    if gate is not None:
+        assert gate.shape == (B, Cout, H, W) and gate.is_contiguous()
     with torch.cuda.device(dev):
-        call("ss_conv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(out),
+        call("ss_conv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(gate), ptr(out),
              B, Cin, D, H, W, Cout, 1, int(relu), int(nterms))
     return out
 
@@ -174,8 +181,8 @@ def _conv_geometry(conv):
     return k[0], s[0]
 
 
-def run_convbn(owner, key, conv, bn, x, relu, residual=None):
-    """Fused Conv3d -> BN(eval) [-> +residual] [-> ReLU] through ss_conv3d_fwd."""
+def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
+    """Fused Conv3d -> BN(eval) [-> +residual] [-> ReLU] [-> * sigmoid(gate)] on the selected engine."""
     k, s = _conv_geometry(conv)
     if CONV_ENGINE != "f32" and k == 3 and s == 1 and conv.out_channels > 1:
         nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
@@ -185,9 +192,9 @@ def run_convbn(owner, key, conv, bn, x, relu, residual=None):
             sc, sh = fold_bn(bn) if bn is not None else (None, None)
             return pack_conv_weight_bf16s(conv.weight), sc, sh
         ws, scale, shift = _cache(owner).get(key + "/bf16s", srcs, build)
-        return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual)
+        return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual, gate)
     wp, scale, shift = _convbn_params(owner, key, conv, bn)
-    return conv3d_hip(x, wp, scale, shift, k, s, relu, residual)
+    return conv3d_hip(x, wp, scale, shift, k, s, relu, residual, gate)
 
 
 # --------------------------------------------------------------------------------------
@@ -242,10 +249,13 @@ class BasicConv(nn.Module):
         self.train(ref.training)
         return self
 
-    def forward(self, x):
-        if self.is_3d and not self.deconv and _inference(self, x):
+    def forward(self, x, gate_logits=None):
+        """gate_logits [B,Cout,H,W] (3-D form only): fuses the channelAtt gate that follows `concat_stem`
+        in the model (models/SemStereo.py:319-320) into the conv epilogue."""
+        if self.is_3d and not self.deconv and _inference(self, x, gate_logits):
             PATH_COUNTS["hip"] += 1
-            return run_convbn(self, "bc", self.conv, self.bn if self.use_bn else None, x, relu=bool(self.relu))
+            g = None if gate_logits is None else gate_logits.contiguous()
+            return run_convbn(self, "bc", self.conv, self.bn if self.use_bn else None, x, relu=bool(self.relu), gate=g)
         if self.is_3d:
             PATH_COUNTS["torch"] += 1
         x = self.conv(x)
@@ -253,6 +263,8 @@ class BasicConv(nn.Module):
             x = self.bn(x)
         if self.relu:
             x = F.relu(x)
+        if gate_logits is not None:
+            x = torch.sigmoid(gate_logits).unsqueeze(2) * x
         return x
 
 

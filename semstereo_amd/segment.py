@@ -118,8 +118,11 @@ class HotSegment(nn.Module):
         else:
             right_w, left_b = ops.SpatialTransformer_grid(cl, cr, samples)
             volume = att_topk * torch.cat((left_b, right_w), dim=1)
-        volume = self.concat_stem(volume)                                                      # :319
-        volume = self.concat_feature_att_4(volume, fl4)                                        # :320
+        if fast:
+            volume = self.concat_stem(volume, self.concat_feature_att_4.logits(fl4))           # :319 + :320 fused
+        else:
+            volume = self.concat_stem(volume)                                                  # :319
+            volume = self.concat_feature_att_4(volume, fl4)                                    # :320
         cost = self.classif(self.hourglass(volume))                                            # :321-322
         return ops.regression_topk(cost.squeeze(1), samples, 2)                                # :323
 

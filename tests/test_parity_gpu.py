@@ -316,6 +316,28 @@ def test_conv3d_kernel(sa, case):
     check(f"conv3d/{case}", y, ref, 2e-4)
 
 
+@pytest.mark.parametrize("engine", ["f32", "bf16x6"])
+def test_conv3d_fused_channel_gate(sa, engine):
+    """concat_stem + concat_feature_att_4 (models/SemStereo.py:319-320) as ONE kernel:
+    sigmoid(gate)[:, :, None] * relu(bn(conv(x)))."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin, Cout, D, H, W = 64, 32, 3, 9, 37
+    x = dd.t_normalish((2, Cin, D, H, W), 191)
+    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 192, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    scale, shift = dd.t_uniform((Cout,), 193, 0.5, 1.5), dd.t_uniform((Cout,), 194, -0.2, 0.2)
+    gate = dd.t_normalish((2, Cout, H, W), 195)
+    ref = F.relu(F.conv3d(x, w, None, 1, 1) * scale.reshape(1, -1, 1, 1, 1) + shift.reshape(1, -1, 1, 1, 1))
+    ref = torch.sigmoid(gate).unsqueeze(2) * ref
+    if engine == "f32":
+        y = sa.modules.conv3d_hip(dev(x), sa.modules.pack_conv_weight(dev(w)), dev(scale), dev(shift), 3, 1, True,
+                                  None, dev(gate))
+    else:
+        y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w)), Cout, dev(scale), dev(shift),
+                                        True, 6, None, dev(gate))
+    check(f"conv3d_gate/{engine}", y, ref, 2e-5)
+
+
 BF16S_CASES = [
     # (Cin, Cout, D, H, W, relu, residual)
     (32, 32, 5, 9, 37, True, False),
@@ -358,8 +380,8 @@ def test_conv3d_split_bf16_engine(sa, case, nterms):
         assert e_split <= 4e-5, (e_split, e_f32)
 
 
-@pytest.mark.parametrize("engine", ["bf16x6", "bf16x3"])
-def test_hot_segment_on_split_bf16_engine(sa, golden, engine):
+@pytest.mark.parametrize("engine", ["f32", "bf16x6", "bf16x3"])
+def test_hot_segment_on_each_conv_engine(sa, golden, engine):
     name = "s128"
     old = sa.modules.CONV_ENGINE
     sa.modules.CONV_ENGINE = engine
