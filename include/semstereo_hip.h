@@ -128,6 +128,16 @@ int ss_topk_candidates_fwd(const float* logits, const float* strength, float* sa
 int ss_regression_topk_fwd(const float* cost, const float* samples, float* out,
                            int B, int nd, int H, int W, int k, ss_stream_t stream);
 
+/* SSR_upsample.forward(depth_low, weights, pred_label)   models/submodule.py:412-431 (calls: SemStereo.py:311, 324)
+ * 4x bilinear up-sampling of the 1/4-scale disparity + class-probability-gated residual, one kernel.
+ *   depth_low [B,1,h,w]; weights (spx_pred), pred_label [B,n,4h,4w]; out [B,4h,4w]; n = 6.
+ *   params: ss_ssr_param_count() floats = the module's parameters with every BatchNorm2d folded to
+ *   (scale, shift), packed as laid out at the top of csrc/ssr_upsample.hip (semstereo_amd/modules.py packs it). */
+int ss_ssr_upsample_fwd(const float* depth_low, const float* weights, const float* pred_label,
+                        const float* params, float* out, int B, int h, int w, int num_classes,
+                        ss_stream_t stream);
+int ss_ssr_param_count(void);
+
 /* channelAtt gating (models/SemStereo.py:101-102): out[b,c,d,y,x] = sigmoid(att[b,c,y,x]) * cv[b,c,d,y,x] */
 int ss_channel_gate_fwd(const float* att_logits, const float* cv, float* out,
                         int B, int C, int D, int H, int W, ss_stream_t stream);
@@ -141,8 +151,8 @@ int ss_channel_gate_fwd(const float* att_logits, const float* cv, float* out,
  *   scale, shift   per-Cout affine applied to the accumulator (folded BN; NULL = 1 / 0)
  *   residual       [B,Cout,Do,Ho,Wo] added after the affine (NULL = none)
  *   relu           != 0 -> max(.,0)
- *   gate           [B,Cout,Ho,Wo] channelAtt logits (models/SemStereo.py:101-102): the result is multiplied
- *                  by sigmoid(gate) broadcast over D, last (NULL = none)
+ *   gate           [B,Cout,Ho,Wo] channelAtt gate, already sigmoid-activated (models/SemStereo.py:101-102):
+ *                  the result is multiplied by it, broadcast over D, last (NULL = none)
  *   kernel k in {1,3} (cubic), stride in {1,2}, pad = k/2.  out [B,Cout,Do,Ho,Wo],
  *   Do = (D + 2*pad - k)/stride + 1 ... */
 int ss_conv3d_fwd(const float* in, const float* wpack, const float* scale, const float* shift,

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "ss_sample_strength_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_topk_candidates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_channel_gate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_ssr_upsample_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_bf16s_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_weights_bf16s": [_P, _P, _I, _I, _P],
@@ -42,7 +43,7 @@ _SIGNATURES = {
     "ss_depthwise_patch_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
-EXPORTS = sorted(list(_SIGNATURES) + ["ss_abi_version", "ss_status_string", "ss_last_hip_error"])
+EXPORTS = sorted(list(_SIGNATURES) + ["ss_abi_version", "ss_status_string", "ss_last_hip_error", "ss_ssr_param_count"])
 
 _lib = None
 

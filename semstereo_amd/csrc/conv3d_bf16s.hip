@@ -216,25 +216,39 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     const int od = od0 + dzw;
     if (ow >= Wo || od >= Do) return;
     const size_t out_plane = (size_t)Ho * Wo;
+    // the side inputs (affine, gate, residual) of a group of 4 fragment rows are fetched first, with
+    // clamped (always valid) addresses and no branches, so their latencies overlap instead of chaining
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= Cout) continue;
-        const float sc = scale ? scale[co] : 1.0f;
-        const float sh = shift ? shift[co] : 0.0f;
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+        float sc[4], sh[4], gv[4][NT], rv[4][NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int oh = oh0 + hy0 + i;
-            if (oh >= Ho) continue;
-            const size_t o = (((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow;
-            float v = ss::add_rn(ss::mul_rn(acc[i][r], sc), sh);
-            if (residual) v = ss::add_rn(v, residual[o]);
-            if (relu) v = fmaxf(v, 0.f);
-            if (gate) {      // channelAtt: sigmoid(gate[b,co,h,w]) broadcast over D
-                const float gl = gate[(((size_t)b * Cout + co) * Ho + oh) * Wo + ow];
-                v = ss::mul_rn(1.0f / (1.0f + expf(-gl)), v);
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q;
+            const int co = min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
+            sc[q] = scale ? scale[co] : 1.0f;
+            sh[q] = shift ? shift[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int oh = min(oh0 + hy0 + i, Ho - 1);
+                gv[q][i] = gate ? gate[(((size_t)b * Cout + co) * Ho + oh) * Wo + ow] : 1.0f;
+                rv[q][i] = residual ? residual[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] : 0.0f;
             }
-            out[o] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q;
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co >= Cout) continue;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int oh = oh0 + hy0 + i;
+                if (oh >= Ho) continue;
+                float v = ss::add_rn(ss::mul_rn(acc[i][r], sc[q]), sh[q]);
+                if (residual) v = ss::add_rn(v, rv[q][i]);
+                if (relu) v = fmaxf(v, 0.f);
+                if (gate) v = ss::mul_rn(gv[q][i], v);      // channelAtt gate, broadcast over D
+                out[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] = v;
+            }
         }
     }
 }

@@ -47,6 +47,7 @@ _SWAPS = {
     "patch": M.DepthwisePatch,
     "corr_feature_att_8": M.channelAtt,
     "concat_feature_att_4": M.channelAtt,
+    "ssr_upsample": M.SSR_upsample,
 }
 
 

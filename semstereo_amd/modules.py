@@ -254,7 +254,7 @@ class BasicConv(nn.Module):
         in the model (models/SemStereo.py:319-320) into the conv epilogue."""
         if self.is_3d and not self.deconv and _inference(self, x, gate_logits):
             PATH_COUNTS["hip"] += 1
-            g = None if gate_logits is None else gate_logits.contiguous()
+            g = None if gate_logits is None else torch.sigmoid(gate_logits).contiguous()     # [B,Cout,H,W]: tiny
             return run_convbn(self, "bc", self.conv, self.bn if self.use_bn else None, x, relu=bool(self.relu), gate=g)
         if self.is_3d:
             PATH_COUNTS["torch"] += 1
@@ -493,3 +493,66 @@ class channelAtt(nn.Module):
             return ops.channel_gate(att, cv)
         PATH_COUNTS["torch"] += 1
         return torch.sigmoid(att.unsqueeze(2)) * cv
+
+
+class SSR_upsample(nn.Module):
+    """Semantic-guided refinement head (models/submodule.py:412-431): 4x bilinear up-sampling of the
+    1/4-scale disparity plus a residual gated by the class probabilities.  Keys `conv.{0,1,2}.*`,
+    `conv1.{0,1}.*`, `conv2.{0,1}.*`, `conv3.*`.  Inference: one HIP kernel (ss_ssr_upsample_fwd)."""
+
+    def __init__(self, num_classes):
+        super().__init__()
+        n = self.num_classes = num_classes
+        self.conv = nn.Sequential(nn.BatchNorm2d(1), nn.Conv2d(1, n, kernel_size=3, padding=1), nn.BatchNorm2d(n))
+        self.conv1 = nn.Sequential(nn.Conv2d(n, n, kernel_size=1, padding=0), nn.BatchNorm2d(n))
+        self.conv2 = nn.Sequential(nn.Conv2d(n, n, kernel_size=1, padding=0), nn.BatchNorm2d(n))
+        self.conv3 = nn.Conv2d(n, 1, kernel_size=1, padding=0)
+
+    @classmethod
+    def adopt(cls, ref):
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.num_classes = ref.num_classes
+        for name, child in ref.named_children():
+            setattr(self, name, child)
+        self.train(ref.training)
+        return self
+
+    def _params(self):
+        srcs = [t for t in list(self.parameters()) + list(self.buffers()) if t.dtype.is_floating_point]
+
+        def build():
+            n = self.num_classes
+            s0, t0 = fold_bn(self.conv[0])
+            sa, ta = fold_bn(self.conv[2])
+            s1, t1 = fold_bn(self.conv1[1])
+            s2, t2 = fold_bn(self.conv2[1])
+            parts = [s0, t0, self.conv[1].weight.reshape(n * 9), self.conv[1].bias, sa, ta,
+                     self.conv1[0].weight.reshape(n * n), self.conv1[0].bias, s1, t1,
+                     self.conv2[0].weight.reshape(n * n), self.conv2[0].bias, s2, t2,
+                     self.conv3.weight.reshape(n), self.conv3.bias]
+            return torch.cat([p.detach().float().reshape(-1) for p in parts]).contiguous()
+        return _cache(self).get("ssr", srcs, build)
+
+    def forward(self, depth_low, weights, pred_label):
+        if _inference(self, depth_low, weights, pred_label):
+            PATH_COUNTS["hip"] += 1
+            depth_low, weights, pred_label = [t if t.is_contiguous() else t.contiguous() for t in (depth_low, weights, pred_label)]
+            dev = _lib.require_device(depth_low, weights, pred_label)
+            b, c, h, w = depth_low.shape
+            assert c == 1 and weights.shape == (b, self.num_classes, 4 * h, 4 * w) and pred_label.shape == weights.shape
+            prm = self._params()
+            assert prm.numel() == _lib.load().ss_ssr_param_count()
+            out = torch.empty((b, 4 * h, 4 * w), dtype=depth_low.dtype, device=depth_low.device)
+            with torch.cuda.device(dev):
+                call("ss_ssr_upsample_fwd", ptr(depth_low), ptr(weights), ptr(pred_label), ptr(prm), ptr(out),
+                     b, h, w, self.num_classes)
+            return out
+        PATH_COUNTS["torch"] += 1
+        b, c, h, w = depth_low.shape
+        pred_label = F.softmax(pred_label, dim=1)
+        depth_ = F.interpolate(depth_low, (h * 4, w * 4), mode="bilinear").reshape(b, 1, h * 4, w * 4)
+        depth = self.conv(depth_)
+        prob = torch.sigmoid(self.conv1(pred_label * weights))
+        prob = torch.sigmoid(self.conv2(prob * weights))
+        return (depth_ + self.conv3(depth * prob)).squeeze(1)

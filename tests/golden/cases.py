@@ -129,6 +129,19 @@ def segment_inputs(name):
     return fl4, fr4, fl8, fr8, maxdisp
 
 
+# ---- SSR_upsample head: name -> (B, h, w) of the 1/4-scale disparity -----------------------
+SSR = {"a": (2, 5, 7), "one_px_rows": (1, 1, 9), "b32": (1, 8, 32)}
+
+
+def ssr_inputs(name):
+    B, h, w = SSR[name]
+    s = 900 + sorted(SSR).index(name) * 3
+    depth_low = dd.t_uniform((B, 1, h, w), s, -12.0, 12.0)
+    weights = dd.t_normalish((B, 6, 4 * h, 4 * w), s + 1)
+    label = dd.t_normalish((B, 6, 4 * h, 4 * w), s + 2) * 2.0
+    return depth_low, weights, label
+
+
 def sample_index(numel, n=64, salt=0):
     """n deterministic flat indices into a tensor of `numel` elements."""
     u = dd.uniform((n,), 9000 + salt, 0.0, 1.0).astype(np.float64)

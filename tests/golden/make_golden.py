@@ -194,8 +194,24 @@ def gen_segment(ms):
     print("segment.npz:", len(out), "arrays")
 
 
+def gen_ssr(ref):
+    from oracle import ssr as ossr
+    P = ossr.deterministic_ssr_params()
+    mod = ref.SSR_upsample(6).eval()
+    res = mod.load_state_dict({k[len("ssr_upsample."):]: v for k, v in P.items()}, strict=False)
+    assert not res.unexpected_keys and all(k.endswith("num_batches_tracked") for k in res.missing_keys), res
+    out = {}
+    with torch.no_grad():
+        for n in cases.SSR:
+            d, w, l = cases.ssr_inputs(n)
+            out[f"ssr/{n}"] = f32(mod(d, w, l))
+    np.savez_compressed(os.path.join(HERE, "ssr.npz"), **out)
+    print("ssr.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
+    gen_ssr(load_ref_oplib())
     gen_ops(load_ref_oplib())
     ms = load_ref_model_module()
     gen_stack(ms)

@@ -331,10 +331,10 @@ def test_conv3d_fused_channel_gate(sa, engine):
     ref = torch.sigmoid(gate).unsqueeze(2) * ref
     if engine == "f32":
         y = sa.modules.conv3d_hip(dev(x), sa.modules.pack_conv_weight(dev(w)), dev(scale), dev(shift), 3, 1, True,
-                                  None, dev(gate))
+                                  None, dev(torch.sigmoid(gate)))
     else:
         y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w)), Cout, dev(scale), dev(shift),
-                                        True, 6, None, dev(gate))
+                                        True, 6, None, dev(torch.sigmoid(gate)))
     check(f"conv3d_gate/{engine}", y, ref, 2e-5)
 
 
