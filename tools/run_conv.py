@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Runs only the dominant conv (concat_stem, 64->32 k3 on [B,64,24,H/4,W/4]) so that rocprofv3 PMC passes see
+nothing else.  usage: run_conv.py [engine f32|bf16x6|bf16x3] [iters] [batch]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from semstereo_amd import modules as M  # noqa: E402
+
+engine = sys.argv[1] if len(sys.argv) > 1 else "bf16x6"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+dev = torch.device("cuda")
+x = torch.randn(B, 64, 24, 256, 256, device=dev)
+w = torch.randn(32, 64, 3, 3, 3, device=dev) * (1.0 / (64 * 27)) ** 0.5
+sc, sh = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+if engine == "f32":
+    wp = M.pack_conv_weight(w)
+    fn = lambda: M.conv3d_hip(x, wp, sc, sh, 3, 1, True)
+else:
+    ws = M.pack_conv_weight_bf16s(w)
+    fn = lambda: M.conv3d_bf16s_hip(x, ws, 32, sc, sh, True, 6 if engine == "bf16x6" else 3)
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    fn()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+gf = 2.0 * B * 32 * 64 * 27 * 24 * 256 * 256 / 1e9
+print(f"concat_stem conv [{engine}] B={B}: {ms*1e3:.1f} us/launch, {gf:.1f} GFLOP, {gf/ms:.1f} TFLOP/s fp32-equivalent")
