@@ -31,7 +31,8 @@ struct ACfg {
     static constexpr int QKV = 3 * 32 * TP;       // q,k,v slab of one head group
     static constexpr int YG = 32 * TP;            // attended channels of one head group
     static constexpr int FLAGS = TP;              // pad flag per token
-    static constexpr size_t LDS_BYTES = (size_t)(XS + QKV + YG + FLAGS) * 4;
+    static constexpr int WL = C * 96;             // q/k/v weight slab of one head group, [k][96 features]
+    static constexpr size_t LDS_BYTES = (size_t)(XS + QKV + YG + FLAGS + WL) * 4;
 };
 
 template <int T, int C>
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     float* qkv = xs + A::XS;         // [3*32][TP]   rows 0-31 q, 32-63 k, 64-95 v of the current head group
     float* yg = qkv + A::QKV;        // [32][TP]
     float* flag = yg + A::YG;        // [TP]  1 = padded position (reference mask semantics)
+    float* wl = flag + A::FLAGS;     // [C][96]  qkv_3d weight rows of the current head group, k-major
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -57,15 +59,32 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     const float* xb = x + (size_t)b * C * vol;
 
     // ---- phase 0: window tokens -> LDS (zeros at padded positions and in the N-tile tail) ----
-    for (int e = tid; e < C * A::TP; e += 256) {
-        const int t = e % A::TP, c = e / A::TP;
-        float v = 0.f;
-        if (t < T) {
-            const int iw = t % bw, ih = (t / bw) % bh, id = t / (bw * bh);
-            const int gw = ww * bw + iw, gh = wh * bh + ih, gd = wd * bd + id;
-            if (gh < H && gw < W) v = xb[(size_t)c * vol + (size_t)gd * plane + (size_t)gh * W + gw];
+    if (bw == 4 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+        // a window row is exactly one aligned float4: C * T/4 quads, loaded in branch-free batches
+        constexpr int NQ = C * (A::TP / 4) / 256;          // quads per thread (12 or 8)
+        static_assert(C * (A::TP / 4) % 256 == 0, "whole batches");
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = tid + 256 * i;
+            const int tq = e % (A::TP / 4), c = e / (A::TP / 4);
+            const int ih = tq % bh, id = tq / bh;
+            const int gh = wh * bh + ih, gd = wd * bd + id, gw = ww * 4;
+            const bool ok = gh < H && gw < W;
+            const float4 q = *reinterpret_cast<const float4*>(xb + (size_t)c * vol + (size_t)gd * plane +
+                                                              (size_t)min(gh, H - 1) * W + min(gw, W - 4));
+            *reinterpret_cast<float4*>(&xs[e * 4]) = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        xs[e] = v;
+    } else {
+        for (int e = tid; e < C * A::TP; e += 256) {
+            const int t = e % A::TP, c = e / A::TP;
+            float v = 0.f;
+            if (t < T) {
+                const int iw = t % bw, ih = (t / bw) % bh, id = t / (bw * bh);
+                const int gw = ww * bw + iw, gh = wh * bh + ih, gd = wd * bd + id;
+                if (gh < H && gw < W) v = xb[(size_t)c * vol + (size_t)gd * plane + (size_t)gh * W + gw];
+            }
+            xs[e] = v;
+        }
     }
     for (int t = tid; t < A::TP; t += 256) {
         float f = 0.f;
@@ -88,7 +107,29 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     const float scale = 0.35355339059327379f;    // 8 ** -0.5, rounded to fp32 like the reference's Python float
     constexpr int NGROUPS = C / (HG * HD);
 
+    // the group's 96 weight rows (48 KB) go through LDS, fetched one group ahead into registers:
+    // 4 waves share them, and the MFMA loop never waits on a global load
+    constexpr int NWQ = C * 24 / 256;                 // float4 per thread
+    float4 wreg[NWQ];
+    const float* wsrc[NWQ];                           // this thread's NWQ quads of group 0; group g is + g*32 floats
+#pragma unroll
+    for (int i = 0; i < NWQ; ++i) {
+        const int e = tid + 256 * i;
+        wsrc[i] = wqkv_t + (size_t)(e / 24) * 3 * C + ((e % 24) / 8) * C + ((e % 24) % 8) * 4;
+        wreg[i] = *reinterpret_cast<const float4*>(wsrc[i]);
+    }
+
     for (int g = 0; g < NGROUPS; ++g) {
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i) {
+            const int e = tid + 256 * i;
+            *reinterpret_cast<float4*>(&wl[(e / 24) * 96 + (e % 24) * 4]) = wreg[i];
+        }
+        __syncthreads();
+        if (g + 1 < NGROUPS) {
+#pragma unroll
+            for (int i = 0; i < NWQ; ++i) wreg[i] = *reinterpret_cast<const float4*>(wsrc[i] + (g + 1) * 32);
+        }
         // ---- phase 1: q/k/v slab of this head group = W[rows] * X + bias, by MFMA ----
         for (int u = wave; u < 3 * A::NTL; u += 4) {
             const int mt = u / A::NTL, nt = u % A::NTL;        // mt: 0 = q, 1 = k, 2 = v
@@ -96,11 +137,11 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float* ap = wqkv_t + (size_t)half * 3 * C + f0 + l31;
+            const float* ap = wl + half * 96 + mt * 32 + l31;
             const float* bp = xs + half * A::TP + nt * 32 + l31;
 #pragma unroll 8
             for (int kk = 0; kk < C; kk += 2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)kk * 3 * C], bp[kk * A::TP], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * 96], bp[kk * A::TP], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -109,42 +150,61 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         }
         __syncthreads();
 
-        // ---- phase 2: attention of the group's 4 heads, one (head, query) pair per lane ----
-        for (int p = tid; p < HG * T; p += 256) {
-            const int h = p / T, i = p % T;
-            float q[HD];
+        // ---- phase 2: attention of the group's 4 heads on the matrix core ----
+        // One unit = (head hh, tile of 32 queries).  Scores are computed TRANSPOSED,
+        //   St[key][query] = sum_d K[d][key] * Q[d][query]          (A = K^T, B = Q, 4 K-steps of 2 dims),
+        // so a lane holds ONE query (column) and its keys run over the accumulator registers and the two
+        // lane halves: the softmax over keys is in-register plus one cross-half exchange, and each
+        // accumulator register of the normalised tile is, as it stands, the B operand of a K-step of
+        //   Ot[dim][query] = sum_key V[dim][key] * Pt[key][query]   (A = V rows 0-7, rows 8-31 zero):
+        // register r of key tile kt pairs keys kt*32 + (r&3) + 8*(r>>2) (+4 in the upper half).
+        static_assert(A::TP == T, "windows of 64 / 96 tokens are whole 32-token tiles");
+        for (int u = wave; u < HG * A::NTL; u += 4) {
+            const int hh = u / A::NTL, qt = u % A::NTL;
+            f32x16 st[A::NTL];
 #pragma unroll
-            for (int e = 0; e < HD; ++e) q[e] = qkv[(h * HD + e) * A::TP + i];
-            const float fi = flag[i];
-            float s[T];
+            for (int kt = 0; kt < A::NTL; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+                for (int sd = 0; sd < HD / 2; ++sd)
+                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        qkv[(32 + hh * HD + 2 * sd + half) * A::TP + kt * 32 + l31],     // K[dim][key]
+                        qkv[(hh * HD + 2 * sd + half) * A::TP + qt * 32 + l31],          // Q[dim][query]
+                        st[kt], 0, 0, 0);
+            }
+            const float fq = flag[qt * 32 + l31];
             float mx = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                float d = 0.f;
+            for (int kt = 0; kt < A::NTL; ++kt)
 #pragma unroll
-                for (int e = 0; e < HD; ++e) d = fmaf(q[e], qkv[(32 + h * HD + e) * A::TP + j], d);
-                d = ss::mul_rn(d, scale);
-                if (use_mask && flag[j] != fi) d = ss::add_rn(d, -1000.0f);
-                s[j] = d;
-                mx = fmaxf(mx, d);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    float d = ss::mul_rn(st[kt][r], scale);
+                    if (use_mask && flag[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != fq) d = ss::add_rn(d, -1000.0f);
+                    st[kt][r] = d;
+                    mx = fmaxf(mx, d);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
             float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < T; ++j) { s[j] = expf(s[j] - mx); sum = ss::add_rn(sum, s[j]); }
-            float y[HD];
+            for (int kt = 0; kt < A::NTL; ++kt)
 #pragma unroll
-            for (int e = 0; e < HD; ++e) y[e] = 0.f;
+                for (int r = 0; r < 16; ++r) { st[kt][r] = expf(st[kt][r] - mx); sum = ss::add_rn(sum, st[kt][r]); }
+            sum = ss::add_rn(sum, __shfl_xor(sum, 32));
+            f32x16 ot;
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                const float pj = s[j] / sum;
+            for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+            const float* vrow = qkv + (64 + hh * HD + (l31 & 7)) * A::TP + 4 * half;     // V[dim = lane][...]
 #pragma unroll
-                for (int e = 0; e < HD; ++e) y[e] = fmaf(pj, qkv[(64 + h * HD + e) * A::TP + j], y[e]);
-            }
+            for (int kt = 0; kt < A::NTL; ++kt)
 #pragma unroll
-            for (int e = 0; e < HD; ++e) yg[(h * HD + e) * A::TP + i] = y[e];
-        }
-        if (A::TP > T) {   // keep the N-tile tail finite (its columns are never stored)
-            for (int e = tid; e < 32 * (A::TP - T); e += 256) yg[(e / (A::TP - T)) * A::TP + T + e % (A::TP - T)] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const float vv = (l31 < HD) ? vrow[kt * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;
+                    ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[kt][r] / sum, ot, 0, 0, 0);
+                }
+            // rows 0-3 of Ot sit in registers 0-3 of the lower half, rows 4-7 in those of the upper half
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yg[(hh * HD + 4 * half + r) * A::TP + qt * 32 + l31] = ot[r];
         }
         __syncthreads();
 
