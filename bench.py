@@ -181,6 +181,9 @@ def main():
         M.CONV_ENGINE = engine
 
     if rank != 0:
+        # rank 0 still runs the CPU baseline; meet it at a last barrier so the group is torn down together
+        dist.barrier()
+        dist.destroy_process_group()
         return
     D8, k = 2 * (maxdisp // 8), 24
     H8, W8, H4, W4 = H // 8, W // 8, H // 4, W // 4
@@ -253,7 +256,7 @@ def main():
                                           "algorithmic_bytes_per_launch": nb8,
                                           "traffic": "PMC (profiles/): FETCH_SIZE x2 + WRITE_SIZE = 806.7 MB vs 805.3 MB algorithmic"}
         del a8, b8
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:        # CPU baseline and EPE: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the
         # same workload: about 10-30 s of CPU work.  ATen's CPU kernels stop scaling (the slice
         # loop of build_gwc_volume_norm anti-scales) beyond a few dozen threads, so cap them.
@@ -284,7 +287,10 @@ def main():
         res["epe_vs_oracle_px"] = par["epe_px"]
         res["parity_vs_oracle"] = par
         res["parity_vs_oracle_by_conv_engine"] = {e: parity(o) for e, o in outs.items() if e != engine}
-    print(json.dumps(res))
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

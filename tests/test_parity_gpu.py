@@ -86,6 +86,18 @@ def test_gwc_vs_oracle_fast_path(sa, shape):
           oops.build_gwc_volume_norm(a, b, m, G), 2e-6)
 
 
+def test_gwc_streaming_stores_identical(sa, monkeypatch):
+    """Volumes beyond the infinity cache are written with nontemporal stores: same bits either way."""
+    from oracle import detdata as dd
+    a, b = dd.t_normalish((1, 64, 9, 256, ), 13), dd.t_normalish((1, 64, 9, 256), 14)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SS_GWC_STREAM", flag)
+        outs.append(sa.ops.build_gwc_volume_norm(dev(a), dev(b), 24, 8).cpu())
+    assert torch.equal(outs[0], outs[1])
+    check("gwc_stream", outs[1], oops.build_gwc_volume_norm(a, b, 24, 8), 2e-6)
+
+
 @pytest.mark.parametrize("name", sorted(cases.CONCAT))
 def test_concat(sa, golden, name):
     a, b, m = cases.concat_inputs(name)
