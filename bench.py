@@ -115,6 +115,8 @@ def main():
                                                    "(default: semstereo_amd.modules.CONV_ENGINE)")
     ap.add_argument("--no-other-engines", action="store_true", help="skip the extra timings of the other engines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64-truth", action="store_true", help="skip the float64 run of the oracle (about 4x the "
+                    "fp32 oracle's time) that tells kernel error from the reference algorithm's own conditioning")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the oracle run")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
@@ -250,11 +252,14 @@ def main():
         torch.cuda.synchronize()
         ms8 = e0.elapsed_time(e1) / 20
         nb8 = 8 * nbytes / B
-        res["roofline_cost_volume_b8"] = {"kernel": "gwc_volume_v4<8,true>, batch 8 (BASELINE.json configs[2])", "bound": "hbm",
+        res["roofline_cost_volume_b8"] = {"kernel": "gwc_volume_v4<8,true,stream>, batch 8 (BASELINE.json configs[2])", "bound": "hbm",
                                           "achieved": nb8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": nb8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": ms8,
                                           "algorithmic_bytes_per_launch": nb8,
-                                          "traffic": "PMC (profiles/): FETCH_SIZE x2 + WRITE_SIZE = 806.7 MB vs 805.3 MB algorithmic"}
+                                          "traffic": 806.1e6,
+                                          "traffic_note": "HBM bytes per launch from PMC passes of tools/run_gwc.py 8 (profiles/"
+                                                          "r01_f_gwc_b8_stream_pmc.md): 2 x FETCH_SIZE + WRITE_SIZE, gfx950 "
+                                                          "correction applied; algorithmic 805.3e6"}
         del a8, b8
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and EPE: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the
@@ -284,6 +289,51 @@ def main():
                     "pixels_abs_err_gt_1e-3": (err > 1e-3).float().mean().item(),
                     "pixels_with_identical_top24_candidates": same_px.float().mean().item()}
         par = parity(out)
+        if not args.no_f64_truth:
+            # The same oracle in float64 = the mathematically exact answer of the reference graph for
+            # these weights.  regression_topk's hard top-2 pick (models/submodule.py:436-437) makes
+            # `pred` discontinuous in the costs, so any two fp32 implementations differ by whole
+            # candidates wherever the 2nd/3rd largest cost are closer than their rounding error:
+            # measure both fp32 paths against the truth, and the EPE where the truth's gap is not tiny.
+            P64 = {k_: (v.double() if v.is_floating_point() else v) for k_, v in P.items()}
+            c1 = time.perf_counter()
+            cpu64 = [t.double() for t in cpu_in]
+            tru = oseg.hot_segment(P64, *cpu64, maxdisp, keep=True)
+            e_hip = (out["pred"][:1].cpu().double() - tru["pred"]).abs()
+            e_o32 = (ref["pred"].double() - tru["pred"]).abs()
+            # matching branch alone, every path fed the truth's candidates (no top-24 differences, whose
+            # effect spreads over the 3-D stack's receptive field): cost error and EPE of each fp32 path
+            att32, smp = tru["att_topk"].float(), tru["samples"].float()
+            keep32, cap = {}, {}
+            p32 = oseg.matching_branch(P, cpu_in[0], cpu_in[1], att32, smp, keep32)
+            hk = seg.classif.register_forward_hook(lambda m_, a_, o_: cap.__setitem__("cost", o_.detach()))
+            with torch.no_grad():
+                ph = seg.matching_branch(feats[0][:1], feats[1][:1], att32.to(device), smp.to(device))
+            hk.remove()
+            cost64 = tru["cost"].squeeze(1)
+            top3 = cost64.topk(3, dim=1).values
+            gap = (top3[:, 1] - top3[:, 2]).unsqueeze(1)
+            ok = gap > 1e-4
+            g_hip = (ph.cpu().double() - tru["pred"]).abs()
+            g_o32 = (p32.double() - tru["pred"]).abs()
+
+            def rms(x):
+                return x.double().pow(2).mean().sqrt().item()
+            par["vs_float64_truth"] = {
+                "whole_path_hip_epe_px": e_hip.mean().item(), "whole_path_oracle_fp32_epe_px": e_o32.mean().item(),
+                "given_truth_candidates": {
+                    "hip_cost_rms_err": rms(cap["cost"].cpu().squeeze(1).double() - cost64),
+                    "oracle_fp32_cost_rms_err": rms(keep32["cost"].squeeze(1).double() - cost64),
+                    "hip_epe_px": g_hip.mean().item(), "oracle_fp32_epe_px": g_o32.mean().item(),
+                    "hip_epe_px_where_truth_top2_gap_gt_1e-4": g_hip[ok].mean().item(),
+                    "hip_max_err_px_there": g_hip[ok].max().item(),
+                    "oracle_fp32_epe_px_there": g_o32[ok].mean().item(),
+                    "oracle_fp32_max_err_px_there": g_o32[ok].max().item(),
+                    "fraction_of_pixels_there": ok.double().mean().item()},
+                "truth_cost_std_over_candidates": cost64.std(dim=1).mean().item(),
+                "truth_top2_gap_median": gap.median().item(),
+                "fraction_of_pixels_with_gap_lt_1e-5": (gap < 1e-5).double().mean().item(),
+                "seconds": time.perf_counter() - c1}
         res["epe_vs_oracle_px"] = par["epe_px"]
         res["parity_vs_oracle"] = par
         res["parity_vs_oracle_by_conv_engine"] = {e: parity(o) for e, o in outs.items() if e != engine}

@@ -46,7 +46,8 @@ def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None):
     att_prob = F.softmax(torch.gather(aw, 2, ind_k).squeeze(1), dim=1)                 # :307-308
     pred_att = (att_prob * samples).sum(dim=1)                                         # :309-310
     if out is not None:
-        out.update(corr_volume=corr, cost_att=cost_att, att_weights=aw, pred_att0=pred0)
+        out.update(corr_volume=corr, cost_att=cost_att, att_weights=aw, pred_att0=pred0, strength=strength,
+                   att_topk_full=att_topk)
     return att_topk, samples, pred_att
 
 
@@ -58,7 +59,11 @@ def matching_branch(P, fl4, fr4, att_topk, samples, out=None):
     volume = att_topk * torch.cat((left_b, right_w), dim=1)                            # :243, :318
     volume = stack.basic_conv(P, "concat_stem", volume, is_3d=True)                    # :319
     volume = stack.channel_att(P, "concat_feature_att_4", volume, fl4)                 # :320
+    if out is not None:
+        out.update(concat_l=cl, stem=volume)
     cost = stack.hourglass(P, "hourglass", volume, (6, 4, 4))                          # :321
+    if out is not None:
+        out.update(hourglass=cost)
     cost = stack.classifier(P, "classif", cost)                                        # :322
     pred = ops.regression_topk(cost.squeeze(1), samples, 2)                            # :323
     if out is not None:

@@ -16,6 +16,8 @@
 // only approximately (w - disp, h): rows h-1..h+1 can carry ~1e-5 weights, which we keep.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -68,10 +70,19 @@ template <> __device__ __forceinline__ void load_vec<4>(const float* p, float (&
     const float4 q = *reinterpret_cast<const float4*>(p);
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 }
-template <int VEC> __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]);
-template <> __device__ __forceinline__ void store_vec<1>(float* p, const float (&v)[1]) { *p = v[0]; }
-template <> __device__ __forceinline__ void store_vec<4>(float* p, const float (&v)[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+// nt: nontemporal store (volumes larger than the 256 MB infinity cache gain nothing from allocating in it)
+template <int VEC> __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC], int nt);
+template <> __device__ __forceinline__ void store_vec<1>(float* p, const float (&v)[1], int nt) {
+    if (nt) __builtin_nontemporal_store(v[0], p); else *p = v[0];
+}
+template <> __device__ __forceinline__ void store_vec<4>(float* p, const float (&v)[4], int nt) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    if (nt) {
+        v4f q = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
 }
 
 enum { MODE_WARP = 0, MODE_CONCAT = 1, MODE_CORR = 2 };
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
                                                     const float* __restrict__ disp, const float* __restrict__ gate,
                                                     float* __restrict__ out0, float* __restrict__ out1,
                                                     int C, int H, int W, int nd, float half_w, float half_h,
-                                                    long long total) {
+                                                    long long total, int nt) {
     const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int WQ = W / VEC;
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
         }
 #pragma unroll
         for (int p = 0; p < VEC; ++p) acc[p] = acc[p] / (float)C;
-        store_vec<VEC>(out0 + (b * nd + j) * plane + pix, acc);
+        store_vec<VEC>(out0 + (b * nd + j) * plane + pix, acc, 0);
         return;
     }
 
@@ -130,11 +141,11 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
 #pragma unroll
         for (int p = 0; p < VEC; ++p) wv[p] = sample(yp, tp[p]);
         if (MODE == MODE_WARP) {
-            store_vec<VEC>(out0 + ((b * CO + c) * nd + j) * plane + pix, wv);
+            store_vec<VEC>(out0 + ((b * CO + c) * nd + j) * plane + pix, wv, nt);
             if (out1 != nullptr) {
                 float xv[VEC];
                 load_vec<VEC>(x + (b * C + c) * plane + pix, xv);
-                store_vec<VEC>(out1 + ((b * CO + c) * nd + j) * plane + pix, xv);
+                store_vec<VEC>(out1 + ((b * CO + c) * nd + j) * plane + pix, xv, nt);
             }
         } else {
             float xv[VEC];
@@ -143,8 +154,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
 #pragma unroll
                 for (int p = 0; p < VEC; ++p) { xv[p] = ss::mul_rn(g[p], xv[p]); wv[p] = ss::mul_rn(g[p], wv[p]); }
             }
-            store_vec<VEC>(out0 + ((b * CO + c) * nd + j) * plane + pix, xv);
-            store_vec<VEC>(out0 + ((b * CO + C + c) * nd + j) * plane + pix, wv);
+            store_vec<VEC>(out0 + ((b * CO + c) * nd + j) * plane + pix, xv, nt);
+            store_vec<VEC>(out0 + ((b * CO + C + c) * nd + j) * plane + pix, wv, nt);
         }
     }
 }
@@ -161,12 +172,15 @@ int launch(const float* x, const float* y, const float* disp, const float* gate,
     const long long total = (long long)B * nd * H * (v4 ? W / 4 : W);
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    const int planes = (MODE == MODE_CORR) ? 1 : (MODE == MODE_CONCAT || out1 != nullptr) ? 2 * C : C;
+    int nt = (size_t)B * planes * nd * H * W * sizeof(float) > ((size_t)192 << 20);
+    if (const char* f = getenv("SS_WARP_STREAM")) nt = f[0] == '1';      // tuning aid
     if (v4)
         hipLaunchKernelGGL((warp_kernel<MODE, 4>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, disp, gate, out0,
-                           out1, C, H, W, nd, half_w, half_h, total);
+                           out1, C, H, W, nd, half_w, half_h, total, nt);
     else
         hipLaunchKernelGGL((warp_kernel<MODE, 1>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, disp, gate, out0,
-                           out1, C, H, W, nd, half_w, half_h, total);
+                           out1, C, H, W, nd, half_w, half_h, total, nt);
     return ss::check_launch();
 }
 

@@ -9,6 +9,8 @@ the fusions SURVEY.md section 8(f) asks for (patch+gate, softmax+regression+vari
 warp+correlation, warp+concat+gate); the remaining glue (trilinear upsampling, softmax, sort /
 top-24 / gather, the 5-tap propagation) is PyTorch-on-GPU as in the reference.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -21,6 +23,16 @@ _PROP_TAPS = ((-1, -1), (0, 0), (1, 1), (1, -1), (-1, 1))    # models/submodule.
 
 OWNED_PREFIXES = ("patch", "corr_feature_att_8", "hourglass_att", "classif_att_", "gamma", "beta",
                   "concat_feature", "concat_stem", "concat_feature_att_4", "hourglass", "classif")
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
 
 
 def propagation(x):
@@ -39,6 +51,8 @@ def propagation_prob(v):
 
 
 class HotSegment(nn.Module):
+    OVERLAP = os.environ.get("SS_OVERLAP", "1") != "0"     # two-stream overlap of the branches (inference)
+
     def __init__(self, maxdisp, c8=256, c4=128):
         super().__init__()
         assert maxdisp % 64 == 0, "the reference graph needs maxdisp % 64 == 0 (SURVEY.md section 0.4)"
@@ -106,21 +120,24 @@ class HotSegment(nn.Module):
         return att_topk, samples, pred_att, pred0
 
     # ---- models/SemStereo.py:314-323 ---------------------------------------------------
-    def matching_branch(self, fl4, fr4, att_topk, samples):
+    def matching_prelude(self, fl4, fr4):
+        """:314-315 and the image half of :320 -- the 2-D convolutions that do not depend on the attention
+        branch (fast path only): concat features of both views in one batch (shared weights) and the logits
+        of the concat_feature_att_4 gate."""
+        cl, cr = self.concat_feature(torch.cat((fl4, fr4), dim=0)).split(fl4.shape[0], dim=0)
+        return cl, cr, self.concat_feature_att_4.logits(fl4)
+
+    def matching_branch(self, fl4, fr4, att_topk, samples, prelude=None):
         fast = M._inference(self, fl4, fr4, att_topk)
-        if fast:     # one MIOpen call for both views (the weights are shared): :314-315
-            cl, cr = self.concat_feature(torch.cat((fl4, fr4), dim=0)).split(fl4.shape[0], dim=0)
+        if fast:
+            cl, cr, gate4 = prelude if prelude is not None else self.matching_prelude(fl4, fr4)
+            volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                      # :316 + :318 fused
+            volume = self.concat_stem(volume, gate4)                                           # :319 + :320 fused
         else:
             cl = self.concat_feature(fl4)                                                      # :314
             cr = self.concat_feature(fr4)                                                      # :315
-        if fast:
-            volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                      # :316 + :318 fused
-        else:
             right_w, left_b = ops.SpatialTransformer_grid(cl, cr, samples)
             volume = att_topk * torch.cat((left_b, right_w), dim=1)
-        if fast:
-            volume = self.concat_stem(volume, self.concat_feature_att_4.logits(fl4))           # :319 + :320 fused
-        else:
             volume = self.concat_stem(volume)                                                  # :319
             volume = self.concat_feature_att_4(volume, fl4)                                    # :320
         cost = self.classif(self.hourglass(volume))                                            # :321-322
@@ -129,6 +146,19 @@ class HotSegment(nn.Module):
     def forward(self, fl4, fr4, fl8, fr8):
         """features_left[1], features_right[1] [B,128,H/4,W/4]; features_left[2], features_right[2]
         [B,256,H/8,W/8]  ->  dict(pred [B,1,H/4,W/4], pred_att [B,H/4,W/4], samples, att_topk, pred_att0)."""
+        prelude = None
+        if self.OVERLAP and fl4.is_cuda and M._inference(self, fl4, fr4, fl8, fr8):
+            # The attention branch works at 1/8 scale: at small batch most of its kernels cannot fill
+            # 256 CUs.  The matching branch's 2-D convolutions are independent of it, so they run on a
+            # second HIP stream underneath and join before the sparse concat volume is built.
+            cur, side = torch.cuda.current_stream(fl4.device), _side_stream(fl4.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                prelude = self.matching_prelude(fl4, fr4)
         att_topk, samples, pred_att, pred0 = self.attention_branch(fl4, fr4, fl8, fr8)
-        pred = self.matching_branch(fl4, fr4, att_topk, samples)
+        if prelude is not None:
+            cur.wait_stream(side)
+            for t in prelude:
+                t.record_stream(cur)
+        pred = self.matching_branch(fl4, fr4, att_topk, samples, prelude)
         return dict(pred=pred, pred_att=pred_att, samples=samples, att_topk=att_topk, pred_att0=pred0)

@@ -154,6 +154,19 @@ def test_warp_fused_forms(sa):
     check("warp_correlation", sa.ops.warp_correlation(dev(x), dev(y), dev(disp)), (xw * yw).mean(dim=1), 1e-6, 2e-6)
 
 
+def test_warp_streaming_stores_identical(sa, monkeypatch):
+    from oracle import detdata as dd
+    B, C, H, W, nd = 1, 8, 6, 64, 5
+    x, y = dd.t_normalish((B, C, H, W), 45), dd.t_normalish((B, C, H, W), 46)
+    disp = dd.distinct_sorted_candidates(B, nd, H, W, 16, 47)
+    att = dd.t_uniform((B, 1, nd, H, W), 48, 0.0, 1.0)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SS_WARP_STREAM", flag)
+        outs.append(sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp), dev(att)).cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("name", sorted(cases.TOPK))
 def test_topk(sa, golden, name):
     c, s, k = cases.topk_inputs(name)
@@ -474,6 +487,44 @@ def test_hot_segment_vs_reference_fixture(sa, golden, name):
     check(f"segment/{name}/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
     check(f"segment/{name}/pred", r["pred"], g[f"{name}/pred"], 1e-3)
     REPORT[f"segment/{name}/epe_vs_ref"] = oops.epe(r["pred"].cpu(), torch.as_tensor(g[f"{name}/pred"]))
+
+
+def test_matching_branch_as_close_to_float64_truth_as_the_fp32_oracle(sa):
+    """The property bench.py reports at full size.  `pred` is discontinuous in the costs (hard top-2 pick,
+    models/submodule.py:436-437), so against the float64 evaluation of the same graph ("truth") any fp32
+    path is off by whole candidates wherever the 2nd/3rd largest costs sit within rounding error.  With
+    every path fed the truth's 24 candidates: the HIP path's cost error is no larger than 2x the fp32 CPU
+    oracle's, and where the truth's top-2/top-3 gap exceeds 1e-4 the EPE is <= 1e-4 px (max <= 1e-3 px)."""
+    from oracle import detdata as dd
+    H, maxdisp = 512, 128
+    seg, P = _segment(sa, maxdisp)
+    ins = [dd.t_normalish((1, 128, H // 4, H // 4), 201), dd.t_normalish((1, 128, H // 4, H // 4), 202),
+           dd.t_normalish((1, 256, H // 8, H // 8), 203), dd.t_normalish((1, 256, H // 8, H // 8), 204)]
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    tru = oseg.hot_segment(P64, *[t.double() for t in ins], maxdisp, keep=True)
+    att32, smp = tru["att_topk"].float(), tru["samples"].float()
+    keep32, cap = {}, {}
+    with torch.no_grad():
+        p32 = oseg.matching_branch(P, ins[0], ins[1], att32, smp, keep32)
+        hk = seg.classif.register_forward_hook(lambda m, a, o: cap.__setitem__("cost", o.detach()))
+        ph = seg.matching_branch(dev(ins[0]), dev(ins[1]), dev(att32), dev(smp))
+        hk.remove()
+    cost64 = tru["cost"].squeeze(1)
+    top3 = cost64.topk(3, dim=1).values
+    ok = ((top3[:, 1] - top3[:, 2]) > 1e-4).unsqueeze(1)
+    rms = lambda x: float(x.double().pow(2).mean().sqrt())                                   # noqa: E731
+    c_hip, c_o32 = rms(cap["cost"].cpu().squeeze(1).double() - cost64), rms(keep32["cost"].squeeze(1).double() - cost64)
+    e_hip = (ph.cpu().double() - tru["pred"]).abs()
+    e_o32 = (p32.double() - tru["pred"]).abs()
+    REPORT["segment_f64/cost_rms_err_hip"] = c_hip
+    REPORT["segment_f64/cost_rms_err_oracle32"] = c_o32
+    REPORT["segment_f64/epe_hip"] = float(e_hip.mean())
+    REPORT["segment_f64/epe_oracle32"] = float(e_o32.mean())
+    REPORT["segment_f64/epe_hip_gap_gt_1e-4"] = float(e_hip[ok].mean())
+    REPORT["segment_f64/fraction_gap_gt_1e-4"] = float(ok.double().mean())
+    assert c_hip <= 2.0 * c_o32 + 1e-7
+    assert float(ok.double().mean()) > 0.5
+    assert float(e_hip[ok].mean()) <= 1e-4 and float(e_hip[ok].max()) <= 1e-3
 
 
 def test_reference_shaped_composition_on_gpu(sa, golden):
