@@ -10,9 +10,10 @@
 //                                     probabilities, and the soft-argmax over them
 //
 // The reference runs ~25 ATen kernels here, materialises a [B,5,D,H,W] volume and fully sorts D
-// values per pixel to keep 24.  Both kernels are one thread per pixel with lanes along W (every
-// plane access is a coalesced row segment); the candidate kernel parks the pixel's D logits and
-// probabilities in LDS ([D][threads], conflict-free) and ranks them by counting.
+// values per pixel to keep 24.  Both kernels put 64 consecutive pixels on the lanes (every plane access is
+// a coalesced row segment) and split the per-pixel work -- channels, candidates -- over the 4 waves of
+// the workgroup, so that a single 1024x1024 pair still gives every SIMD 4 waves; the candidate kernel
+// parks the pixel's D probabilities in LDS ([D][64], conflict-free) and ranks them by counting.
 #include <algorithm>
 #include <limits.h>
 
@@ -64,38 +65,53 @@ __device__ __forceinline__ float bilinear(const float* __restrict__ plane, const
 }
 
 // strength[b,t,y,x] = softmax_t( mean_c left[c] * warp(right, pred0[nb_t])[c]  *  sigmoid(beta + gamma * var[nb_t]) )
+// 64 pixels x 4 waves: wave q owns channels [q*C/4, (q+1)*C/4) of the same 64 pixels (a pixel per thread
+// would leave a 1024x1024 pair with one wave per SIMD and 1408 dependent L2 reads each); the four partial
+// correlations meet in LDS and wave 0 finishes the softmax.
 __global__ __launch_bounds__(256) void sample_strength_kernel(const float* __restrict__ left, const float* __restrict__ right,
                                                                const float* __restrict__ pred0, const float* __restrict__ var,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* __restrict__ strength, int C, int H, int W,
                                                                float half_w, float half_h, long long total) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    __shared__ float part[4][5][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long i = blockIdx.x * 64LL + lane;
+    const bool active = i < total;
     const long long plane = (long long)H * W;
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const long long b = i / plane;
-    const float g = gamma[0], bt = beta[0];
+    const long long ii = active ? i : 0;
+    const int x = (int)(ii % W), y = (int)((ii / W) % H);
+    const long long b = ii / plane;
     Taps4 tp[5];
-    float gate[5];
+    long long nbs[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);   // replicate pad
-        const long long nb = b * plane + (long long)yy * W + xx;
-        const float v = ss::add_rn(bt, ss::mul_rn(g, var[nb]));
-        gate[t] = 1.0f / (1.0f + expf(-v));
-        tp[t] = bilinear_taps(pred0[nb], y, x, H, W, half_w, half_h);
+        nbs[t] = b * plane + (long long)yy * W + xx;
+        tp[t] = bilinear_taps(pred0[nbs[t]], y, x, H, W, half_w, half_h);
     }
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     const long long pix = (long long)y * W + x;
-    for (int c = 0; c < C; ++c) {
+    const int cq = (C + 3) / 4, c0 = q * cq, c1 = min(C, c0 + cq);
+    for (int c = c0; c < c1; ++c) {
         const float l = left[(b * C + c) * plane + pix];
         const float* rp = right + (b * C + c) * plane;
 #pragma unroll
         for (int t = 0; t < 5; ++t) acc[t] = ss::add_rn(acc[t], ss::mul_rn(l, bilinear(rp, tp[t])));
     }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) part[q][t][lane] = acc[t];
+    __syncthreads();
+    if (q != 0 || !active) return;
+    const float g = gamma[0], bt = beta[0];
     float z[5], mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) { z[t] = ss::mul_rn(acc[t] / (float)C, gate[t]); mx = fmaxf(mx, z[t]); }
+    for (int t = 0; t < 5; ++t) {
+        const float v = ss::add_rn(bt, ss::mul_rn(g, var[nbs[t]]));
+        const float gate = 1.0f / (1.0f + expf(-v));
+        const float corr = ss::add_rn(ss::add_rn(ss::add_rn(part[0][t][lane], part[1][t][lane]), part[2][t][lane]), part[3][t][lane]);
+        z[t] = ss::mul_rn(corr / (float)C, gate);
+        mx = fmaxf(mx, z[t]);
+    }
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 5; ++t) { z[t] = expf(z[t] - mx); sum = ss::add_rn(sum, z[t]); }
@@ -177,26 +193,31 @@ __global__ void topk_candidates_kernel(const float* __restrict__ logits, const f
     pred_att[b * plane + pix] = acc;
 }
 
-// Same contract, D known at compile time: the pixel's D probabilities live in registers and the
-// ranking is a count of strictly greater values (2 VALU ops per pair, no LDS traffic).  Stable-sort
-// semantics from the counts alone: values of one tie group share their count G and occupy ranks
-// G .. G+E-1 in index order; with g* = max{G < K} every group with G < g* is selected whole and the
-// group G == g* contributes its first K - g* members in index order.
+// Same contract, D known at compile time.  64 pixels x 4 waves: wave q owns the candidates
+// [q*D/4, (q+1)*D/4) of the same 64 pixels (one thread per pixel leaves a 1024x1024 pair with a single
+// wave per SIMD).  Ranking is a count of strictly greater values: each thread keeps its D/4
+// probabilities in registers and streams all D of the pixel past them from LDS ([D][64], conflict-
+// free).  Stable-sort semantics from the counts alone: values of one tie group share their count G
+// and occupy ranks G .. G+E-1 in index order; with g* = max{G < K} every group with G < g* is selected
+// whole and the group G == g* contributes its first K - g* members in index order (the per-wave
+// quotas follow from the waves' tie counts).
 template <int D>
-__global__ __launch_bounds__(128) void topk_candidates_reg(const float* __restrict__ logits, const float* __restrict__ strength,
-                                                            float* __restrict__ samples, float* __restrict__ att_topk,
-                                                            float* __restrict__ pred_att, int H, int W, int K, int m,
-                                                            long long total) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int T = 128;
-    const int tid = threadIdx.x;
-    float* aw = lds;                                            // [D][T] logits after propagation
-    int* gl = reinterpret_cast<int*>(lds + (size_t)D * T);      // [D][T] strictly-greater counts
-    const long long i = blockIdx.x * (long long)T + tid;
-    if (i >= total) return;
+__global__ __launch_bounds__(256) void topk_candidates_split(const float* __restrict__ logits, const float* __restrict__ strength,
+                                                              float* __restrict__ samples, float* __restrict__ att_topk,
+                                                              float* __restrict__ pred_att, int H, int W, int K, int m,
+                                                              long long total) {
+    constexpr int DQ = D / 4;
+    static_assert(D % 4 == 0, "D splits over 4 waves");
+    __shared__ float pr[D][64];
+    __shared__ float redf[4][64];
+    __shared__ int redi[2][4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long i = blockIdx.x * 64LL + lane;
+    const bool active = i < total;
+    const long long ii = active ? i : 0;
     const long long plane = (long long)H * W;
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const long long b = i / plane;
+    const int x = (int)(ii % W), y = (int)((ii / W) % H);
+    const long long b = ii / plane;
     const long long pix = (long long)y * W + x;
     int nb[5];
     float st[5];
@@ -206,67 +227,99 @@ __global__ __launch_bounds__(128) void topk_candidates_reg(const float* __restri
         nb[t] = yy * W + xx;
         st[t] = strength[(b * 5 + t) * plane + pix];
     }
-    const float* lb = logits + b * D * plane;
-    float p[D];
+    // aw[d] = sum_t logits[d, nb_t] * strength[t]   (:295-297)
+    const float* lb = logits + (b * D + q * DQ) * plane;
+    float aw[DQ], p[DQ];
     float mx = -INFINITY;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float* lp = lb + d * plane;
+    for (int k = 0; k < DQ; ++k) {
+        const float* lp = lb + k * plane;
         float a = 0.f;
 #pragma unroll
         for (int t = 0; t < 5; ++t) a = ss::add_rn(a, ss::mul_rn(lp[nb[t]], st[t]));
-        p[d] = a;
-        aw[d * T + tid] = a;
+        aw[k] = a;
         mx = fmaxf(mx, a);
     }
-    float sum = 0.f;
+    redf[q][lane] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0][lane], redf[1][lane]), fmaxf(redf[2][lane], redf[3][lane]));
+    __syncthreads();
+    float sum = 0.f;                                            // softmax over D (:298)
 #pragma unroll
-    for (int d = 0; d < D; ++d) { p[d] = expf(p[d] - mx); sum = ss::add_rn(sum, p[d]); }
+    for (int k = 0; k < DQ; ++k) { p[k] = expf(aw[k] - mx); sum = ss::add_rn(sum, p[k]); }
+    redf[q][lane] = sum;
+    __syncthreads();
+    sum = ss::add_rn(ss::add_rn(ss::add_rn(redf[0][lane], redf[1][lane]), redf[2][lane]), redf[3][lane]);
 #pragma unroll
-    for (int d = 0; d < D; ++d) p[d] = p[d] / sum;
+    for (int k = 0; k < DQ; ++k) { p[k] = p[k] / sum; pr[q * DQ + k][lane] = p[k]; }
+    __syncthreads();
 
+    int g[DQ];
 #pragma unroll
-    for (int d = 0; d < D; ++d) gl[d * T + tid] = __float_as_int(p[d]);   // slot c holds p[c] until its count replaces it
-
+    for (int k = 0; k < DQ; ++k) g[k] = 0;
+#pragma unroll 4
+    for (int j = 0; j < D; ++j) {
+        const float u = pr[j][lane];
+#pragma unroll
+        for (int k = 0; k < DQ; ++k) g[k] += (u > p[k]) ? 1 : 0;
+    }
     int gstar = -1;
-#pragma unroll 2
-    for (int c = 0; c < D; ++c) {
-        const float v = __int_as_float(gl[c * T + tid]);
-        int g = 0;
 #pragma unroll
-        for (int j = 0; j < D; ++j) g += (p[j] > v) ? 1 : 0;
-        gl[c * T + tid] = g;
-        if (g < K) gstar = max(gstar, g);
+    for (int k = 0; k < DQ; ++k)
+        if (g[k] < K) gstar = max(gstar, g[k]);
+    redi[0][q][lane] = gstar;
+    __syncthreads();
+    gstar = max(max(redi[0][0][lane], redi[0][1][lane]), max(redi[0][2][lane], redi[0][3][lane]));
+    int nsel = 0, ntie = 0;                                     // this wave's whole-group members / boundary-group members
+#pragma unroll
+    for (int k = 0; k < DQ; ++k) { nsel += (g[k] < gstar) ? 1 : 0; ntie += (g[k] == gstar) ? 1 : 0; }
+    redi[1][q][lane] = nsel | (ntie << 16);
+    __syncthreads();
+    int quota = K - gstar, cnt = 0;                             // ties still to take when this wave starts, outputs before it
+    for (int qq = 0; qq < q; ++qq) {
+        const int v = redi[1][qq][lane];
+        const int take = min(v >> 16, quota);
+        quota -= take;
+        cnt += (v & 0xffff) + take;
     }
-    int quota = K - gstar;               // members of the boundary tie group still to take
+    unsigned sel = 0u;
     float smax = -INFINITY;
-    unsigned long long sel[(D + 63) / 64];
 #pragma unroll
-    for (int w = 0; w < (D + 63) / 64; ++w) sel[w] = 0ull;
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        const int g = gl[c * T + tid];
-        bool s = g < gstar;
-        if (g == gstar && quota > 0) { s = true; --quota; }
-        if (s) { sel[c / 64] |= 1ull << (c % 64); smax = fmaxf(smax, aw[c * T + tid]); }
+    for (int k = 0; k < DQ; ++k) {
+        bool s = g[k] < gstar;
+        if (g[k] == gstar && quota > 0) { s = true; --quota; }
+        if (s) { sel |= 1u << k; smax = fmaxf(smax, aw[k]); }
     }
-    float esum = 0.f;
-    int cnt = 0;
+    redf[q][lane] = smax;
+    __syncthreads();
+    smax = fmaxf(fmaxf(redf[0][lane], redf[1][lane]), fmaxf(redf[2][lane], redf[3][lane]));
+    __syncthreads();
+    float esum = 0.f, wsum = 0.f;                               // :307-310 over the selected, ascending index
 #pragma unroll
-    for (int c = 0; c < D; ++c) {
-        if (!((sel[c / 64] >> (c % 64)) & 1ull)) continue;
-        samples[(b * K + cnt) * plane + pix] = (float)(c - m);
-        att_topk[(b * K + cnt) * plane + pix] = p[c];
-        esum = ss::add_rn(esum, expf(aw[c * T + tid] - smax));
+    for (int k = 0; k < DQ; ++k) {
+        if (!((sel >> k) & 1u)) continue;
+        const int c = q * DQ + k;
+        if (active) {
+            samples[(b * K + cnt) * plane + pix] = (float)(c - m);
+            att_topk[(b * K + cnt) * plane + pix] = p[k];
+        }
+        const float e = expf(aw[k] - smax);
+        esum = ss::add_rn(esum, e);
         ++cnt;
     }
-    float acc = 0.f;
+    redf[q][lane] = esum;
+    __syncthreads();
+    esum = ss::add_rn(ss::add_rn(ss::add_rn(redf[0][lane], redf[1][lane]), redf[2][lane]), redf[3][lane]);
+    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < D; ++c) {
-        if (!((sel[c / 64] >> (c % 64)) & 1ull)) continue;
-        acc = ss::add_rn(acc, ss::mul_rn(expf(aw[c * T + tid] - smax) / esum, (float)(c - m)));
+    for (int k = 0; k < DQ; ++k) {
+        if (!((sel >> k) & 1u)) continue;
+        wsum = ss::add_rn(wsum, ss::mul_rn(expf(aw[k] - smax) / esum, (float)(q * DQ + k - m)));
     }
-    pred_att[b * plane + pix] = acc;
+    redf[q][lane] = wsum;
+    __syncthreads();
+    if (q == 0 && active)
+        pred_att[b * plane + pix] = ss::add_rn(ss::add_rn(ss::add_rn(redf[0][lane], redf[1][lane]), redf[2][lane]), redf[3][lane]);
 }
 
 // softmax over D + expectation + variance (models/SemStereo.py:281-285): 64 pixels x 4 waves, the
@@ -360,7 +413,7 @@ extern "C" int ss_sample_strength_fwd(const float* left, const float* right, con
     SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0);
     const long long total = (long long)B * H * W;
     const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
-    hipLaunchKernelGGL(sample_strength_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(sample_strength_kernel, dim3((unsigned)ss::ceil_div_ll(total, 64)), dim3(256), 0,
                        ss::as_stream(stream), left, right, pred0, var, gamma, beta, strength, C, H, W, half_w, half_h, total);
     return ss::check_launch();
 }
@@ -376,15 +429,9 @@ extern "C" int ss_topk_candidates_fwd(const float* logits, const float* strength
     const long long npix = (long long)B * H * W;
 #define SS_TOPK_REG(DD)                                                                                              \
     if (D == DD) {                                                                                                   \
-        auto kr = topk_candidates_reg<DD>;                                                                           \
-        const size_t bytes = (size_t)2 * DD * T * sizeof(float);                                                     \
-        if (bytes > 64 * 1024) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr),                                    \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);              \
-            if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }                                    \
-        }                                                                                                            \
-        hipLaunchKernelGGL(kr, dim3((unsigned)ss::ceil_div_ll(npix, T)), dim3(T), bytes, ss::as_stream(stream),     \
-                           logits, strength, samples, att_topk, pred_att, H, W, k, maxdisp, npix);                   \
+        hipLaunchKernelGGL(topk_candidates_split<DD>, dim3((unsigned)ss::ceil_div_ll(npix, 64)), dim3(256), 0,       \
+                           ss::as_stream(stream), logits, strength, samples, att_topk, pred_att, H, W, k, maxdisp,   \
+                           npix);                                                                                    \
         return ss::check_launch();                                                                                   \
     }
     SS_TOPK_REG(32)

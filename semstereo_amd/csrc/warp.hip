@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
         float acc[VEC];
 #pragma unroll
         for (int p = 0; p < VEC; ++p) acc[p] = 0.f;
+#pragma unroll 4
         for (int c = 0; c < C; ++c) {
             const float* yp = y + (b * C + c) * plane;
             float xv[VEC];
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
     float g[VEC];
     if (MODE == MODE_CONCAT && gate != nullptr) load_vec<VEC>(gate + (b * nd + j) * plane + pix, g);
     const int CO = (MODE == MODE_CONCAT) ? 2 * C : C;
+#pragma unroll 4
     for (int c = 0; c < C; ++c) {
         const float* yp = y + (b * C + c) * plane;
         float wv[VEC];
