@@ -21,25 +21,23 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int TD, int TH, int CIT, int CST>
+template <int TD, int TH, int CIT>
 struct DCfg {
     static constexpr int ID = TD + 1, IH = TH + 1, IW = 33;
     static constexpr int CS = ID * IH * IW;
     static constexpr int IN_FLOATS = CIT * CS;
     static constexpr int W_FLOATS = CIT * 27 * 32;
-    static constexpr int SK_CS = (2 * TD) * (2 * TH) * 64;      // floats per staged skip channel
-    static constexpr int SK_FLOATS = CST * SK_CS + CST * 32;
-    static constexpr int LDS_FLOATS = (IN_FLOATS + W_FLOATS) > SK_FLOATS ? (IN_FLOATS + W_FLOATS) : SK_FLOATS;
-    static_assert(TD * TH == 4 && CIT % 2 == 0 && CST % 2 == 0, "4 waves x one row each");
+    static constexpr int LDS_FLOATS = IN_FLOATS + W_FLOATS;
+    static_assert(TD * TH == 4 && CIT % 2 == 0, "4 waves x one row each");
 };
 
-template <int TD, int TH, int CIT, int CST>
+template <int TD, int TH, int CIT, bool HAS_SKIP>
 __global__ __launch_bounds__(256, 2) void deconv3d_mfma(const float* __restrict__ in, const float* __restrict__ wpack,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ skip, const float* __restrict__ skip_w,
                                                          float* __restrict__ out, int Cin, int D, int H, int W, int Cout,
                                                          int Cs, int tiles_w, int tiles_h, int relu) {
-    using C = DCfg<TD, TH, CIT, CST>;
+    using C = DCfg<TD, TH, CIT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ilds = lds;                    // [CIT][ID][IH][IW]
     float* wlds = lds + C::IN_FLOATS;     // [CIT][27][32]
@@ -151,64 +149,53 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma(const float* __restrict_
 
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const size_t out_plane = (size_t)Ho * Wo;
-    if (skip != nullptr) {
+    if (HAS_SKIP) {
         // ---- 1x1x1 projection of the skip tensor at the 8 output positions of every lane ----
-        float* slds = lds;                          // [CST][2TD][2TH][64]
-        float* swl = lds + CST * C::SK_CS;          // [CST][32]
-        const float* skb = skip + (size_t)b * Cs * Do * out_plane;
-        const int lane_s = half * C::SK_CS + ((2 * dzw) * (2 * TH) + 2 * hyw) * 64 + 2 * l31;
-        // same register-prefetched staging as the main loop
-        constexpr int NSK = (CST * C::SK_CS + 255) / 256;
-        static_assert(NSK <= 32 && CST * 32 <= 256, "skip staging plan");
-        unsigned soff[NSK], smask = 0u;
+        // No LDS: the 32x32x2 B operand is one value per lane (k = channel cs + half, n = this lane's
+        // column), so each lane reads its own 2x2x2 cube of the skip tensor straight from global memory
+        // as four float2 (a wave reads 256-byte row segments), two channel pairs per group, the next
+        // group in flight while the current one is multiplied.
+        // Buffer loads: SGPR descriptor + one 32-bit offset per lane, and out-of-range offsets (channel
+        // pairs beyond Cs) read as zero without a branch.  Lanes outside the volume read garbage into
+        // their own accumulator column only, which the epilogue never stores.
+        const size_t schan = (size_t)Do * out_plane;
+        const int jw_ = min(iw0 + l31, W - 1), jd_ = min(id0 + dzw, D - 1), jh_ = min(ih0 + hyw, H - 1);
+        const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(skip + (size_t)b * Cs * schan), 0, (int)((size_t)Cs * schan * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(skip_w), 0, Cs * Cout * 4, 0x00020000);
+        const unsigned lane_s = (unsigned)(((size_t)half * schan + (size_t)(2 * jd_) * out_plane + (size_t)(2 * jh_) * Wo + 2 * jw_) * 4);
+        const unsigned lane_w = (unsigned)((half * Cout + min(co0 + l31, Cout - 1)) * 4);
+        struct Group { float2 s[2][4]; float w[2]; };
+        auto load_group = [&](Group& g, int cs0) {
 #pragma unroll
-        for (int i = 0; i < NSK; ++i) {
-            const int e = tid + 256 * i;
-            const int wx = e % 64;
-            int r = e / 64;
-            const int hy = r % (2 * TH); r /= (2 * TH);
-            const int dz = r % (2 * TD);
-            const int cs = r / (2 * TD);
-            const int gw = 2 * iw0 + wx, gh = 2 * ih0 + hy, gd = 2 * id0 + dz;
-            const bool ok = (e < CST * C::SK_CS) && gd < Do && gh < Ho && gw < Wo;
-            soff[i] = ok ? (unsigned)((((size_t)cs * Do + gd) * out_plane + (size_t)gh * Wo + gw) * 4) : 0u;
-            smask |= (unsigned)ok << i;
-        }
-        float rsk[NSK], rsw = 0.f;
-        unsigned slive = smask;
-        auto prefetch_skip = [&](int cs0) {
-            slive = smask;
-            if (cs0 + CST > Cs) {
+            for (int cp = 0; cp < 2; ++cp) {
+                const unsigned cb = (unsigned)((size_t)(cs0 + 2 * cp) * schan * 4);
 #pragma unroll
-                for (int i = 0; i < NSK; ++i)
-                    if (cs0 + (tid + 256 * i) / C::SK_CS >= Cs) slive &= ~(1u << i);
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned qo = (unsigned)(((size_t)(q >> 1) * out_plane + (size_t)(q & 1) * Wo) * 4);
+                    g.s[cp][q] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(sres, (int)(lane_s + cb + qo), 0, 0));
+                }
+                g.w[cp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    wres, (int)(lane_w + (unsigned)((cs0 + 2 * cp) * Cout * 4)), 0, 0));
             }
-            const char* sb = reinterpret_cast<const char*>(skb + (size_t)cs0 * Do * out_plane);
-#pragma unroll
-            for (int i = 0; i < NSK; ++i) rsk[i] = *reinterpret_cast<const float*>(sb + (((slive >> i) & 1u) ? soff[i] : 0u));
-            const int co = co0 + tid % 32, cs = cs0 + tid / 32;
-            rsw = (tid < CST * 32 && cs < Cs && co < Cout) ? skip_w[(size_t)cs * Cout + co] : 0.f;
         };
-        prefetch_skip(0);
-        for (int cs0 = 0; cs0 < Cs; cs0 += CST) {
+        auto mul_group = [&](const Group& g) {
 #pragma unroll
-            for (int i = 0; i < NSK; ++i) {
-                const int e = tid + 256 * i;
-                if (e < CST * C::SK_CS) slds[e] = ((slive >> i) & 1u) ? rsk[i] : 0.f;
-            }
-            if (tid < CST * 32) swl[tid] = rsw;
-            __syncthreads();
-            if (cs0 + CST < Cs) prefetch_skip(cs0 + CST);
+            for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
-            for (int cp = 0; cp < CST / 2; ++cp) {
-                const float wv = swl[(cp * 2 + half) * 32 + l31];
-                const float* sp = slds + lane_s + cp * 2 * C::SK_CS;
-#pragma unroll
-                for (int p = 0; p < 8; ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        wv, sp[(((p >> 2) & 1) * (2 * TH) + ((p >> 1) & 1)) * 64 + (p & 1)], acc[p], 0, 0, 0);
-            }
-            __syncthreads();
+                for (int q = 0; q < 4; ++q) {
+                    acc[q * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g.w[cp], g.s[cp][q].x, acc[q * 2 + 0], 0, 0, 0);
+                    acc[q * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g.w[cp], g.s[cp][q].y, acc[q * 2 + 1], 0, 0, 0);
+                }
+        };
+        Group ga, gb;
+        load_group(ga, 0);
+#pragma unroll 1
+        for (int cs0 = 0; cs0 < Cs; cs0 += 4) {
+            load_group(gb, cs0 + 4);
+            mul_group(ga);
+            ga = gb;
         }
     }
 
@@ -233,15 +220,15 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma(const float* __restrict_
     }
 }
 
-template <int TD, int TH, int CIT, int CST>
-int launch_deconv(const float* in, const float* wpack, const float* scale, const float* shift, const float* skip,
-                  const float* skip_w, float* out, int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu,
-                  hipStream_t st) {
-    using C = DCfg<TD, TH, CIT, CST>;
+template <int TD, int TH, int CIT, bool HAS_SKIP>
+int launch_deconv_as(const float* in, const float* wpack, const float* scale, const float* shift, const float* skip,
+                     const float* skip_w, float* out, int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu,
+                     hipStream_t st) {
+    using C = DCfg<TD, TH, CIT>;
     const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, TH), tiles_d = ss::ceil_div(D, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = deconv3d_mfma<TD, TH, CIT, CST>;
+    auto kern = deconv3d_mfma<TD, TH, CIT, HAS_SKIP>;
     const size_t lds = (size_t)C::LDS_FLOATS * 4;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -251,6 +238,15 @@ int launch_deconv(const float* in, const float* wpack, const float* scale, const
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, wpack, scale, shift, skip, skip_w, out, Cin, D, H, W, Cout, Cs,
                        tiles_w, tiles_h, relu);
     return ss::check_launch();
+}
+
+template <int TD, int TH, int CIT>
+int launch_deconv(const float* in, const float* wpack, const float* scale, const float* shift, const float* skip,
+                  const float* skip_w, float* out, int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu,
+                  hipStream_t st) {
+    if (skip != nullptr)
+        return launch_deconv_as<TD, TH, CIT, true>(in, wpack, scale, shift, skip, skip_w, out, B, Cin, D, H, W, Cout, Cs, relu, st);
+    return launch_deconv_as<TD, TH, CIT, false>(in, wpack, scale, shift, skip, skip_w, out, B, Cin, D, H, W, Cout, Cs, relu, st);
 }
 
 }  // namespace
@@ -267,9 +263,11 @@ extern "C" int ss_deconv3d_fwd(const float* in, const float* wpack, const float*
     if (skip_scale != nullptr || skip_shift != nullptr) return SS_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(out) & 7) != 0) return SS_ERR_INVALID;
     if (Cout % 4 != 0) return SS_ERR_UNSUPPORTED;      // weight slabs are moved as float4
+    if (skip != nullptr && (size_t)(Cs + 10) * 8 * D * H * W * 4 >= ((size_t)1 << 32))
+        return SS_ERR_UNSUPPORTED;                      // the skip tensor of one pair is addressed with 32-bit offsets
     hipStream_t st = ss::as_stream(stream);
     // 2 planes x 2 rows when the volume has fewer than 4 rows (keeps the tile inside the volume)
     if (D >= 2 && H < 4)
-        return launch_deconv<2, 2, 8, 8>(in, wpack, scale, shift, skip, skip_wpack, out, B, Cin, D, H, W, Cout, Cs, relu, st);
-    return launch_deconv<1, 4, 8, 8>(in, wpack, scale, shift, skip, skip_wpack, out, B, Cin, D, H, W, Cout, Cs, relu, st);
+        return launch_deconv<2, 2, 8>(in, wpack, scale, shift, skip, skip_wpack, out, B, Cin, D, H, W, Cout, Cs, relu, st);
+    return launch_deconv<1, 4, 8>(in, wpack, scale, shift, skip, skip_wpack, out, B, Cin, D, H, W, Cout, Cs, relu, st);
 }
