@@ -30,6 +30,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
 constexpr int KSTEPS = 14;        // ceil(27 taps / 2)
+#ifndef SS_IN_STEPS
+#define SS_IN_STEPS 10            // K-steps over which the next chunk's input loads are issued
+#endif
+#ifndef SS_A_AHEAD
+#define SS_A_AHEAD 2              // K-steps between the load of a weight fragment and its MFMAs
+#endif
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {       // finite inputs
     unsigned u = __float_as_uint(x);
@@ -44,6 +50,22 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
     m = bf16_rne(r1);
     const float r2 = r1 - bf16_up(m);
     l = bf16_rne(r2);
+}
+
+// the same split for two values at once on gfx950's packed converter: v_cvt_pk_bf16_f32 (RNE) gives
+// lo16 = bf16(x0), hi16 = bf16(x1) -- exactly the LDS slot layout -- and the residuals are one v_pk_add_f32
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
+    const f32x2_t v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
 }
 
 template <int S, int NT, int TD, int TH>
@@ -89,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     const float* inb = in + (size_t)b * Cin * chan;
 
     // staging plan: this thread owns positions p = tid + 256*i of the halo tile, all 8 channels
-    unsigned poff[C::NPOS], pmask = 0u;
+    unsigned poff[C::NPOS];
 #pragma unroll
     for (int i = 0; i < C::NPOS; ++i) {
         const int p = tid + 256 * i;
@@ -99,13 +121,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
         const int dz = r / C::IH;
         const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz;
         const bool ok = (p < C::CS) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        poff[i] = ok ? (unsigned)(((size_t)gd * in_plane + (size_t)gh * W + gw) * 4) : 0u;
-        pmask |= (unsigned)ok << i;
+        // halo positions outside the volume get an offset beyond the buffer's num_records: the buffer
+        // load returns 0 for them, no select needed
+        poff[i] = ok ? (unsigned)(((size_t)gd * in_plane + (size_t)gh * W + gw) * 4) : 0x80000000u;
     }
     // input prefetch registers, flattened q = c * NPOS + i, loaded in KSTEPS slices spread over the
     // K-steps of the previous chunk so that a wait for a weight fragment never drains them all
     constexpr int NQ = 8 * C::NPOS;
-    constexpr int QS = (NQ + KSTEPS - 1) / KSTEPS;
+    // ... all of them within the first SS_IN_STEPS steps: the split phase at the end of the chunk waits
+    // for the youngest slice, which needs a few K-steps (HBM latency) to land
+    constexpr int IN_STEPS = SS_IN_STEPS;
+    constexpr int QS = (NQ + IN_STEPS - 1) / IN_STEPS;
     float rin[NQ];
     int nlive = min(8, Cin), nlive_next = 8;                 // channels that exist in the staged / prefetched chunk
     if (tid == 0) lds[3 * C::CS] = make_uint4(0u, 0u, 0u, 0u);
@@ -128,12 +154,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, 0));
     };
     const int G = ((Cin + 7) / 8) * KSTEPS;
-    uint4 aq[3][NC];                                           // aq[s % 3] = fragments of step s of the chunk
+    // Ring of weight fragments, AP steps ahead: vmcnt retires in order, so a wait for a fragment also
+    // waits for every input (HBM) load issued before it -- the distance must cover HBM latency, not L2's.
+    constexpr int AP = SS_A_AHEAD, AR = AP + 1;
+    uint4 aq[AR][NC];                                          // aq[s % AR] = fragments of step s of the chunk
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        aq[0][c] = load_a(0, c);
-        aq[1][c] = load_a(1, c);
-    }
+    for (int k = 0; k < AP; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aq[k][c] = load_a(min(k, G - 1), c);
     {   // first chunk: plain load of every slice
 #pragma unroll
         for (int q = 0; q < NQ; ++q) rin[q] = load_in(min(q / C::NPOS, nlive - 1), q % C::NPOS);
@@ -141,19 +169,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 
     for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
         // ---- split + transpose: registers -> [term][position][8 ch] ----
+        // (SS_ABL_*: timing ablations built by tools/ablate_conv.sh only -- results are wrong with them)
+#ifndef SS_ABL_SPLIT
 #pragma unroll
         for (int i = 0; i < C::NPOS; ++i) {
             const int p = tid + 256 * i;
             if (p >= C::CS) continue;
-            unsigned hh[8], mm[8], ll[8];
-            const bool ok = (pmask >> i) & 1u;
+            unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) split3((ok && c < nlive) ? rin[c * C::NPOS + i] : 0.f, hh[c], mm[c], ll[c]);
-            lds[0 * C::CS + p] = make_uint4(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16));
-            lds[1 * C::CS + p] = make_uint4(mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16));
-            if (NC == 3)
-                lds[2 * C::CS + p] = make_uint4(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16));
+            for (int c = 0; c < 4; ++c)
+                split3_pk((2 * c < nlive) ? rin[(2 * c) * C::NPOS + i] : 0.f,
+                          (2 * c + 1 < nlive) ? rin[(2 * c + 1) * C::NPOS + i] : 0.f, hh[c], mm[c], ll[c]);
+            lds[0 * C::CS + p] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            lds[1 * C::CS + p] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+            if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
         }
+#endif
         __syncthreads();
         const bool more = ci0 + 8 < Cin;
         nlive_next = min(8, Cin - ci0 - 8);
@@ -172,22 +203,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             // weight fragments two steps ahead, then this step's slice of the next chunk's input
-            if (g0 + s + 2 < G) {
+#ifndef SS_ABL_A
+            if (g0 + s + AP < G) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) aq[(s + 2) % 3][c] = load_a(g0 + s + 2, c);
+                for (int c = 0; c < NC; ++c) aq[(s + AP) % AR][c] = load_a(g0 + s + AP, c);
             }
+#endif
+#ifndef SS_ABL_IN
             if (more) {
 #pragma unroll
                 for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q)
                     rin[q] = load_in(ci0 + 8 + min(q / C::NPOS, nlive_next - 1), q % C::NPOS);
             }
+#endif
             bf16x8 a[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) a[c] = __builtin_bit_cast(bf16x8, aq[s % 3][c]);
+            for (int c = 0; c < NC; ++c) a[c] = __builtin_bit_cast(bf16x8, aq[s % AR][c]);
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
+#ifndef SS_ABL_B
                 if (i + 1 < NT) read_b(bnxt, s, i + 1);
                 else if (s + 1 < KSTEPS) read_b(bnxt, s + 1, 0);
+#else
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bnxt[c] = bcur[c];
+#endif
                 bf16x8 bq[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) bq[c] = __builtin_bit_cast(bf16x8, bcur[c]);
@@ -204,9 +244,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
             }
             __builtin_amdgcn_sched_barrier(0);     // keep each step's loads inside the step
         }
-        // steps 14, 15 of this chunk are steps 0, 1 of the next: re-base the fragment ring
+        // steps 14 .. 14+AP-1 of this chunk are steps 0 .. AP-1 of the next: re-base the fragment ring
+        {
+            uint4 tq[AP][NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const uint4 t0 = aq[0][c]; aq[0][c] = aq[KSTEPS % 3][c]; aq[1][c] = t0; }
+            for (int k = 0; k < AP; ++k)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) tq[k][c] = aq[(KSTEPS + k) % AR][c];
+#pragma unroll
+            for (int k = 0; k < AP; ++k)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) aq[k][c] = tq[k][c];
+        }
         nlive = nlive_next;
         __syncthreads();
     }

@@ -118,12 +118,15 @@ def stack_input(name):
 SEGMENT = {
     "s128": (1, 128, 128, 64),
     "s96x160_b2": (2, 96, 160, 64),
+    "s256_md128": (1, 256, 256, 128),          # the disparity range of BASELINE.json configs[1-3]: D8 = 32, D4 = 64
+    "s192x256_md192": (1, 192, 256, 192),      # ... of configs[4]: D8 = 48, D4 = 96; H/32 = 6 pads the attention windows
 }
+_SEGMENT_SEED = {"s128": 800, "s96x160_b2": 804, "s256_md128": 808, "s192x256_md192": 812}
 
 
 def segment_inputs(name):
     B, H, W, maxdisp = SEGMENT[name]
-    s = 800 + sorted(SEGMENT).index(name) * 4
+    s = _SEGMENT_SEED[name]
     fl8, fr8 = dd.stereo_features(B, 256, H // 8, W // 8, s, max_shift=3)
     fl4, fr4 = dd.stereo_features(B, 128, H // 4, W // 4, s + 1, max_shift=6)
     return fl4, fr4, fl8, fr8, maxdisp

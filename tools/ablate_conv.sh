@@ -1,0 +1,16 @@
+#!/bin/bash
+# Timing ablations of the split-bf16 conv: rebuilds conv3d_bf16s.hip with one pipeline stage removed
+# (results are WRONG, only the time is meaningful) into tools/_build/lib_abl_*.so.
+# usage: tools/ablate_conv.sh   (then on the GPU: SS_TOOL_LIB=tools/_build/lib_abl_X.so python tools/run_conv.py)
+set -e
+cd "$(dirname "$0")/../semstereo_amd/csrc"
+make -s -j8
+OUT=../../tools/_build
+mkdir -p $OUT
+for v in SPLIT A IN B "SPLIT -DSS_ABL_IN" "SPLIT -DSS_ABL_IN -DSS_ABL_A" "SPLIT -DSS_ABL_IN -DSS_ABL_A -DSS_ABL_B"; do
+  name=$(echo "$v" | sed 's/ -DSS_ABL_/_/g')
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSS_ABL_$v -c conv3d_bf16s.hip -o /tmp/abl_$name.o
+  objs=$(ls *.o | grep -v conv3d_bf16s.o)
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_abl_$name.so /tmp/abl_$name.o $objs
+  echo built $OUT/lib_abl_$name.so
+done

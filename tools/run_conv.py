@@ -7,6 +7,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from semstereo_amd import _lib  # noqa: E402
+if os.environ.get("SS_TOOL_LIB"):          # ablation builds of the library (tools/ablate_conv.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["SS_TOOL_LIB"])
 from semstereo_amd import modules as M  # noqa: E402
 
 engine = sys.argv[1] if len(sys.argv) > 1 else "bf16x6"
@@ -22,9 +25,12 @@ if engine == "f32":
 else:
     ws = M.pack_conv_weight_bf16s(w)
     fn = lambda: M.conv3d_bf16s_hip(x, ws, 32, sc, sh, True, 6 if engine == "bf16x6" else 3)
-for _ in range(3):
-    fn()
-torch.cuda.synchronize()
+import time  # noqa: E402
+t0 = time.time()
+while time.time() - t0 < 0.4:           # warm clocks: a cold chip measures ~20 % slower
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(iters):
@@ -33,4 +39,7 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 gf = 2.0 * B * 32 * 64 * 27 * 24 * 256 * 256 / 1e9
+if engine != "f32" and os.environ.get("SS_TOOL_CHECK"):
+    ref = M.conv3d_hip(x, M.pack_conv_weight(w), sc, sh, 3, 1, True)
+    print(f"max |bf16s - f32 engine| = {(fn() - ref).abs().max().item():.2e}  ", end="")
 print(f"concat_stem conv [{engine}] B={B}: {ms*1e3:.1f} us/launch, {gf:.1f} GFLOP, {gf/ms:.1f} TFLOP/s fp32-equivalent")
