@@ -171,6 +171,14 @@ int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const float* scale,
 /* Conv3d weight [Cout,Cin,3,3,3] fp32 -> split/packed bf16 fragments
  * [ceil(Cin/8)][14 tap pairs][3 terms][2 halves][Cout][8] (ceil(Cin/8)*14*3*2*Cout*16 bytes). */
 int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
+/* The single-output-channel classifier heads, nn.Conv3d(C, 1, 3, padding=1, bias=False)
+ * (models/SemStereo.py:228-234, classif.2 / classif_att_.2), on the split-bf16 engine with the 27 taps as
+ * the matrix rows:  out [B,1,D,H,W] = relu?(scale[0] * conv(in [B,Cin,D,H,W]) + shift[0]);
+ * Cin in {16, 32, 64}; wsplit from ss_pack_conv3d_head_weights_bf16s ((Cin/16)*3*2*32*16 bytes). */
+int ss_conv3d_head_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                             float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
+                             ss_stream_t stream);
+int ss_pack_conv3d_head_weights_bf16s(const float* w, void* wsplit, int Cin, ss_stream_t stream);
 
 /* ConvTranspose3d(k3, s2, p1, output_padding 1, bias=False) [+BN] fused with the 1x1x1 skip
  * projection of hourglass.forward (models/SemStereo.py:141-142):

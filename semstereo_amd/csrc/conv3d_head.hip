@@ -1,0 +1,233 @@
+// 3x3x3 Conv3d with ONE output channel (the classifier heads classif.2 / classif_att_.2, reference
+// models/SemStereo.py:228-234: nn.Conv3d(32, 1, 3, padding=1, bias=False)) on the bf16 matrix core with
+// split-bf16 fp32 emulation (see conv3d_bf16s.hip for the arithmetic).
+//
+// A single output channel wastes 31/32 of an M = 32 tile, so the roles are turned around: the 27 TAPS are
+// the M rows.  For one input row (d', h') of 32 consecutive columns
+//
+//     P[tap][x] = sum_c  w[c, tap] * in[c, d', h', x]            (M = 27 taps, N = 32 columns, K = Cin)
+//
+// is two K-steps of v_mfma_f32_32x32x16_bf16 per 16 channels, with the weights resident in registers
+// and the B operand read straight from global memory (lane n holds 8 channels of column n: no LDS
+// staging at all).  The output is the shifted sum  out[d, h, x] = sum_{kd,kh,kw} P[(kd,kh,kw)][d+kd-1,
+// h+kh-1, x+kw-1]:  the kw part is a +-1 lane shift of accumulator registers (DPP wave_shr/wave_shl;
+// taps are assigned to accumulator rows so that the three kw taps of a (kd,kh) group sit in the same
+// lane half), which leaves 9 partial rows S[(kd,kh)][d', h'][x] per input row.  Those go to LDS, and a
+// second phase adds the 9 of every output position in a fixed order (deterministic).  A workgroup owns
+// TD x TH x 30 outputs; the 32-lane tile carries one halo column on each side.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+
+constexpr int TWO = 30;           // output columns per tile (32 lanes - 2 halo columns)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {       // lo16 = bf16(x0), hi16 = bf16(x1), RNE
+    const f32x2_t v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ float from_lane_below(float v) {   // lane n <- lane n-1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float v) {   // lane n <- lane n+1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// accumulator row (MFMA M index) -> tap, or -1.  Row i lives in register (i&3) + 4*(i>>3) of the lanes of
+// half (i>>2)&1; lane half 0 carries the (kd,kh) groups 0-4 in registers 3g+kw, half 1 the groups 5-8.
+__host__ __device__ inline int head_row_tap(int i) {
+    const int half = (i >> 2) & 1, reg = (i & 3) + 4 * (i >> 3);
+    if (half == 0) return reg < 15 ? (reg / 3) * 3 + reg % 3 : -1;
+    return reg < 12 ? (5 + reg / 3) * 3 + reg % 3 : -1;
+}
+
+template <int TD, int TH, int KS, int NTERMS>     // KS = Cin / 16
+__global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             float* __restrict__ out, int D, int H, int W, int tiles_w,
+                                                             int tiles_h, int relu) {
+    constexpr int NC = (NTERMS == 6) ? 3 : 2;
+    constexpr int IH = TH + 2, NR = (TD + 2) * IH, Cin = KS * 16;
+    extern __shared__ __attribute__((aligned(16))) float S[];     // [9][NR][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    int t = blockIdx.x;
+    const int tw = t % tiles_w; t /= tiles_w;
+    const int th = t % tiles_h; t /= tiles_h;
+    const int w0 = tw * TWO, h0 = th * TH, d0 = t * TD;
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W, chan = (size_t)D * plane;
+
+    bf16x8 a[KS][NC];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) a[ks][c] = __builtin_bit_cast(bf16x8, wsplit[((ks * 3 + c) * 2 + half) * 32 + l31]);
+
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in + (size_t)b * Cin * chan), 0, (int)min((long long)Cin * (long long)chan * 4, 0x7fffffffLL), 0x00020000);
+    const int chan_b = (int)(chan * 4);
+    const int gw = w0 - 1 + l31;
+    const bool col_ok = (unsigned)gw < (unsigned)W;
+    // lane part of the offset: this lane's 8-channel block and column (beyond the buffer when outside the row)
+    const unsigned lane_off = col_ok ? (unsigned)((size_t)(8 * half) * chan * 4 + (size_t)gw * 4) : 0x80000000u;
+
+    float xn[KS][8];
+    auto row_valid = [&](int r) {
+        const int gd = d0 - 1 + r / IH, gh = h0 - 1 + r % IH;
+        return (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+    };
+    auto load_row = [&](int r) {
+        const int gd = d0 - 1 + r / IH, gh = h0 - 1 + r % IH;
+        const unsigned ro = (unsigned)(((size_t)gd * H + gh) * W * 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xn[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    ires, (int)(lane_off + ro), (ks * 16 + j) * chan_b, 0));
+    };
+
+    if (wave < NR && row_valid(wave)) load_row(wave);
+#pragma unroll 1
+    for (int r = wave; r < NR; r += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        const bool valid = row_valid(r);                 // wave-uniform
+        if (valid) {
+            unsigned bh[KS][4], bm[KS][4], bl[KS][4];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split3_pk(xn[ks][2 * j], xn[ks][2 * j + 1], bh[ks][j], bm[ks][j], bl[ks][j]);
+            if (r + 4 < NR && row_valid(r + 4)) load_row(r + 4);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[ks][0], bh[ks][1], bh[ks][2], bh[ks][3]));
+                const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[ks][0], bm[ks][1], bm[ks][2], bm[ks][3]));
+                if (NTERMS == 6) {
+                    const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[ks][0], bl[ks][1], bl[ks][2], bl[ks][3]));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], m8, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], l8, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][NC - 1], h8, acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], m8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], h8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], h8, acc, 0, 0, 0);
+            }
+        } else if (r + 4 < NR && row_valid(r + 4)) {
+            load_row(r + 4);
+        }
+        // kw = 0 comes from the column to the left, kw = 2 from the column to the right
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const float s = ss::add_rn(ss::add_rn(from_lane_below(acc[3 * q]), acc[3 * q + 1]), from_lane_above(acc[3 * q + 2]));
+            if (half == 0 || q < 4) S[((half ? 5 + q : q) * NR + r) * 32 + l31] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: out[d,h,x] = sum over the 9 (kd,kh) partial rows, fixed order ----
+    const float sc = scale ? scale[0] : 1.0f, sh = shift ? shift[0] : 0.0f;
+    float* ob = out + (size_t)b * chan;
+#pragma unroll
+    for (int i = 0; i < TD * TH * 32 / 256; ++i) {
+        const int o = tid + 256 * i;
+        const int n = o & 31, hh = (o >> 5) % TH, dd = (o >> 5) / TH;
+        const int ow = w0 - 1 + n, oh = h0 + hh, od = d0 + dd;
+        if (n < 1 || n > TWO || ow >= W || oh >= H || od >= D) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 9; ++g) v = ss::add_rn(v, S[(g * NR + (dd + g / 3) * IH + hh + g % 3) * 32 + n]);
+        v = ss::add_rn(ss::mul_rn(v, sc), sh);
+        if (relu) v = fmaxf(v, 0.f);
+        ob[(size_t)od * plane + (size_t)oh * W + ow] = v;
+    }
+}
+
+// [1,Cin,3,3,3] fp32 -> [Cin/16][3 terms][2 k-halves][32 rows][8] bf16 (rows = taps in accumulator-row order)
+__global__ void pack_head_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit, int Cin, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = i % 8;
+    int r = i / 8;
+    const int row = r % 32; r /= 32;
+    const int hk = r % 2; r /= 2;
+    const int term = r % 3;
+    const int ks = r / 3;
+    const int tap = head_row_tap(row), c = ks * 16 + 8 * hk + j;
+    const float x = (tap >= 0 && c < Cin) ? w[(size_t)c * 27 + tap] : 0.f;
+    unsigned h, m, l;
+    split3_pk(x, 0.f, h, m, l);
+    wsplit[i] = (unsigned short)((term == 0 ? h : (term == 1 ? m : l)) & 0xffffu);
+}
+
+template <int TD, int TH, int KS, int NTERMS>
+int launch_head(const float* in, const void* wsplit, const float* scale, const float* shift, float* out, int B, int D,
+                int H, int W, int relu, hipStream_t st) {
+    const int tiles_w = ss::ceil_div(W, TWO), tiles_h = ss::ceil_div(H, TH), tiles_d = ss::ceil_div(D, TD);
+    const long long nt = (long long)tiles_w * tiles_h * tiles_d;
+    if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
+    auto kern = conv3d_head_bf16s<TD, TH, KS, NTERMS>;
+    const size_t lds = (size_t)9 * (TD + 2) * (TH + 2) * 32 * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nt, B), dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
+                       out, D, H, W, tiles_w, tiles_h, relu);
+    return ss::check_launch();
+}
+
+template <int KS, int NTERMS>
+int launch_head_tile(const float* in, const void* wsplit, const float* scale, const float* shift, float* out, int B, int D,
+                     int H, int W, int relu, hipStream_t st) {
+    // 4 planes x 8 rows per workgroup unless that leaves the chip short of workgroups (small volumes)
+    const long long big = (long long)ss::ceil_div(W, TWO) * ss::ceil_div(H, 8) * ss::ceil_div(D, 4) * B;
+    if (big >= 1024 && D >= 4)
+        return launch_head<4, 8, KS, NTERMS>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
+    return launch_head<2, 8, KS, NTERMS>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
+}
+
+}  // namespace
+
+extern "C" int ss_pack_conv3d_head_weights_bf16s(const float* w, void* wsplit, int Cin, ss_stream_t stream) {
+    SS_REQUIRE(w && wsplit && Cin > 0 && Cin % 16 == 0);
+    const int total = (Cin / 16) * 3 * 2 * 32 * 8;
+    hipLaunchKernelGGL(pack_head_weights_kernel, dim3(ss::ceil_div(total, 256)), dim3(256), 0, ss::as_stream(stream), w,
+                       reinterpret_cast<unsigned short*>(wsplit), Cin, total);
+    return ss::check_launch();
+}
+
+extern "C" int ss_conv3d_head_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                        float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
+                                        ss_stream_t stream) {
+    SS_REQUIRE(in && wsplit && out);
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
+    if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;     // 32-bit buffer offsets per pair
+    hipStream_t st = ss::as_stream(stream);
+#define SS_HEAD(KSV)                                                                                                  \
+    if (Cin == 16 * KSV)                                                                                              \
+        return nterms == 6 ? launch_head_tile<KSV, 6>(in, wsplit, scale, shift, out, B, D, H, W, relu, st)            \
+                           : launch_head_tile<KSV, 3>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
+    SS_HEAD(1)
+    SS_HEAD(2)
+    SS_HEAD(4)
+#undef SS_HEAD
+    return SS_ERR_UNSUPPORTED;
+}

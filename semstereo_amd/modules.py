@@ -161,6 +161,30 @@ def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None,
     return out
 
 
+def pack_head_weight_bf16s(w):
+    """[1,Cin,3,3,3] fp32 -> split-bf16 fragments (taps as matrix rows) for ss_conv3d_head_bf16s_fwd."""
+    w = w.detach().float().contiguous()
+    _lib.require_device(w)
+    Cin = w.shape[1]
+    assert w.shape[0] == 1 and tuple(w.shape[2:]) == (3, 3, 3) and Cin % 16 == 0
+    out = torch.empty((Cin // 16) * 3 * 2 * 32 * 8, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        call("ss_pack_conv3d_head_weights_bf16s", ptr(w), ptr(out), Cin)
+    return out
+
+
+def conv3d_head_bf16s_hip(x, wsplit, scale, shift, relu, nterms):
+    """Conv3d(C, 1, 3, padding=1) + affine (+ReLU) on the split-bf16 engine (conv3d_head.hip)."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, scale, shift)
+    B, Cin, D, H, W = x.shape
+    out = torch.empty((B, 1, D, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(dev):
+        call("ss_conv3d_head_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(out), B, Cin, D, H, W,
+             int(relu), int(nterms))
+    return out
+
+
 def _convbn_params(owner, key, conv, bn):
     """(wpack, scale, shift) of a Conv3d(+BN) pair, cached on `owner`."""
     srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
@@ -193,6 +217,16 @@ def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
             return pack_conv_weight_bf16s(conv.weight), sc, sh
         ws, scale, shift = _cache(owner).get(key + "/bf16s", srcs, build)
         return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual, gate)
+    if (CONV_ENGINE != "f32" and k == 3 and s == 1 and conv.out_channels == 1 and conv.in_channels in (16, 32, 64)
+            and residual is None and gate is None):
+        nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+        srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+        def build_head():
+            sc, sh = fold_bn(bn) if bn is not None else (None, None)
+            return pack_head_weight_bf16s(conv.weight), sc, sh
+        ws, scale, shift = _cache(owner).get(key + "/head_bf16s", srcs, build_head)
+        return conv3d_head_bf16s_hip(x, ws, scale, shift, relu, nterms)
     wp, scale, shift = _convbn_params(owner, key, conv, bn)
     return conv3d_hip(x, wp, scale, shift, k, s, relu, residual, gate)
 

@@ -363,6 +363,43 @@ def test_conv3d_fused_channel_gate(sa, engine):
     check(f"conv3d_gate/{engine}", y, ref, 2e-5)
 
 
+HEAD_CASES = [
+    # (B, Cin, D, H, W, relu): the 32 -> 1 classifier heads; W not a multiple of 30, both tile shapes, tiny volumes
+    (2, 32, 5, 9, 37, False),
+    (1, 32, 9, 70, 95, False),         # >= 1024 tiles of 4x8x30 -> the 4-plane tile
+    (1, 16, 1, 1, 1, True),
+    (1, 64, 3, 8, 31, False),
+    (1, 32, 2, 3, 30, True),
+]
+
+
+@pytest.mark.parametrize("nterms", [6, 3])
+@pytest.mark.parametrize("case", HEAD_CASES)
+def test_conv3d_head_split_bf16(sa, case, nterms):
+    """classif.2 / classif_att_.2 (models/SemStereo.py:228-234) with the taps as matrix rows: as close to the
+    float64 result as the exact-fp32 kernel (6 products), within 4e-5 absolute (3 products)."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, Cin, D, H, W, relu = case
+    x = dd.t_normalish((B, Cin, D, H, W), 281)
+    w = dd.t_uniform((1, Cin, 3, 3, 3), 282, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    scale, shift = dd.t_uniform((1,), 283, 0.5, 1.5), dd.t_uniform((1,), 284, -0.2, 0.2)
+    ref = F.conv3d(x.double(), w.double(), None, 1, 1) * scale.double() + shift.double()
+    if relu:
+        ref = F.relu(ref)
+    y = sa.modules.conv3d_head_bf16s_hip(dev(x), sa.modules.pack_head_weight_bf16s(dev(w)), dev(scale), dev(shift), relu, nterms)
+    y32 = sa.modules.conv3d_hip(dev(x), sa.modules.pack_conv_weight(dev(w)), dev(scale), dev(shift), 3, 1, relu)
+    e_split = float((y.double().cpu() - ref).abs().max())
+    e_f32 = float((y32.double().cpu() - ref).abs().max())
+    REPORT[f"conv3d_head_bf16x{nterms}/{case}"] = e_split
+    REPORT[f"conv3d_head_f32_vs_f64/{case}"] = e_f32
+    tol = 1.5 * e_f32 + 1e-6 if nterms == 6 else 4e-5        # 3 products: ~1e-5 relative, absolute bound on O(1) outputs
+    assert e_split <= tol, (e_split, e_f32)
+    yn = sa.modules.conv3d_head_bf16s_hip(dev(x), sa.modules.pack_head_weight_bf16s(dev(w)), None, None, False, nterms)
+    refn = F.conv3d(x.double(), w.double(), None, 1, 1)
+    assert float((yn.double().cpu() - refn).abs().max()) <= (4e-6 if nterms == 6 else 4e-5)
+
+
 BF16S_CASES = [
     # (Cin, Cout, D, H, W, relu, residual)
     (32, 32, 5, 9, 37, True, False),
