@@ -179,6 +179,15 @@ int ss_conv3d_head_bf16s_fwd(const float* in, const void* wsplit, const float* s
                              float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
                              ss_stream_t stream);
 int ss_pack_conv3d_head_weights_bf16s(const float* w, void* wsplit, int Cin, ss_stream_t stream);
+/* 1x1x1 Conv3d / per-position Linear (+ per-channel affine: bias; ReLU) on the split-bf16 engine:
+ * qkv_3d and final1x1 of attention_block (models/submodule_other.py:804, 835).
+ *   out [B,Cout,npos] = relu?(scale * (W in) + shift), in [B,Cin,npos], npos = D*H*W, W [Cout,Cin];
+ * Cin in {32, 64, 128}; wsplit from ss_pack_pointwise_weights_bf16s
+ * (ceil(Cout/32)*(Cin/16)*3*2*32*16 bytes). */
+int ss_conv3d_pointwise_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                  float* out, int B, int Cin, int Cout, long long npos, int relu, int nterms,
+                                  ss_stream_t stream);
+int ss_pack_pointwise_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
 
 /* ConvTranspose3d(k3, s2, p1, output_padding 1, bias=False) [+BN] fused with the 1x1x1 skip
  * projection of hourglass.forward (models/SemStereo.py:141-142):
@@ -208,6 +217,13 @@ int ss_window_attention_fwd(const float* x, const float* wqkv_t, const float* bq
                             const float* wout_t, const float* bout, float* out,
                             int B, int C, int D, int H, int W, int heads, int bd, int bh, int bw,
                             ss_stream_t stream);
+/* The attention core alone, for the three-launch form of the same block: qkv [B,3C,D,H,W] is the
+ * qkv_3d projection (+bias) of the UNPADDED volume (a 1x1x1 ss_conv3d_fwd), bqkv [3C] the value a
+ * zero-padded token projects to; y [B,C,D,H,W] = softmax(q k^T / sqrt(hd) [+ pad mask]) v per window and
+ * head, un-partitioned and cropped (models/submodule_other.py:805-834); final1x1 is another
+ * ss_conv3d_fwd.  One workgroup per (window, 4 heads). */
+int ss_window_attention_core_fwd(const float* qkv, const float* bqkv, float* y, int B, int C, int D, int H,
+                                 int W, int heads, int bd, int bh, int bw, ss_stream_t stream);
 
 #ifdef __cplusplus
 }

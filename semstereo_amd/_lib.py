@@ -40,10 +40,13 @@ _SIGNATURES = {
     "ss_pack_conv3d_weights_bf16s": [_P, _P, _I, _I, _P],
     "ss_conv3d_head_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_head_weights_bf16s": [_P, _P, _I, _P],
+    "ss_conv3d_pointwise_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_longlong, _I, _I, _P],
+    "ss_pack_pointwise_weights_bf16s": [_P, _P, _I, _I, _P],
     "ss_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_weights": [_P, _P, _I, _I, _I, _I, _P],
     "ss_depthwise_patch_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_window_attention_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 EXPORTS = sorted(list(_SIGNATURES) + ["ss_abi_version", "ss_status_string", "ss_last_hip_error", "ss_ssr_param_count"])
 

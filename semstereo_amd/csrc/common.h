@@ -30,6 +30,16 @@ __host__ __device__ inline long long ceil_div_ll(long long a, long long b) { ret
 // before reducing; keeping the two roundings makes several kernels bit-identical to it).
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+// exp(x) for finite x <= ~88 to ~1.5 ulp in 6 VALU ops: 2^(x*log2e) on the hardware exp2 (v_exp_f32, 1 ulp),
+// with the rounding error of the product and the low bits of log2(e) carried as a first-order correction
+// (a plain __expf loses |x| * 6e-8 relative there).  Not for x = -inf (use expf).
+__device__ __forceinline__ float exp_fast(float x) {
+    const float L = 1.44269502162933349609375f, Llo = 1.925962991126617e-8f;    // log2(e) = L + Llo
+    const float t = __fmul_rn(x, L);
+    const float e = __fmaf_rn(x, L, -t) + x * Llo;
+    const float p = __builtin_amdgcn_exp2f(t);
+    return __fmaf_rn(p, e * 0.693147180559945f, p);
+}
 
 }  // namespace ss
 

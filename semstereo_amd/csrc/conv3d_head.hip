@@ -85,59 +85,76 @@ __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restr
     // lane part of the offset: this lane's 8-channel block and column (beyond the buffer when outside the row)
     const unsigned lane_off = col_ok ? (unsigned)((size_t)(8 * half) * chan * 4 + (size_t)gw * 4) : 0x80000000u;
 
-    float xn[KS][8];
+    // This wave's input rows r = wave + 4*i, in groups of GR: the loads of a whole group (GR x KS x 8 per lane)
+    // are in flight while the previous group is multiplied -- one row ahead does not cover HBM latency with
+    // only two waves per SIMD.
+    constexpr int NRW = NR / 4, GR = (KS <= 2) ? 5 : 2, NG = (NRW + GR - 1) / GR;
+    static_assert(NR % 4 == 0, "rows split evenly over the 4 waves");
     auto row_valid = [&](int r) {
         const int gd = d0 - 1 + r / IH, gh = h0 - 1 + r % IH;
         return (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
     };
-    auto load_row = [&](int r) {
-        const int gd = d0 - 1 + r / IH, gh = h0 - 1 + r % IH;
-        const unsigned ro = (unsigned)(((size_t)gd * H + gh) * W * 4);
+    auto load_group = [&](float (&xg)[GR][KS][8], int gi) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                xn[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    ires, (int)(lane_off + ro), (ks * 16 + j) * chan_b, 0));
-    };
-
-    if (wave < NR && row_valid(wave)) load_row(wave);
-#pragma unroll 1
-    for (int r = wave; r < NR; r += 4) {
-        f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-        const bool valid = row_valid(r);                 // wave-uniform
-        if (valid) {
-            unsigned bh[KS][4], bm[KS][4], bl[KS][4];
+        for (int k = 0; k < GR; ++k) {
+            const int i = gi * GR + k;
+            if (i >= NRW) continue;
+            const int r = wave + 4 * i;
+            if (!row_valid(r)) continue;                 // wave-uniform
+            const int gd = d0 - 1 + r / IH, gh = h0 - 1 + r % IH;
+            const unsigned ro = (unsigned)(((size_t)gd * H + gh) * W * 4);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) split3_pk(xn[ks][2 * j], xn[ks][2 * j + 1], bh[ks][j], bm[ks][j], bl[ks][j]);
-            if (r + 4 < NR && row_valid(r + 4)) load_row(r + 4);
+                for (int j = 0; j < 8; ++j)
+                    xg[k][ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        ires, (int)(lane_off + ro), (ks * 16 + j) * chan_b, 0));
+        }
+    };
+    auto process_group = [&](float (&xg)[GR][KS][8], int gi) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[ks][0], bh[ks][1], bh[ks][2], bh[ks][3]));
-                const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[ks][0], bm[ks][1], bm[ks][2], bm[ks][3]));
-                if (NTERMS == 6) {
-                    const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[ks][0], bl[ks][1], bl[ks][2], bl[ks][3]));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], m8, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], l8, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][NC - 1], h8, acc, 0, 0, 0);
+        for (int k = 0; k < GR; ++k) {
+            const int i = gi * GR + k;
+            if (i >= NRW) continue;
+            const int r = wave + 4 * i;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            if (row_valid(r)) {                          // rows outside the volume contribute zeros
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) split3_pk(xg[k][ks][2 * j], xg[k][ks][2 * j + 1], bh[j], bm[j], bl[j]);
+                    const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                    const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+                    if (NTERMS == 6) {
+                        const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], m8, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], l8, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][NC - 1], h8, acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], m8, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], h8, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], h8, acc, 0, 0, 0);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], m8, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], h8, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], h8, acc, 0, 0, 0);
             }
-        } else if (r + 4 < NR && row_valid(r + 4)) {
-            load_row(r + 4);
-        }
-        // kw = 0 comes from the column to the left, kw = 2 from the column to the right
+            // kw = 0 comes from the column to the left, kw = 2 from the column to the right
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const float s = ss::add_rn(ss::add_rn(from_lane_below(acc[3 * q]), acc[3 * q + 1]), from_lane_above(acc[3 * q + 2]));
-            if (half == 0 || q < 4) S[((half ? 5 + q : q) * NR + r) * 32 + l31] = s;
+            for (int q = 0; q < 5; ++q) {
+                const float sv = ss::add_rn(ss::add_rn(from_lane_below(acc[3 * q]), acc[3 * q + 1]), from_lane_above(acc[3 * q + 2]));
+                if (half == 0 || q < 4) S[((half ? 5 + q : q) * NR + r) * 32 + l31] = sv;
+            }
         }
+    };
+    float xa[GR][KS][8], xb[GR][KS][8];
+    load_group(xa, 0);
+#pragma unroll
+    for (int gi = 0; gi < NG; gi += 2) {
+        if (gi + 1 < NG) load_group(xb, gi + 1);
+        process_group(xa, gi);
+        if (gi + 2 < NG) load_group(xa, gi + 2);
+        if (gi + 1 < NG) process_group(xb, gi + 1);
     }
     __syncthreads();
 
@@ -229,5 +246,162 @@ extern "C" int ss_conv3d_head_bf16s_fwd(const float* in, const void* wsplit, con
     SS_HEAD(2)
     SS_HEAD(4)
 #undef SS_HEAD
+    return SS_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1x1x1 Conv3d / Linear over channels (+ per-channel affine = bias, ReLU) on the same split-bf16
+// arithmetic: qkv_3d and final1x1 of attention_block (reference models/submodule_other.py:804, 835).
+//   out[co, p] = sum_ci W[co, ci] * in[ci, p]        p = flattened (d, h, w)
+// A wave owns 32 output channels with ALL their weights resident in registers (Cin <= 128: 8 K-steps x
+// 3 terms x 4 registers) and walks over tiles of 32 consecutive positions; the activation operand is
+// read straight from global memory (lane n = position, 8 channels per lane half), split in registers.
+// No LDS, no barriers.
+namespace {
+
+template <int KS, int NTERMS>     // KS = Cin / 16
+__global__ __launch_bounds__(256, 2) void pointwise_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ out, int Cout, long long npos,
+                                                           int tiles_per_wave, int relu) {
+    constexpr int NC = (NTERMS == 6) ? 3 : 2;
+    constexpr int Cin = KS * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int mt = blockIdx.y * 4 + wave;                     // this wave's tile of 32 output channels
+    const int b = blockIdx.z;
+    if (mt * 32 >= Cout) return;
+    bf16x8 a[KS][NC];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            a[ks][c] = __builtin_bit_cast(bf16x8, wsplit[(((size_t)mt * KS + ks) * 3 + c) * 64 + half * 32 + l31]);
+
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in + (size_t)b * Cin * npos), 0, (int)min((long long)Cin * npos * 4, 0x7fffffffLL), 0x00020000);
+    const int chan_b = (int)(npos * 4);
+    float* ob = out + (size_t)b * Cout * npos;
+    const long long t0 = (long long)blockIdx.x * tiles_per_wave;
+    float x[KS][8];
+    auto lane_offset = [&](long long tile) {
+        const long long p = tile * 32 + l31;
+        // positions beyond the volume get an offset beyond the buffer -> zeros
+        return (p < npos) ? (unsigned)((8LL * half * npos + p) * 4) : 0x80000000u;
+    };
+    auto load_step = [&](unsigned off, int ks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            x[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)off, (ks * 16 + j) * chan_b, 0));
+    };
+    {
+        const unsigned off0 = lane_offset(t0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) load_step(off0, ks);
+    }
+#pragma unroll 1
+    for (int it = 0; it < tiles_per_wave; ++it) {
+        const long long tile = t0 + it;
+        if (tile * 32 >= npos) break;
+        const bool more = it + 1 < tiles_per_wave;
+        const unsigned offn = lane_offset(tile + 1);          // beyond npos: every lane reads zeros
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            // split this K-step's 8 channels, then refill its registers with the next tile's
+            unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split3_pk(x[ks][2 * j], x[ks][2 * j + 1], bh[j], bm[j], bl[j]);
+            if (more) load_step(offn, ks);
+            const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+            if (NTERMS == 6) {
+                const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], m8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], l8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][NC - 1], h8, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], m8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], h8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], h8, acc, 0, 0, 0);
+        }
+        const long long p = tile * 32 + l31;
+        if (p < npos) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co >= Cout) continue;
+                float v = ss::add_rn(ss::mul_rn(acc[r], scale ? scale[co] : 1.0f), shift ? shift[co] : 0.0f);
+                if (relu) v = fmaxf(v, 0.f);
+                ob[(size_t)co * npos + p] = v;
+            }
+        }
+    }
+}
+
+// [Cout,Cin] fp32 -> [ceil(Cout/32)][Cin/16][3 terms][2 k-halves][32 rows][8] bf16
+__global__ void pack_pointwise_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit, int Cout,
+                                              int Cin, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = i % 8;
+    int r = i / 8;
+    const int row = r % 32; r /= 32;
+    const int hk = r % 2; r /= 2;
+    const int term = r % 3; r /= 3;
+    const int KS = Cin / 16;
+    const int ks = r % KS;
+    const int mt = r / KS;
+    const int co = mt * 32 + row, c = ks * 16 + 8 * hk + j;
+    const float x = (co < Cout) ? w[(size_t)co * Cin + c] : 0.f;
+    unsigned h, m, l;
+    split3_pk(x, 0.f, h, m, l);
+    wsplit[i] = (unsigned short)((term == 0 ? h : (term == 1 ? m : l)) & 0xffffu);
+}
+
+template <int KS, int NTERMS>
+int launch_pointwise(const float* in, const void* wsplit, const float* scale, const float* shift, float* out, int B,
+                     int Cout, long long npos, int relu, hipStream_t st) {
+    const long long ntiles = (npos + 31) / 32;
+    const int mgroups = ss::ceil_div(ss::ceil_div(Cout, 32), 4);
+    // tiles of 32 positions per wave: as many as keeps >= 1024 workgroups (4 per CU), at most 8 --
+    // the weights are loaded once per wave (24 KB), so more tiles per wave amortise them better
+    int tpw = 8;
+    while (tpw > 1 && ((ntiles + tpw - 1) / tpw) * mgroups * B < 1024) tpw >>= 1;
+    const long long gx = (ntiles + tpw - 1) / tpw;
+    if (gx > 0x7fffffffLL || B > 65535 || mgroups > 65535) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((pointwise_bf16s<KS, NTERMS>), dim3((unsigned)gx, mgroups, B), dim3(256), 0, st, in,
+                       reinterpret_cast<const uint4*>(wsplit), scale, shift, out, Cout, npos, tpw, relu);
+    return ss::check_launch();
+}
+
+}  // namespace
+
+extern "C" int ss_pack_pointwise_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream) {
+    SS_REQUIRE(w && wsplit && Cout > 0 && Cin > 0 && Cin % 16 == 0);
+    const int total = ss::ceil_div(Cout, 32) * (Cin / 16) * 3 * 2 * 32 * 8;
+    hipLaunchKernelGGL(pack_pointwise_weights_kernel, dim3(ss::ceil_div(total, 256)), dim3(256), 0, ss::as_stream(stream), w,
+                       reinterpret_cast<unsigned short*>(wsplit), Cout, Cin, total);
+    return ss::check_launch();
+}
+
+extern "C" int ss_conv3d_pointwise_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                             float* out, int B, int Cin, int Cout, long long npos, int relu, int nterms,
+                                             ss_stream_t stream) {
+    SS_REQUIRE(in && wsplit && out);
+    SS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && npos > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
+    if ((long long)Cin * npos * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;     // 32-bit buffer offsets per pair
+    hipStream_t st = ss::as_stream(stream);
+#define SS_PW(KSV)                                                                                                    \
+    if (Cin == 16 * KSV)                                                                                              \
+        return nterms == 6 ? launch_pointwise<KSV, 6>(in, wsplit, scale, shift, out, B, Cout, npos, relu, st)         \
+                           : launch_pointwise<KSV, 3>(in, wsplit, scale, shift, out, B, Cout, npos, relu, st);
+    SS_PW(2)
+    SS_PW(4)
+    SS_PW(8)
+#undef SS_PW
     return SS_ERR_UNSUPPORTED;
 }

@@ -189,8 +189,9 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
 #pragma unroll
             for (int kt = 0; kt < A::NTL; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st[kt][r] = expf(st[kt][r] - mx); sum = ss::add_rn(sum, st[kt][r]); }
+                for (int r = 0; r < 16; ++r) { st[kt][r] = ss::exp_fast(st[kt][r] - mx); sum = ss::add_rn(sum, st[kt][r]); }
             sum = ss::add_rn(sum, __shfl_xor(sum, 32));
+            const float rsum = 1.0f / sum;            // one division per query; p = e * (1/sum) is within 1 ulp of e / sum
             f32x16 ot;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[r] = 0.f;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float vv = (l31 < HD) ? vrow[kt * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;
-                    ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[kt][r] / sum, ot, 0, 0, 0);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, ss::mul_rn(st[kt][r], rsum), ot, 0, 0, 0);
                 }
             // rows 0-3 of Ot sit in registers 0-3 of the lower half, rows 4-7 in those of the upper half
 #pragma unroll
@@ -241,6 +242,134 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     }
 }
 
+// The same attention, split in three launches (ss_window_attention_core_fwd below): the q/k/v projection
+// and the output projection are plain 1x1x1 convolutions over the unpadded volume (ss_conv3d_fwd, k = 1),
+// and this kernel is only softmax(q k^T) v for ONE (window, group of 4 heads): 37 KB of LDS instead of
+// 148 KB, 4x the workgroups -- a single 1024x1024 pair then fills the chip (the fused kernel above has one
+// workgroup per window: 128-256 of them, one wave per SIMD).  A padded token's q/k/v is the Linear bias
+// (the reference pads with zeros before qkv_3d, models/submodule_other.py:797-803).
+template <int T, int C>
+__global__ __launch_bounds__(256) void window_attention_core(const float* __restrict__ qkv_in, const float* __restrict__ bqkv,
+                                                              float* __restrict__ y, int D, int H, int W, int bd, int bh,
+                                                              int bw, int nwh, int nww, int use_mask) {
+    using A = ACfg<T, C>;
+    static_assert(A::TP == T, "windows of 64 / 96 tokens are whole 32-token tiles");
+    __shared__ __attribute__((aligned(16))) float qkv[3 * 32 * A::TP];     // rows 0-31 q, 32-63 k, 64-95 v of this head group
+    __shared__ float flag[A::TP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    constexpr int NGROUPS = C / (HG * HD);
+    int wi = blockIdx.x;
+    const int g = wi % NGROUPS; wi /= NGROUPS;
+    const int ww = wi % nww; wi /= nww;
+    const int wh = wi % nwh; wi /= nwh;
+    const int wd = wi;
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    const float* qb = qkv_in + (size_t)b * 3 * C * vol;
+
+    if (bw == 4 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv_in) & 15) == 0)) {
+        constexpr int NQ = 96 * (A::TP / 4) / 256;           // quads per thread (9 or 6)
+        static_assert(96 * (A::TP / 4) % 256 == 0, "whole batches");
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = tid + 256 * i;
+            const int tq = e % (A::TP / 4), row = e / (A::TP / 4);
+            const int f = (row >> 5) * C + g * 32 + (row & 31);
+            const int ih = tq % bh, id = tq / bh;
+            const int gh = wh * bh + ih, gd = wd * bd + id, gw = ww * 4;
+            const bool ok = gh < H && gw < W;
+            const float4 q = *reinterpret_cast<const float4*>(qb + (size_t)f * vol + (size_t)gd * plane +
+                                                              (size_t)min(gh, H - 1) * W + min(gw, W - 4));
+            const float bf = bqkv[f];
+            *reinterpret_cast<float4*>(&qkv[e * 4]) = ok ? q : make_float4(bf, bf, bf, bf);
+        }
+    } else {
+        for (int e = tid; e < 96 * A::TP; e += 256) {
+            const int t = e % A::TP, row = e / A::TP;
+            const int f = (row >> 5) * C + g * 32 + (row & 31);
+            const int iw = t % bw, ih = (t / bw) % bh, id = t / (bw * bh);
+            const int gw = ww * bw + iw, gh = wh * bh + ih, gd = wd * bd + id;
+            qkv[e] = (gh < H && gw < W) ? qb[(size_t)f * vol + (size_t)gd * plane + (size_t)gh * W + gw] : bqkv[f];
+        }
+    }
+    for (int t = tid; t < A::TP; t += 256) {
+        const int iw = t % bw, ih = (t / bw) % bh;
+        flag[t] = ((wh * bh + ih >= H) || (ww * bw + iw >= W)) ? 1.f : 0.f;
+    }
+    __syncthreads();
+
+    const float scale = 0.35355339059327379f;    // 8 ** -0.5
+    float* yb = y + (size_t)b * C * vol;
+    // one unit = (head hh, tile of 32 queries); see the fused kernel's phase 2 for the operand layout
+    for (int u = wave; u < HG * A::NTL; u += 4) {
+        const int hh = u / A::NTL, qt = u % A::NTL;
+        f32x16 st[A::NTL];
+#pragma unroll
+        for (int kt = 0; kt < A::NTL; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int sd = 0; sd < HD / 2; ++sd)
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    qkv[(32 + hh * HD + 2 * sd + half) * A::TP + kt * 32 + l31],     // K[dim][key]
+                    qkv[(hh * HD + 2 * sd + half) * A::TP + qt * 32 + l31],          // Q[dim][query]
+                    st[kt], 0, 0, 0);
+        }
+        const float fq = flag[qt * 32 + l31];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < A::NTL; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float d = ss::mul_rn(st[kt][r], scale);
+                if (use_mask && flag[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != fq) d = ss::add_rn(d, -1000.0f);
+                st[kt][r] = d;
+                mx = fmaxf(mx, d);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < A::NTL; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kt][r] = ss::exp_fast(st[kt][r] - mx); sum = ss::add_rn(sum, st[kt][r]); }
+        sum = ss::add_rn(sum, __shfl_xor(sum, 32));
+        const float rsum = 1.0f / sum;                // one division per query; p = e * (1/sum) is within 1 ulp of e / sum
+        f32x16 ot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+        const float* vrow = qkv + (64 + hh * HD + (l31 & 7)) * A::TP + 4 * half;     // V[dim = lane][...]
+#pragma unroll
+        for (int kt = 0; kt < A::NTL; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float vv = (l31 < HD) ? vrow[kt * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;
+                ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, ss::mul_rn(st[kt][r], rsum), ot, 0, 0, 0);
+            }
+        // rows 0-3 of Ot sit in registers 0-3 of the lower half, rows 4-7 in those of the upper half
+        const int t = qt * 32 + l31;
+        const int iw = t % bw, ih = (t / bw) % bh, id = t / (bw * bh);
+        const int gw = ww * bw + iw, gh = wh * bh + ih, gd = wd * bd + id;
+        if (gh < H && gw < W) {
+            const size_t pos = (size_t)gd * plane + (size_t)gh * W + gw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yb[(size_t)(g * 32 + hh * HD + 4 * half + r) * vol + pos] = ot[r];
+        }
+    }
+}
+
+template <int T>
+int launch_attn_core(const float* qkv, const float* bqkv, float* y, int B, int D, int H, int W, int bd, int bh, int bw,
+                     hipStream_t st) {
+    const int nwd = D / bd, nwh = ss::ceil_div(H, bh), nww = ss::ceil_div(W, bw);
+    const int use_mask = (H % bh != 0) && (W % bw != 0);      // the reference's "-0:" quirk, see launch_attn
+    const long long nblk = (long long)nwd * nwh * nww * (128 / (HG * HD));
+    if (nblk > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((window_attention_core<T, 128>), dim3((unsigned)nblk, B), dim3(256), 0, st, qkv, bqkv, y, D, H, W, bd,
+                       bh, bw, nwh, nww, use_mask);
+    return ss::check_launch();
+}
+
 template <int T>
 int launch_attn(const float* x, const float* wqkv_t, const float* bqkv, const float* wout_t, const float* bout,
                 float* out, int B, int D, int H, int W, int bd, int bh, int bw, hipStream_t st) {
@@ -275,5 +404,18 @@ extern "C" int ss_window_attention_fwd(const float* x, const float* wqkv_t, cons
     hipStream_t st = ss::as_stream(stream);
     if (T == 64) return launch_attn<64>(x, wqkv_t, bqkv, wout_t, bout, out, B, D, H, W, bd, bh, bw, st);
     if (T == 96) return launch_attn<96>(x, wqkv_t, bqkv, wout_t, bout, out, B, D, H, W, bd, bh, bw, st);
+    return SS_ERR_UNSUPPORTED;
+}
+
+extern "C" int ss_window_attention_core_fwd(const float* qkv, const float* bqkv, float* y, int B, int C, int D, int H,
+                                            int W, int heads, int bd, int bh, int bw, ss_stream_t stream) {
+    SS_REQUIRE(qkv && bqkv && y);
+    SS_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && heads > 0 && bd > 0 && bh > 0 && bw > 0);
+    SS_REQUIRE(D % bd == 0);
+    if (C != 128 || heads != 16) return SS_ERR_UNSUPPORTED;
+    const int T = bd * bh * bw;
+    hipStream_t st = ss::as_stream(stream);
+    if (T == 64) return launch_attn_core<64>(qkv, bqkv, y, B, D, H, W, bd, bh, bw, st);
+    if (T == 96) return launch_attn_core<96>(qkv, bqkv, y, B, D, H, W, bd, bh, bw, st);
     return SS_ERR_UNSUPPORTED;
 }

@@ -185,6 +185,30 @@ def conv3d_head_bf16s_hip(x, wsplit, scale, shift, relu, nterms):
     return out
 
 
+def pack_pointwise_weight_bf16s(w):
+    """[Cout,Cin] (or [Cout,Cin,1,1,1]) fp32 -> split-bf16 fragments for ss_conv3d_pointwise_bf16s_fwd."""
+    w = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
+    _lib.require_device(w)
+    Cout, Cin = w.shape
+    assert Cin % 16 == 0
+    out = torch.empty(((Cout + 31) // 32) * (Cin // 16) * 3 * 2 * 32 * 8, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        call("ss_pack_pointwise_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
+    return out
+
+
+def conv3d_pointwise_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms):
+    """1x1x1 Conv3d / Linear over channels + affine (+ReLU) on the split-bf16 engine; x [B,Cin,*spatial]."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, scale, shift)
+    B, Cin = x.shape[0], x.shape[1]
+    out = torch.empty((B, Cout) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(dev):
+        call("ss_conv3d_pointwise_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(out), B, Cin, Cout,
+             x[0, 0].numel(), int(relu), int(nterms))
+    return out
+
+
 def _convbn_params(owner, key, conv, bn):
     """(wpack, scale, shift) of a Conv3d(+BN) pair, cached on `owner`."""
     srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
@@ -302,6 +326,9 @@ class BasicConv(nn.Module):
         return x
 
 
+ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launches) | "fused" (one kernel per window)
+
+
 class attention_block(nn.Module):
     """Windowed multi-head self-attention + 1x1x1 conv; keys `qkv_3d.*`, `final1x1.*`."""
 
@@ -334,6 +361,20 @@ class attention_block(nn.Module):
                     self.final1x1.bias.detach().float().contiguous())
         return _cache(self).get("attn", srcs, build)
 
+    def _params_split(self):
+        srcs = [self.qkv_3d.weight, self.qkv_3d.bias, self.final1x1.weight, self.final1x1.bias]
+
+        bf = CONV_ENGINE != "f32" and self.dim_3d in (32, 64, 128)
+
+        def build():
+            C = self.dim_3d
+            pack = pack_pointwise_weight_bf16s if bf else pack_conv_weight
+            return (pack(self.qkv_3d.weight.detach().float().reshape(3 * C, C, 1, 1, 1)),
+                    self.qkv_3d.bias.detach().float().contiguous(),
+                    pack(self.final1x1.weight.detach().float()),
+                    self.final1x1.bias.detach().float().contiguous())
+        return _cache(self).get("attn_split/" + ("bf16s" if bf else "f32"), srcs, build) + (bf,)
+
     def forward(self, x):
         if _inference(self, x):
             PATH_COUNTS["hip"] += 1
@@ -341,6 +382,22 @@ class attention_block(nn.Module):
             dev = _lib.require_device(x)
             B, C, D, H, W = x.shape
             assert C == self.dim_3d and D % self.block[0] == 0
+            if ATTENTION_FORM == "split":
+                # projection -> per-(window, 4 heads) attention -> projection: three launches that each fill
+                # the chip at batch 1 (the fused kernel has one workgroup per window)
+                wq, bq, wo, bo, bf = self._params_split()
+                nterms = 3 if CONV_ENGINE == "bf16x3" else 6
+                if bf:
+                    qkv = conv3d_pointwise_bf16s_hip(x, wq, 3 * C, None, bq, False, nterms)
+                else:
+                    qkv = conv3d_hip(x, wq, None, bq, 1, 1, False)
+                y = torch.empty_like(x)
+                with torch.cuda.device(dev):
+                    call("ss_window_attention_core_fwd", ptr(qkv), ptr(bq), ptr(y), B, C, D, H, W, self.num_heads,
+                         self.block[0], self.block[1], self.block[2])
+                if bf:
+                    return conv3d_pointwise_bf16s_hip(y, wo, C, None, bo, False, nterms)
+                return conv3d_hip(y, wo, None, bo, 1, 1, False)
             wq, bq, wo, bo = self._params()
             out = torch.empty_like(x)
             with torch.cuda.device(dev):

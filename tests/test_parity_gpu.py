@@ -363,6 +363,50 @@ def test_conv3d_fused_channel_gate(sa, engine):
     check(f"conv3d_gate/{engine}", y, ref, 2e-5)
 
 
+@pytest.mark.parametrize("shape", [((4, 4, 4), 8, 8, 12), ((6, 4, 4), 6, 8, 8), ((4, 4, 4), 4, 6, 7), ((6, 4, 4), 12, 5, 8),
+                                   ((4, 4, 4), 4, 9, 3)])
+def test_attention_block_forms_agree(sa, shape):
+    """attention_block (models/submodule_other.py:790-837) in both HIP forms -- the fused one-kernel-per-window
+    form and the three-launch form (projection, per-(window, 4 heads) attention, projection) -- against the
+    PyTorch composition of the same module, including H/W padding (both, one, none)."""
+    from oracle import detdata as dd
+    block, D, H, W = shape
+    mod = sa.modules.attention_block(128, 16, block).cuda().eval()
+    with torch.no_grad():
+        for i, p in enumerate(mod.parameters()):
+            a = (3.0 / 128) ** 0.5 if p.dim() > 1 else 0.2
+            p.copy_(dev(dd.t_uniform(tuple(p.shape), 600 + i, -a, a)))
+    x = dev(dd.t_normalish((2, 128, D, H, W), 610))
+    old = sa.modules.ATTENTION_FORM
+    outs = {}
+    try:
+        with torch.no_grad():
+            for form in ("split", "fused"):
+                sa.modules.ATTENTION_FORM = form
+                outs[form] = mod(x)
+            ref = mod._forward_torch(x)
+    finally:
+        sa.modules.ATTENTION_FORM = old
+    for form in outs:
+        check(f"attention_{form}/{shape}", outs[form], ref.cpu(), 2e-5)
+
+
+@pytest.mark.parametrize("nterms", [6, 3])
+@pytest.mark.parametrize("case", [(2, 128, 384, (3, 5, 7)), (1, 128, 128, (6, 16, 16)), (1, 64, 40, (1, 1, 33)), (1, 32, 32, (2, 9, 70))])
+def test_pointwise_split_bf16(sa, case, nterms):
+    """1x1x1 conv / Linear over channels (qkv_3d, final1x1 of attention_block) on the split-bf16 engine vs float64."""
+    from oracle import detdata as dd
+    B, Cin, Cout, sp = case
+    x = dd.t_normalish((B, Cin) + sp, 291)
+    w = dd.t_uniform((Cout, Cin), 292, -1, 1) * (3.0 / Cin) ** 0.5
+    bias = dd.t_uniform((Cout,), 293, -0.2, 0.2)
+    ref = torch.einsum("oc,bcdhw->bodhw", w.double(), x.double()) + bias.double().reshape(1, -1, 1, 1, 1)
+    y = sa.modules.conv3d_pointwise_bf16s_hip(dev(x), sa.modules.pack_pointwise_weight_bf16s(dev(w)), Cout, None, dev(bias), False, nterms)
+    e = float((y.double().cpu() - ref).abs().max())
+    REPORT[f"pointwise_bf16x{nterms}/{case}"] = e
+    assert e <= (2e-6 if nterms == 6 else 4e-5), e
+
+
 HEAD_CASES = [
     # (B, Cin, D, H, W, relu): the 32 -> 1 classifier heads; W not a multiple of 30, both tile shapes, tiny volumes
     (2, 32, 5, 9, 37, False),
