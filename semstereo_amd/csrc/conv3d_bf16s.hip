@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
             if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
         }
 #endif
+#ifndef SS_ABL_BAR1
         __syncthreads();
+#endif
         const bool more = ci0 + 8 < Cin;
         nlive_next = min(8, Cin - ci0 - 8);
 
@@ -241,6 +243,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[i], 0, 0, 0);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) bcur[c] = bnxt[c];
+#ifndef SS_NO_SGB
+                // pin the software pipeline: the next row's fragment reads are issued BEFORE this row's
+                // MFMAs (the scheduler otherwise sinks them next to their use and every row starts with
+                // an exposed LDS latency)
+                __builtin_amdgcn_sched_group_barrier(0x100, NC, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, (NTERMS == 6) ? 6 : 3, 0);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);     // keep each step's loads inside the step
         }
@@ -257,7 +266,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                 for (int c = 0; c < NC; ++c) aq[k][c] = tq[k][c];
         }
         nlive = nlive_next;
+#ifndef SS_ABL_BAR2
         __syncthreads();
+#endif
     }
 
     // ---- epilogue (identical to conv3d_mfma: the 32x32 D layout does not depend on the input type) ----
