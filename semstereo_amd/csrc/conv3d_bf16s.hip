@@ -33,6 +33,9 @@ constexpr int KSTEPS = 14;        // ceil(27 taps / 2)
 #ifndef SS_IN_STEPS
 #define SS_IN_STEPS 10            // K-steps over which the next chunk's input loads are issued
 #endif
+#ifndef SS_IN_AUX
+#define SS_IN_AUX 0               // cache policy bits of the activation loads (buffer_load aux: 1 = sc0, 2 = nt)
+#endif
 #ifndef SS_A_AHEAD
 #define SS_A_AHEAD 2              // K-steps between the load of a weight fragment and its MFMAs
 #endif
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, wlane, g * wstep + c * 2 * Cout * 16, 0));
     };
     auto load_in = [&](int ch, int i) {                                       // channel ch (absolute), position slot i
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, 0));
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, SS_IN_AUX));
     };
     const int G = ((Cin + 7) / 8) * KSTEPS;
     // Ring of weight fragments, AP steps ahead: vmcnt retires in order, so a wait for a fragment also

@@ -167,6 +167,22 @@ def test_warp_streaming_stores_identical(sa, monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_warp_float4_form_identical(sa, monkeypatch):
+    """SS_WARP_VEC=4 (4 columns per lane) against the default one-column-per-lane form, fractional disparities."""
+    from oracle import detdata as dd
+    B, C, H, W, nd = 2, 8, 7, 64, 5
+    x, y = dd.t_normalish((B, C, H, W), 145), dd.t_normalish((B, C, H, W), 146)
+    disp = dd.t_uniform((B, nd, H, W), 147, -9.0, 9.0)
+    att = dd.t_uniform((B, 1, nd, H, W), 148, 0.0, 1.0)
+    outs = []
+    for flag in ("1", "4"):
+        monkeypatch.setenv("SS_WARP_VEC", flag)
+        outs.append(sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp), dev(att)).cpu())
+    assert torch.equal(outs[0], outs[1])
+    yw, xw = oops.SpatialTransformer_grid(x, y, disp)
+    check("concat_sampled_fractional", outs[0], att * torch.cat((xw, yw), dim=1), 2e-5)
+
+
 @pytest.mark.parametrize("name", sorted(cases.TOPK))
 def test_topk(sa, golden, name):
     c, s, k = cases.topk_inputs(name)
