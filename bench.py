@@ -121,9 +121,14 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
 
-    rank, world, local = sdist.init_from_env("nccl")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # one rank per GPU over RCCL; SS_DIST_BACKEND=gloo lets the N > 1 control flow be rehearsed with several
+    # ranks on ONE GPU (RCCL refuses two ranks on a device) -- the numbers of such a run mean nothing
+    backend = os.environ.get("SS_DIST_BACKEND", "nccl")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists)"
+    if backend != "nccl":
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    rank, world, local = sdist.init_from_env(backend)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     semstereo_amd._lib.load()
@@ -220,7 +225,7 @@ def main():
         else:
             nterms = 6 if engine == "bf16x6" else 3
             ex = nterms * eq                                   # bf16 MFMA flops actually issued per second
-            res["roofline"] = {"kernel": f"conv3d_bf16s<1,4,2,8,{nterms}> (concat_stem, 64->32 k3 on [B,64,24,H/4,W/4])",
+            res["roofline"] = {"kernel": f"conv3d_bf16s<1,4,2,8,{nterms},true> (concat_stem + fused channelAtt gate, 64->32 k3 on [B,64,24,H/4,W/4])",
                                "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ex / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
                                "algorithmic_flop_per_launch": nterms * flops,

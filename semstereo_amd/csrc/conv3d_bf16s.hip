@@ -81,7 +81,9 @@ struct BCfg {
     static_assert(TD * TH == 4 * NT && TH % NT == 0, "4 waves x NT rows tile TD x TH");
 };
 
-template <int S, int NT, int TD, int TH, int NTERMS>
+// GATED: the channelAtt gate is fused into the epilogue (only concat_stem has one, so its launches also carry
+// their own kernel symbol in a profile: conv3d_bf16s<..., true>)
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int oh = min(oh0 + hy0 + i, Ho - 1);
-                gv[q][i] = gate ? gate[(((size_t)b * Cout + co) * Ho + oh) * Wo + ow] : 1.0f;
+                gv[q][i] = GATED ? gate[(((size_t)b * Cout + co) * Ho + oh) * Wo + ow] : 1.0f;
                 rv[q][i] = residual ? residual[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] : 0.0f;
             }
         }
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                 float v = ss::add_rn(ss::mul_rn(acc[i][r], sc[q]), sh[q]);
                 if (residual) v = ss::add_rn(v, rv[q][i]);
                 if (relu) v = fmaxf(v, 0.f);
-                if (gate) v = ss::mul_rn(gv[q][i], v);      // channelAtt gate, broadcast over D
+                if (GATED) v = ss::mul_rn(gv[q][i], v);     // channelAtt gate, broadcast over D
                 out[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] = v;
             }
         }
@@ -336,15 +338,15 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned 
     wsplit[i] = (unsigned short)(term == 0 ? h : (term == 1 ? m : l));
 }
 
-template <int S, int NT, int TD, int TH, int NTERMS>
-int launch_b(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
-             const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED>
+int launch_bg(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
+              const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
     using C = BCfg<S, NT, TD, TH>;
     const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS>;
+    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED>;
     if (C::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)C::LDS_BYTES);
@@ -354,6 +356,14 @@ int launch_b(const float* in, const void* wsplit, const float* scale, const floa
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
                        residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
     return ss::check_launch();
+}
+
+template <int S, int NT, int TD, int TH, int NTERMS>
+int launch_b(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
+             const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
+    if (gate != nullptr)
+        return launch_bg<S, NT, TD, TH, NTERMS, true>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
+    return launch_bg<S, NT, TD, TH, NTERMS, false>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
 }
 
 }  // namespace
