@@ -36,6 +36,9 @@ constexpr int KSTEPS = 14;        // ceil(27 taps / 2)
 #ifndef SS_IN_AUX
 #define SS_IN_AUX 0               // cache policy bits of the activation loads (buffer_load aux: 1 = sc0, 2 = nt)
 #endif
+#ifndef SS_ROW_PAIR
+#define SS_ROW_PAIR 1             // rows whose MFMAs alternate; 2 measured 1 % slower: the other wave of the SIMD already fills the gaps
+#endif
 #ifndef SS_A_AHEAD
 #define SS_A_AHEAD 2              // K-steps between the load of a weight fragment and its MFMAs
 #endif
@@ -196,8 +199,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
         const bool more = ci0 + 8 < Cin;
         nlive_next = min(8, Cin - ci0 - 8);
 
-        // B fragments are read one (step, row) ahead of their MFMAs
-        uint4 bcur[NC], bnxt[NC];
+        // B fragments are read one row GROUP ahead of their MFMAs.  With RP = 2 the MFMAs of two rows
+        // alternate so that no two consecutive ones share an accumulator (SS_ROW_PAIR; no gain measured).
+        constexpr int RP = (NT >= 2) ? SS_ROW_PAIR : 1;
+        static_assert(NT % RP == 0, "rows are processed in whole groups");
+        uint4 bcur[RP][NC], bnxt[RP][NC];
         auto read_b = [&](uint4 (&dst)[NC], int s, int i) {
             const int ta = 2 * s, tb = 2 * s + 1;
             const int offa = ((ta / 9) * C::IH + (ta / 3) % 3) * C::IW + ta % 3;
@@ -206,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #pragma unroll
             for (int c = 0; c < NC; ++c) dst[c] = lds[(tb >= 27 && half) ? 3 * C::CS : c * C::CS + slot];
         };
-        read_b(bcur, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RP; ++r) read_b(bcur[r], 0, r);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             // weight fragments two steps ahead, then this step's slice of the next chunk's input
@@ -227,33 +234,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #pragma unroll
             for (int c = 0; c < NC; ++c) a[c] = __builtin_bit_cast(bf16x8, aq[s % AR][c]);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
+            for (int i0 = 0; i0 < NT; i0 += RP) {
+#pragma unroll
+                for (int r = 0; r < RP; ++r) {
 #ifndef SS_ABL_B
-                if (i + 1 < NT) read_b(bnxt, s, i + 1);
-                else if (s + 1 < KSTEPS) read_b(bnxt, s + 1, 0);
+                    if (i0 + RP < NT) read_b(bnxt[r], s, i0 + RP + r);
+                    else if (s + 1 < KSTEPS) read_b(bnxt[r], s + 1, r);
 #else
 #pragma unroll
-                for (int c = 0; c < NC; ++c) bnxt[c] = bcur[c];
+                    for (int c = 0; c < NC; ++c) bnxt[r][c] = bcur[r][c];
 #endif
-                bf16x8 bq[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) bq[c] = __builtin_bit_cast(bf16x8, bcur[c]);
-                if (NTERMS == 6) {     // smallest cross terms first
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[2], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[0], acc[i], 0, 0, 0);
                 }
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[i], 0, 0, 0);
+                // cross terms (a term, b term), smallest first; rows of the group alternate
+                constexpr int NP = (NTERMS == 6) ? 6 : 3;
+                constexpr int pa[6] = {1, 0, NC - 1, 0, 1, 0}, pb[6] = {1, NC - 1, 0, 1, 0, 0};
 #pragma unroll
-                for (int c = 0; c < NC; ++c) bcur[c] = bnxt[c];
+                for (int p = 6 - NP; p < 6; ++p)
+#pragma unroll
+                    for (int r = 0; r < RP; ++r)
+                        acc[i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            a[pa[p]], __builtin_bit_cast(bf16x8, bcur[r][pb[p]]), acc[i0 + r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < RP; ++r)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) bcur[r][c] = bnxt[r][c];
 #ifndef SS_NO_SGB
-                // pin the software pipeline: the next row's fragment reads are issued BEFORE this row's
-                // MFMAs (the scheduler otherwise sinks them next to their use and every row starts with
-                // an exposed LDS latency)
-                __builtin_amdgcn_sched_group_barrier(0x100, NC, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, (NTERMS == 6) ? 6 : 3, 0);
+                // pin the software pipeline: the next group's fragment reads are issued BEFORE this
+                // group's MFMAs (the scheduler otherwise sinks them next to their use and every row
+                // starts with an exposed LDS latency)
+                __builtin_amdgcn_sched_group_barrier(0x100, NC * RP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NP * RP, 0);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);     // keep each step's loads inside the step
