@@ -186,6 +186,14 @@ def main():
                 o, p_, t_ = timed_run(max(3, args.steps // 2), 2)
                 by_engine[e], outs[e] = p_ / t_, o
         M.CONV_ENGINE = engine
+        # what install() + accelerate() alone give a reference model whose forward() is left untouched: every op and
+        # module on the HIP kernels, PyTorch glue in between, none of the cross-line fusions
+        seg.FUSED = False
+        _, p_, t_ = timed_run(max(3, args.steps // 2), 2)
+        unfused_rate = p_ / t_
+        seg.FUSED = True
+    else:
+        unfused_rate = None
 
     if rank != 0:
         # rank 0 still runs the CPU baseline; meet it at a last barrier so the group is torn down together
@@ -212,6 +220,7 @@ def main():
                    "weights": "random init at unit gain (see init_unit_gain), BatchNorm eval",
                    "conv_engine": engine, "conv_engine_note": engine_note},
         "pairs_per_s_by_conv_engine": by_engine,
+        "pairs_per_s_reference_forward_untouched": unfused_rate,
     }
     ms = timer.mean_ms("concat_stem")
     if ms:

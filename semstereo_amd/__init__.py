@@ -10,7 +10,7 @@ The compute lives in csrc/libsemstereo_hip.so behind the C ABI of include/semste
 Nothing here falls back to the CPU or to the test oracle.
 """
 from . import _lib, dist, modules, ops, segment  # noqa: F401
-from .install import accelerate, install, uninstall  # noqa: F401
+from .install import accelerate, install, restore_forward, uninstall  # noqa: F401
 from .segment import HotSegment  # noqa: F401
 
 __version__ = "0.1.0"

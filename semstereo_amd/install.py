@@ -10,11 +10,23 @@ the functions up BY BARE NAME in its module globals at call time (models/SemSter
     semstereo_amd.install(ms)                      # rebind the op-library names in ITS globals
     net = ms.SemStereo(...); net.load_state_dict(ckpt); net.cuda().eval()
     semstereo_amd.accelerate(net)                  # swap hourglass/classifier/... for HIP-backed twins
+
+That alone runs every hot op and module of the reference's forward() on the HIP kernels (measured on the
+bench shape: 190 pairs/s for the hot segment).  The fusions that cross the lines of forward() -- patch+gate,
+softmax+regression+variance, the two attention-tail kernels, warp+concat+gate, stem+gate, the two-stream
+overlap (260 pairs/s) -- need the inference call path itself:
+
+    semstereo_amd.accelerate(net, fuse_forward=True)   # eval()/no_grad calls take the fused path; training,
+                                                       # autograd and seg-only calls still run the reference forward()
 """
+import types
+
+import torch
 import torch.nn as nn
 
 from . import modules as M
 from . import ops
+from . import segment
 
 
 def install(model_module, names=ops.REFERENCE_NAMES):
@@ -51,10 +63,11 @@ _SWAPS = {
 }
 
 
-def accelerate(model):
+def accelerate(model, fuse_forward=False):
     """Replace the hot-path sub-modules of a reference `SemStereo` instance (or of the .module of
     its nn.DataParallel wrapper) by HIP-backed twins that SHARE its parameters; state_dict keys and
-    values are unchanged.  Returns the list of swapped attribute names."""
+    values are unchanged.  With `fuse_forward` the instance's forward is additionally routed through
+    `fused_inference_forward` for inference calls.  Returns the list of swapped attribute names."""
     target = model.module if isinstance(model, nn.DataParallel) else model
     done = []
     for name, cls in _SWAPS.items():
@@ -66,4 +79,48 @@ def accelerate(model):
         assert list(new.state_dict().keys()) == before, f"state_dict keys of {name} changed"
         setattr(target, name, new)
         done.append(name)
+    if fuse_forward and "_ss_reference_forward" not in target.__dict__:
+        target.__dict__["_ss_reference_forward"] = target.forward           # the bound reference method
+        target.forward = types.MethodType(fused_inference_forward, target)
     return done
+
+
+def restore_forward(model):
+    """Undo `accelerate(..., fuse_forward=True)`'s forward routing (the swapped sub-modules stay)."""
+    target = model.module if isinstance(model, nn.DataParallel) else model
+    if "_ss_reference_forward" in target.__dict__:
+        del target.__dict__["forward"]
+        del target.__dict__["_ss_reference_forward"]
+
+
+def fused_inference_forward(self, left, right):
+    """The caller side of the hot path, models/SemStereo.py:246-346, for eval-mode / no-autograd calls: the
+    same sub-module calls in the same order as the reference's forward() around `segment.run_segment`
+    (:273-323 fused).  Returns exactly what the reference returns in eval mode: `[disp_full_res]` or
+    `([disp_full_res], label_logits)`, disp = 4 * SSR_upsample(pred).  Everything else (training, autograd,
+    segmentation-only models) is handed to the reference's own forward()."""
+    reference_forward = self.__dict__["_ss_reference_forward"]
+    if (self.training or not self.stereo_if or not left.is_cuda
+            or (torch.is_grad_enabled() and (left.requires_grad or right.requires_grad
+                                             or any(p.requires_grad for p in self.parameters())))):
+        return reference_forward(left, right)
+    fl, fr = self.feature(left), self.feature(right)                                         # :248-249
+    fl, fr = self.feature_up(fl, fr)                                                         # :251
+    fl, fr = list(fl), list(fr)
+    # :253-255; without seg_if the reference itself fails at ssr_upsample (pred_label undefined), so the
+    # label logits are computed whenever the stereo branch runs
+    pred_label = self.head_l(fl[0])
+    for i, name in enumerate(("chal_0", "chal_1", "chal_2", "chal_3", "chal_4")):            # :258-262
+        fl[i] = getattr(self, name)(fl[i])
+    fr[1], fr[2] = self.chal_1(fr[1]), self.chal_2(fr[2])                                    # :264-265
+    xspx = self.spx32_16(fl[4], fl[3])                                                       # :267-271
+    xspx = self.spx16_8(xspx, fl[2])
+    xspx = self.spx8_4(xspx, fl[1])
+    xspx = self.spx4_2(xspx, fl[0])
+    spx_pred = self.spx2(xspx)
+    r = segment.run_segment(self, fl[1], fr[1], fl[2], fr[2], matching=not self.att_weights_only)   # :273-323
+    if self.att_weights_only:
+        disp = self.ssr_upsample(r["pred_att"].unsqueeze(1), spx_pred, pred_label)           # :311
+    else:
+        disp = self.ssr_upsample(r["pred"], spx_pred, pred_label)                            # :324
+    return ([disp * 4], pred_label) if self.seg_if else [disp * 4]                           # :340-346

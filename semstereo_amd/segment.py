@@ -52,6 +52,10 @@ def propagation_prob(v):
 
 class HotSegment(nn.Module):
     OVERLAP = os.environ.get("SS_OVERLAP", "1") != "0"     # two-stream overlap of the branches (inference)
+    #: False: run the line-by-line composition of the reference's forward() (reference-named ops and modules,
+    #: PyTorch glue in between) also in inference -- what a reference model gets from `install()` +
+    #: `accelerate()` alone, with its forward() untouched.  True: the fused kernels of this file.
+    FUSED = os.environ.get("SS_FUSED", "1") != "0"
 
     def __init__(self, maxdisp, c8=256, c4=128):
         super().__init__()
@@ -85,7 +89,7 @@ class HotSegment(nn.Module):
     def attention_branch(self, fl4, fr4, fl8, fr8):
         m8, m4 = self.maxdisp // 8, self.maxdisp // 4
         H4, W4 = fl4.shape[-2:]
-        fast = M._inference(self, fl4, fr4, fl8, fr8)
+        fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, fl8, fr8)
         corr = ops.build_gwc_volume_norm(fl8, fr8, m8, fl8.shape[1] // 8)                      # :273
         if fast:
             cost_att = self.patch(corr, self.corr_feature_att_8.logits(fl8))                   # :274 + :276 fused
@@ -128,9 +132,9 @@ class HotSegment(nn.Module):
         return cl, cr, self.concat_feature_att_4.logits(fl4)
 
     def matching_branch(self, fl4, fr4, att_topk, samples, prelude=None):
-        fast = M._inference(self, fl4, fr4, att_topk)
+        fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, att_topk)
         if fast:
-            cl, cr, gate4 = prelude if prelude is not None else self.matching_prelude(fl4, fr4)
+            cl, cr, gate4 = prelude if prelude is not None else HotSegment.matching_prelude(self, fl4, fr4)
             volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                      # :316 + :318 fused
             volume = self.concat_stem(volume, gate4)                                           # :319 + :320 fused
         else:
@@ -146,19 +150,28 @@ class HotSegment(nn.Module):
     def forward(self, fl4, fr4, fl8, fr8):
         """features_left[1], features_right[1] [B,128,H/4,W/4]; features_left[2], features_right[2]
         [B,256,H/8,W/8]  ->  dict(pred [B,1,H/4,W/4], pred_att [B,H/4,W/4], samples, att_topk, pred_att0)."""
-        prelude = None
-        if self.OVERLAP and fl4.is_cuda and M._inference(self, fl4, fr4, fl8, fr8):
-            # The attention branch works at 1/8 scale: at small batch most of its kernels cannot fill
-            # 256 CUs.  The matching branch's 2-D convolutions are independent of it, so they run on a
-            # second HIP stream underneath and join before the sparse concat volume is built.
-            cur, side = torch.cuda.current_stream(fl4.device), _side_stream(fl4.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                prelude = self.matching_prelude(fl4, fr4)
-        att_topk, samples, pred_att, pred0 = self.attention_branch(fl4, fr4, fl8, fr8)
-        if prelude is not None:
-            cur.wait_stream(side)
-            for t in prelude:
-                t.record_stream(cur)
-        pred = self.matching_branch(fl4, fr4, att_topk, samples, prelude)
-        return dict(pred=pred, pred_att=pred_att, samples=samples, att_topk=att_topk, pred_att0=pred0)
+        return run_segment(self, fl4, fr4, fl8, fr8)
+
+
+def run_segment(owner, fl4, fr4, fl8, fr8, matching=True):
+    """models/SemStereo.py:273-323 on `owner`: a HotSegment, or a reference SemStereo instance after
+    `install.accelerate` -- the attribute names are the same, so the methods above run unbound on it.
+    `matching=False` stops after the attention branch (the reference's att_weights_only mode)."""
+    fused = getattr(owner, "FUSED", HotSegment.FUSED)
+    overlap = getattr(owner, "OVERLAP", HotSegment.OVERLAP)
+    prelude = None
+    if matching and fused and overlap and fl4.is_cuda and M._inference(owner, fl4, fr4, fl8, fr8):
+        # The attention branch works at 1/8 scale: at small batch most of its kernels cannot fill
+        # 256 CUs.  The matching branch's 2-D convolutions are independent of it, so they run on a
+        # second HIP stream underneath and join before the sparse concat volume is built.
+        cur, side = torch.cuda.current_stream(fl4.device), _side_stream(fl4.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            prelude = HotSegment.matching_prelude(owner, fl4, fr4)
+    att_topk, samples, pred_att, pred0 = HotSegment.attention_branch(owner, fl4, fr4, fl8, fr8)
+    if prelude is not None:
+        cur.wait_stream(side)
+        for t in prelude:
+            t.record_stream(cur)
+    pred = HotSegment.matching_branch(owner, fl4, fr4, att_topk, samples, prelude) if matching else None
+    return dict(pred=pred, pred_att=pred_att, samples=samples, att_topk=att_topk, pred_att0=pred0)

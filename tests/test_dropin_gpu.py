@@ -1,0 +1,91 @@
+"""Drop-in on a model shaped like the reference (tests/standin_model.py): `install()` rebinds the op library in
+the model module's globals, `accelerate()` leaves forward() untouched, `accelerate(fuse_forward=True)` routes
+inference calls through the fused hot segment -- all three must agree.  Run on the MI355X box: pytest -m gpu."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import semstereo_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    semstereo_amd._lib.load()
+    return semstereo_amd
+
+
+def _build(sa, **kw):
+    import standin_model
+    from oracle import detdata as dd
+    net = standin_model.StandInSemStereo(64, sa.modules, **kw)
+    with torch.no_grad():
+        for i, (name, t) in enumerate(sorted(list(net.named_parameters()) + list(net.named_buffers()))):
+            if name.endswith("num_batches_tracked") or name in ("gamma", "beta"):
+                continue
+            if name.endswith("running_var") or (name.endswith(".weight") and t.dim() == 1):
+                t.copy_(dd.t_uniform(tuple(t.shape), 900 + i, 0.6, 1.4))
+            elif t.dim() == 1:
+                t.copy_(dd.t_uniform(tuple(t.shape), 900 + i, -0.1, 0.1))
+            else:
+                fan_in = t.shape[0] * 27 // 8 if (".conv5.0." in name or ".conv6.0." in name) else t[0].numel()
+                a = (3.0 / fan_in) ** 0.5
+                t.copy_(dd.t_uniform(tuple(t.shape), 900 + i, -a, a))
+    return net.cuda().eval(), standin_model
+
+
+def _images(B=1, H=128, W=160):
+    from oracle import detdata as dd
+    left = dd.t_normalish((B, 3, H, W), 951)
+    right = torch.roll(left, shifts=-3, dims=3) + 0.05 * dd.t_normalish((B, 3, H, W), 952)
+    return left.cuda(), right.cuda()
+
+
+@pytest.mark.parametrize("att_only", [False, True])
+def test_fused_forward_equals_untouched_forward(sa, att_only):
+    net, module = _build(sa, att_weights_only=att_only)
+    left, right = _images()
+    previous = sa.install(module)
+    try:
+        assert sa.accelerate(net) == []                       # the stand-in is already built from the twins
+        with torch.no_grad():
+            (d0,), lab0 = net(left, right)                     # forward() untouched: HIP ops + HIP modules, PyTorch glue
+        calls = net.calls
+        sa.accelerate(net, fuse_forward=True)
+        before = dict(sa.modules.PATH_COUNTS)
+        with torch.no_grad():
+            (d1,), lab1 = net(left, right)
+        assert net.calls == calls, "the reference-shaped forward ran although the fused one applies"
+        assert sa.modules.PATH_COUNTS["torch"] == before["torch"]
+        assert d1.shape == d0.shape == (1, 128, 160) and torch.equal(lab0, lab1)
+        err = (d1 - d0).abs()
+        # full-resolution disparities (x4): 1e-3 px at 1/4 scale = 4e-3 here; a top-2 flip on an isolated pixel is tolerated
+        assert float(err.median()) <= 1e-4 and float((err <= 4e-3).float().mean()) >= 0.995, (float(err.median()), float(err.max()))
+        # autograd / training calls are handed to the model's own forward()
+        net.train()
+        out = net(left, right)
+        assert net.calls == calls + 1 and len(out) == 3 and len(out[0]) == (2 if att_only else 4)
+        net.eval()
+        sa.restore_forward(net)
+        with torch.no_grad():
+            net(left, right)
+        assert net.calls == calls + 2
+    finally:
+        sa.uninstall(module, previous)
+
+
+def test_fused_forward_matches_the_cpu_composition(sa):
+    """The stand-in with the ORACLE op library and PyTorch layers on the CPU (no HIP anywhere) against the fused GPU path."""
+    net, module = _build(sa)
+    left, right = _images()
+    import copy
+    cpu_net = copy.deepcopy(net).cpu().eval()
+    for p in cpu_net.parameters():           # eval() (running BN statistics) with autograd on: every twin takes its PyTorch path
+        p.requires_grad_(True)
+    (dc,), labc = cpu_net(left.cpu(), right.cpu())
+    sa.accelerate(net, fuse_forward=True)
+    with torch.no_grad():
+        (dg,), labg = net(left, right)
+    assert float((labg.cpu() - labc.detach()).abs().max()) <= 1e-4
+    err = (dg.cpu() - dc.detach()).abs()
+    assert float(err.median()) <= 1e-4 and float((err <= 4e-3).float().mean()) >= 0.99, (float(err.median()), float(err.max()))

@@ -67,6 +67,19 @@ def test_accelerate_on_the_real_reference_model(ref_module):
     (got,), _ = net(imgL, imgR)
     assert sa.modules.PATH_COUNTS["torch"] > before
     assert torch.allclose(got.detach(), want, atol=1e-4, rtol=1e-4)
+    # fuse_forward: inference calls on GPU tensors would take the fused path; on this GPU-less box the call is
+    # handed to the reference's own forward() (CPU tensors, autograd on), the attribute names it needs exist,
+    # and the routing can be undone
+    sa.accelerate(net, fuse_forward=True)
+    assert net.forward.__func__ is sys.modules["semstereo_amd.install"].fused_inference_forward
+    for name in ("feature", "feature_up", "head_l", "chal_0", "chal_4", "spx32_16", "spx16_8", "spx8_4", "spx4_2", "spx2",
+                 "ssr_upsample", "stereo_if", "seg_if", "att_weights_only", "maxdisp", "gamma", "beta", "concat_feature"):
+        assert hasattr(net, name), name
+    (again,), _ = net(imgL, imgR)
+    assert torch.allclose(again.detach(), want, atol=1e-4, rtol=1e-4)
+    assert list(net.state_dict().keys()) == keys
+    sa.restore_forward(net)
+    assert "forward" not in net.__dict__ and net.forward.__func__ is ref_module.SemStereo.forward
 
 
 def test_install_into_the_real_reference_module(ref_module):
