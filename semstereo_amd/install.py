@@ -60,6 +60,8 @@ _SWAPS = {
     "corr_feature_att_8": M.channelAtt,
     "concat_feature_att_4": M.channelAtt,
     "ssr_upsample": M.SSR_upsample,
+    "propagation": M.Propagation,              # parameter-free: one-hot convolutions -> shifted views
+    "propagation_prob": M.Propagation_prob,
 }
 
 

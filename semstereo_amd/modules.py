@@ -525,6 +525,47 @@ class Classifier(nn.Sequential):
         return super().forward(x)
 
 
+_PROP_TAPS = ((-1, -1), (0, 0), (1, 1), (1, -1), (-1, 1))    # models/submodule.py:295-300 / 367-372
+
+
+def propagation(x):
+    """Propagation.forward (models/submodule.py:290-307): [B,1,H,W] -> [B,5,H,W], the five diagonal
+    neighbours with replicate padding (the reference's one-hot 3x3 convolution, as plain shifts: exact)."""
+    H, W = x.shape[-2:]
+    p = F.pad(x, (1, 1, 1, 1), mode="replicate")
+    return torch.cat([p[..., 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in _PROP_TAPS], dim=1)
+
+
+def propagation_prob(v):
+    """Propagation_prob.forward (models/submodule.py:361-377): [B,1,D,H,W] -> [B,5,D,H,W]."""
+    H, W = v.shape[-2:]
+    p = F.pad(v, (1, 1, 1, 1, 0, 0), mode="replicate")
+    return torch.cat([p[..., 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in _PROP_TAPS], dim=1)
+
+
+class Propagation(nn.Module):
+    """Twin of the reference's parameter-free Propagation (a conv2d with a one-hot [5,1,3,3] filter built on
+    every call): five shifted views, bit-identical for finite inputs, differentiable."""
+
+    @classmethod
+    def adopt(cls, ref):
+        return cls().train(ref.training)
+
+    def forward(self, disparity_samples):
+        return propagation(disparity_samples)
+
+
+class Propagation_prob(nn.Module):
+    """Twin of Propagation_prob (a conv3d with a one-hot [5,1,1,3,3] filter over the whole volume)."""
+
+    @classmethod
+    def adopt(cls, ref):
+        return cls().train(ref.training)
+
+    def forward(self, prob_volume):
+        return propagation_prob(prob_volume)
+
+
 class DepthwisePatch(nn.Conv3d):
     """`patch`: depthwise Conv3d kernel (1,3,3), pad (0,1,1), no bias; key `weight` [C,1,1,3,3]."""
 

@@ -19,7 +19,6 @@ from . import modules as M
 from . import ops
 
 TOPK = 24                                   # models/SemStereo.py:301
-_PROP_TAPS = ((-1, -1), (0, 0), (1, 1), (1, -1), (-1, 1))    # models/submodule.py:295-300 / 367-372
 
 OWNED_PREFIXES = ("patch", "corr_feature_att_8", "hourglass_att", "classif_att_", "gamma", "beta",
                   "concat_feature", "concat_stem", "concat_feature_att_4", "hourglass", "classif")
@@ -35,19 +34,7 @@ def _side_stream(device):
     return st
 
 
-def propagation(x):
-    """Propagation.forward (models/submodule.py:290-307): [B,1,H,W] -> [B,5,H,W], the five diagonal
-    neighbours with replicate padding (the reference's one-hot 3x3 convolution, as plain shifts)."""
-    H, W = x.shape[-2:]
-    p = F.pad(x, (1, 1, 1, 1), mode="replicate")
-    return torch.cat([p[..., 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in _PROP_TAPS], dim=1)
-
-
-def propagation_prob(v):
-    """Propagation_prob.forward (models/submodule.py:361-377): [B,1,D,H,W] -> [B,5,D,H,W]."""
-    H, W = v.shape[-2:]
-    p = F.pad(v, (1, 1, 1, 1, 0, 0), mode="replicate")
-    return torch.cat([p[..., 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in _PROP_TAPS], dim=1)
+propagation, propagation_prob = M.propagation, M.propagation_prob
 
 
 class HotSegment(nn.Module):

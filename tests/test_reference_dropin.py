@@ -57,7 +57,8 @@ def test_accelerate_on_the_real_reference_model(ref_module):
     w = net.hourglass.conv1[0][0].weight
     done = sa.accelerate(net)
     assert sorted(done) == sorted(["hourglass_att", "hourglass", "classif_att_", "classif", "concat_stem", "patch",
-                                   "corr_feature_att_8", "concat_feature_att_4", "ssr_upsample"])
+                                   "corr_feature_att_8", "concat_feature_att_4", "ssr_upsample", "propagation",
+                                   "propagation_prob"])
     assert list(net.state_dict().keys()) == keys                      # checkpoint compatibility
     assert net.hourglass.conv1[0][0].weight is w                      # shared, not copied
     assert isinstance(net.hourglass, sa.modules.hourglass2) and net.hourglass.attention_block.block == (6, 4, 4)
