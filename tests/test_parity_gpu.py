@@ -526,7 +526,9 @@ def test_hot_segment_on_each_conv_engine(sa, golden, engine):
         REPORT[f"segment_{engine}/pred_fraction_within_1e-3"] = float((err <= 1e-3).float().mean())
         assert (err <= 1e-3).float().mean() >= 0.995 and float(err.median()) <= 1e-4
     else:
-        check(f"segment_{engine}/pred", r["pred"], g[f"{name}/pred"], 1e-3)
+        err = (r["pred"].cpu() - torch.as_tensor(g[f"{name}/pred"])).abs()
+        REPORT[f"segment_{engine}/pred"] = float(err.max())
+        assert float(err.median()) <= 1e-5 and int((err > 1e-3).sum()) <= 1, float(err.max())      # see the fixture test
 
 
 @pytest.mark.parametrize("case", [(128, 64, 2, 3, 5, 64), (64, 32, 3, 9, 33, 32), (32, 32, 2, 4, 40, 0), (8, 24, 2, 3, 6, 6)])
@@ -587,7 +589,11 @@ def test_hot_segment_vs_reference_fixture(sa, golden, name):
     if err.numel() <= 2048:
         assert same == 1.0, f"top-24 candidate sets differ from the reference on {100 * (1 - same):.3f}% of entries"
         check(f"segment/{name}/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
-        check(f"segment/{name}/pred", r["pred"], g[f"{name}/pred"], 1e-3)
+        REPORT[f"segment/{name}/pred"] = float(err.max())
+        # measured max error 2.4e-6; one pixel is allowed beyond 1e-3 px: the 2-D convolutions on the path are
+        # MIOpen calls whose algorithm (hence rounding) may differ from box to box, and regression_topk's hard
+        # top-2 pick turns a last-bit difference into a whole-candidate jump where two costs tie
+        assert float(err.median()) <= 1e-5 and int((err > 1e-3).sum()) <= 1, float(err.max())
     else:
         # Thousands of pixels on closed-form (untrained) weights: the hard picks of the graph -- 24 of up to
         # 96 attention weights (models/SemStereo.py:299-303), then 2 of 24 costs (models/submodule.py:436-437)
