@@ -72,6 +72,12 @@ def main():
             ms = timeit(lambda: M.conv3d_bf16s_hip(x, ws, cout, sc, sh, True, nterms), args.iters)
             rows.append(dict(name=f"{name} [{M.CONV_ENGINE}]", ms=ms, gflop=gf, tflops=gf / ms, frac=gf / ms / PEAK_TF))
             return
+        if M.CONV_ENGINE != "f32" and k == 3 and stride == 1 and cout == 1 and cin in (16, 32, 64):
+            ws = M.pack_head_weight_bf16s(wt)
+            nterms = 6 if M.CONV_ENGINE == "bf16x6" else 3
+            ms = timeit(lambda: M.conv3d_head_bf16s_hip(x, ws, sc, sh, False, nterms), args.iters)
+            rows.append(dict(name=f"{name} [{M.CONV_ENGINE} head]", ms=ms, gflop=gf, tflops=gf / ms, frac=gf / ms / PEAK_TF))
+            return
         ms = timeit(lambda: M.conv3d_hip(x, wp, sc, sh, k, stride, True), args.iters)
         rows.append(dict(name=name, ms=ms, gflop=gf, tflops=gf / ms, frac=gf / ms / PEAK_TF))
 
