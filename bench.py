@@ -275,6 +275,22 @@ def main():
                                                           "r01_f_gwc_b8_stream_pmc.md): 2 x FETCH_SIZE + WRITE_SIZE, gfx950 "
                                                           "correction applied; algorithmic 805.3e6"}
         del a8, b8
+        # calibration SURVEY.md section 8(d) asks for: what a plain device-to-device copy reaches on this box
+        # (read + write bytes over time, 1 GiB, 10 back-to-back copies), to read the fractions against
+        src = torch.empty(256 << 20, dtype=torch.float32, device=device)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        res["hbm_copy_measured_gbs"] = copy_gbs
+        res["roofline_cost_volume_b8"]["frac_of_measured_copy"] = res["roofline_cost_volume_b8"]["achieved"] / copy_gbs
+        del src, dst
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and EPE: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the
         # same workload: about 10-30 s of CPU work.  ATen's CPU kernels stop scaling (the slice
