@@ -531,10 +531,12 @@ def test_hot_segment_on_each_conv_engine(sa, golden, engine):
         assert float(err.median()) <= 1e-5 and int((err > 1e-3).sum()) <= 1, float(err.max())      # see the fixture test
 
 
+@pytest.mark.parametrize("split", ["0", "1"])     # one workgroup for all 8 output parity classes / even and odd planes apart
 @pytest.mark.parametrize("case", [(128, 64, 2, 3, 5, 64), (64, 32, 3, 9, 33, 32), (32, 32, 2, 4, 40, 0), (8, 24, 2, 3, 6, 6)])
-def test_deconv3d_kernel(sa, case):
+def test_deconv3d_kernel(sa, case, split, monkeypatch):
     import torch.nn.functional as F
     from oracle import detdata as dd
+    monkeypatch.setenv("SS_DECONV_SPLIT", split)
     Cin, Cout, D, H, W, Cs = case
     x = dd.t_normalish((2, Cin, D, H, W), 91)
     w = dd.t_uniform((Cin, Cout, 3, 3, 3), 92, -1, 1) * (3.0 / (Cin * 27 / 8)) ** 0.5
@@ -549,7 +551,7 @@ def test_deconv3d_kernel(sa, case):
     wp = sa.modules.pack_conv_weight(dev(w), transposed=True)
     wsp = None if ws is None else sa.modules.pack_conv_weight(dev(ws)).reshape(Cs, Cout).contiguous()
     y = sa.modules.deconv3d_hip(dev(x), wp, dev(shift), True, None if skip is None else dev(skip), wsp)
-    check(f"deconv3d/{case}", y, ref, 2e-4)
+    check(f"deconv3d/{case}/split{split}", y, ref, 2e-4)
 
 
 def test_patch_and_gate_fusion(sa):
