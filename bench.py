@@ -147,7 +147,12 @@ def main():
 
     timer = KernelTimer()
     if not args.no_kernel_timers:
-        seg.concat_stem.forward = timer.wrap("concat_stem", seg.concat_stem.forward)
+        if M.CONV_ENGINE == "f32":
+            seg.concat_stem.forward = timer.wrap("concat_stem", seg.concat_stem.forward)
+        else:       # the gated launch of the split-bf16 conv is concat_stem's (the right half of the volume)
+            plain, timed = M.conv3d_bf16s_hip, timer.wrap("concat_stem", M.conv3d_bf16s_hip)
+            M.conv3d_bf16s_hip = lambda *a, **k: (timed if (k.get("gate") is not None or (len(a) > 8 and a[8] is not None))
+                                                  else plain)(*a, **k)
         semstereo_amd.segment.ops.build_gwc_volume_norm = timer.wrap("gwc", semstereo_amd.ops.build_gwc_volume_norm)
 
     def step():
@@ -224,8 +229,10 @@ def main():
     }
     ms = timer.mean_ms("concat_stem")
     if ms:
-        flops = 2.0 * 32 * 64 * 27 * k * H4 * W4 * B          # concat_stem: Conv3d 64->32 k3 on [B,64,24,H4,W4]
-        eq = flops / (ms * 1e-3) / 1e12                        # fp32-equivalent (algorithmic) rate
+        halves = engine != "f32" and semstereo_amd.HotSegment.STEM_BY_HALVES
+        cin_stem = 32 if halves else 64     # by linearity only the warped right half of the volume is convolved
+        flops = 2.0 * 32 * cin_stem * 27 * k * H4 * W4 * B     # concat_stem: Conv3d k3 on [B,cin_stem,24,H4,W4] -> 32 channels
+        eq = flops / (ms * 1e-3) / 1e12                        # fp32-equivalent rate of the flops this launch performs
         if engine == "f32":
             res["roofline"] = {"kernel": "conv3d_mfma<3,1,1,4,2,8,4> (concat_stem, 64->32 k3 on [B,64,24,H/4,W/4])",
                                "bound": "mfma", "achieved": eq, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -234,7 +241,9 @@ def main():
         else:
             nterms = 6 if engine == "bf16x6" else 3
             ex = nterms * eq                                   # bf16 MFMA flops actually issued per second
-            res["roofline"] = {"kernel": f"conv3d_bf16s<1,4,2,8,{nterms},true> (concat_stem + fused channelAtt gate, 64->32 k3 on [B,64,24,H/4,W/4])",
+            res["roofline"] = {"kernel": f"conv3d_bf16s<1,4,2,8,{nterms},true> (concat_stem: {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]"
+                                         + (", the warped half of the volume; + residual (the broadcast half, by linearity) + ReLU + channelAtt gate)" if halves
+                                            else " + ReLU + channelAtt gate)"),
                                "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ex / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
                                "algorithmic_flop_per_launch": nterms * flops,

@@ -82,9 +82,23 @@ int ss_warp_sampled_fwd(const float* x, const float* y, const float* disp,
 /* Fused form of SemStereo.concat_volume_generator + `att_topk * volume`
  * (models/SemStereo.py:241-244, 318): out[b,0:C,j] = att[b,j] * left[b,:],
  * out[b,C:2C,j] = att[b,j] * warp(right)[b,:,j].  att [B,nd,H,W] may be NULL (no gating).
- * -> [B,2C,nd,H,W] */
+ * -> [B,2C,nd,H,W].  left == NULL: only the right half, -> [B,C,nd,H,W] (its left half then enters
+ * concat_stem through ss_stem_left_fwd). */
 int ss_concat_sampled_fwd(const float* left, const float* right, const float* disp, const float* att,
                           float* out, int B, int C, int H, int W, int nd, ss_stream_t stream);
+/* The left (broadcast) half of concat_stem (models/SemStereo.py:319) by linearity:
+ *   out[b,co,j,h,w] = sum_{kd,kh,kw} att[b, j+kd-1, h+kh-1, w+kw-1] * q[b, tap*Cout + co, h+kh-1, w+kw-1]
+ * (zero outside), tap = kd*9+kh*3+kw, q [B,27*Cout,H,W] = the 1x1 convolution of the 2-D left concat
+ * features with concat_stem's left-half weights (ss_conv3d_pointwise_bf16s_fwd), att [B,nd,H,W] the
+ * top-k attention weights, out [B,Cout,nd,H,W]; nd in {6, 24, 32}, Cout % 4 == 0.  The result is the
+ * `residual` operand of the right half's ss_conv3d[_bf16s]_fwd. */
+int ss_stem_left_fwd(const float* q, const float* att, float* out, int B, int Cout, int nd, int H, int W,
+                     ss_stream_t stream);
+/* The same, with q computed on the fly on the matrix core and never written: left [B,C,H,W] (C = 32) is the
+ * 2-D left concat feature map, wsplit = ss_pack_pointwise_weights_bf16s of the [Cout/2 * 64, C] matrix whose
+ * row pair*64 + tap*2 + c is (scale *) W[2*pair + c, :C, tap] (rows 54-63 of every pair zero). */
+int ss_stem_left_fused_fwd(const float* left, const void* wsplit, const float* att, float* out, int B, int C,
+                           int Cout, int nd, int H, int W, int nterms, ss_stream_t stream);
 /* Fused form of models/SemStereo.py:291-292: mean over channels of left * warp(right):
  * x,y [B,C,H,W], disp [B,nd,H,W] -> [B,nd,H,W] */
 int ss_warp_correlation_fwd(const float* x, const float* y, const float* disp, float* out,

@@ -25,6 +25,8 @@ _SIGNATURES = {
     "ss_concat_volume_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_warp_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_concat_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_stem_left_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_stem_left_fused_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_warp_correlation_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_disparity_regression_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "ss_disparity_regression_bwd": [_P, _P, _I, _I, _I, _I, _P],

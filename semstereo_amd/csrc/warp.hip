@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
 
     float g[VEC];
     if (MODE == MODE_CONCAT && gate != nullptr) load_vec<VEC>(gate + (b * nd + j) * plane + pix, g);
-    const int CO = (MODE == MODE_CONCAT) ? 2 * C : C;
+    const bool both = (MODE == MODE_CONCAT) && (x != nullptr);     // MODE_CONCAT with x == null: the gated right half alone
+    const int CO = both ? 2 * C : C;
 #pragma unroll 4
     for (int c = 0; c < C; ++c) {
         const float* yp = y + (b * C + c) * plane;
@@ -150,14 +151,20 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
                 store_vec<VEC>(out1 + ((b * CO + c) * nd + j) * plane + pix, xv, nt);
             }
         } else {
-            float xv[VEC];
-            load_vec<VEC>(x + (b * C + c) * plane + pix, xv);
             if (gate != nullptr) {
 #pragma unroll
-                for (int p = 0; p < VEC; ++p) { xv[p] = ss::mul_rn(g[p], xv[p]); wv[p] = ss::mul_rn(g[p], wv[p]); }
+                for (int p = 0; p < VEC; ++p) wv[p] = ss::mul_rn(g[p], wv[p]);
             }
-            store_vec<VEC>(out0 + ((b * CO + c) * nd + j) * plane + pix, xv, nt);
-            store_vec<VEC>(out0 + ((b * CO + C + c) * nd + j) * plane + pix, wv, nt);
+            if (both) {
+                float xv[VEC];
+                load_vec<VEC>(x + (b * C + c) * plane + pix, xv);
+                if (gate != nullptr) {
+#pragma unroll
+                    for (int p = 0; p < VEC; ++p) xv[p] = ss::mul_rn(g[p], xv[p]);
+                }
+                store_vec<VEC>(out0 + ((b * CO + c) * nd + j) * plane + pix, xv, nt);
+            }
+            store_vec<VEC>(out0 + ((b * CO + (both ? C : 0) + c) * nd + j) * plane + pix, wv, nt);
         }
     }
 }
@@ -177,7 +184,7 @@ int launch(const float* x, const float* y, const float* disp, const float* gate,
     const long long total = (long long)B * nd * H * (v4 ? W / 4 : W);
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
-    const int planes = (MODE == MODE_CORR) ? 1 : (MODE == MODE_CONCAT || out1 != nullptr) ? 2 * C : C;
+    const int planes = (MODE == MODE_CORR) ? 1 : ((MODE == MODE_CONCAT && x != nullptr) || out1 != nullptr) ? 2 * C : C;
     int nt = (size_t)B * planes * nd * H * W * sizeof(float) > ((size_t)192 << 20);
     if (const char* f = getenv("SS_WARP_STREAM")) nt = f[0] == '1';      // tuning aid
     if (v4)
@@ -200,7 +207,7 @@ extern "C" int ss_warp_sampled_fwd(const float* x, const float* y, const float* 
 
 extern "C" int ss_concat_sampled_fwd(const float* left, const float* right, const float* disp, const float* att,
                                      float* out, int B, int C, int H, int W, int nd, ss_stream_t stream) {
-    SS_REQUIRE(left && right && disp && out);
+    SS_REQUIRE(right && disp && out);                    // left == NULL: only the right half, out [B,C,nd,H,W]
     SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nd > 0);
     return launch<MODE_CONCAT>(left, right, disp, att, out, nullptr, B, C, H, W, nd, ss::as_stream(stream));
 }

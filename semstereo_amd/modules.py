@@ -326,6 +326,44 @@ class BasicConv(nn.Module):
         return x
 
 
+STEM_LEFT_FUSED = os.environ.get("SS_STEM_LEFT_FUSED", "1") != "0"     # Q of the broadcast half on the fly (one launch) or through HBM (two)
+
+
+def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate_logits=None):
+    """`stem` (a 3x3x3 stride-1 BasicConv with 2C input channels) applied to cat(att * left broadcast over the
+    candidates, right_vol) WITHOUT building the left half of that volume or convolving it: by linearity its
+    contribution is sum_tap att[pos+tap] * Q[tap](pos+tap), Q = a 1x1 projection of the 2-D map `left` [B,C,H,W]
+    (3.6 instead of 87 GFLOP on the bench shape), which enters the right half's convolution as its residual
+    operand (models/SemStereo.py:241-244, 316-320).  Split-bf16 engines, inference only."""
+    assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, left, att, right_vol, gate_logits)
+    conv, bn = stem.conv, stem.bn if stem.use_bn else None
+    Cout, C = conv.out_channels, right_vol.shape[1]
+    assert conv.in_channels == 2 * C and left.shape[1] == C and _conv_geometry(conv) == (3, 1)
+    nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+    srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+    def build():
+        sc, sh = fold_bn(bn) if bn is not None else (torch.ones(Cout, device=conv.weight.device), None)
+        w = conv.weight.detach().float()
+        # Q weights [tap * Cout + co][c] = scale[co] * W[co, c, tap]: the residual operand is added after the affine
+        wl = w[:, :C].reshape(Cout, C, 27) * sc.reshape(Cout, 1, 1)
+        wq = wl.permute(2, 0, 1).reshape(27 * Cout, C)                           # row tap*Cout + co (two-launch form)
+        # fused form: per pair of output channels 64 rows, row tap*2 + c = channel 2*pair + c, rows 54-63 zero
+        wf = torch.zeros(Cout // 2, 64, C, dtype=w.dtype, device=w.device)
+        wf[:, :54] = wl.reshape(Cout // 2, 2, C, 27).permute(0, 3, 1, 2).reshape(Cout // 2, 54, C)
+        return (pack_pointwise_weight_bf16s(wq), pack_pointwise_weight_bf16s(wf.reshape(Cout // 2 * 64, C)),
+                pack_conv_weight_bf16s(w[:, C:].contiguous()), sc, sh)
+    wq, wf, wr, scale, shift = _cache(stem).get("bc/halves", srcs, build)
+    PATH_COUNTS["hip"] += 1
+    if C == 32 and Cout % 2 == 0 and STEM_LEFT_FUSED:
+        resid = ops.stem_left_fused(left, wf, att, Cout, nterms)                                 # [B, Cout, nd, H, W]
+    else:
+        q = conv3d_pointwise_bf16s_hip(left, wq, 27 * Cout, None, None, False, nterms)           # [B, 27*Cout, H, W]
+        resid = ops.stem_left(q, att)
+    g = None if gate_logits is None else torch.sigmoid(gate_logits).contiguous()
+    return conv3d_bf16s_hip(right_vol, wr, Cout, scale, shift, bool(stem.relu), nterms, resid, g)
+
+
 ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launches) | "fused" (one kernel per window)
 
 

@@ -326,15 +326,45 @@ def concat_volume_sampled(left, right, disparity_samples, att=None):
     """Fused SemStereo.concat_volume_generator + `att_topk * volume` (models/SemStereo.py:241-244,
     316-318): -> [B, 2C, nd, H, W] = att * cat(left broadcast, warp(right)).  att is [B,1,nd,H,W],
     [B,nd,H,W] or None.  Inference only."""
-    left, right, disp = _c(left), _c(right), _c(disparity_samples)
+    right, disp = _c(right), _c(disparity_samples)
+    left = None if left is None else _c(left)            # None: only the right half, [B, C, nd, H, W]
     if att is not None:
         att = _c(att.reshape(att.shape[0], att.shape[-3], att.shape[-2], att.shape[-1]))
     dev = _lib.require_device(left, right, disp, att)
-    B, C, H, W = left.shape
+    B, C, H, W = right.shape
     nd = disp.shape[1]
-    out = torch.empty((B, 2 * C, nd, H, W), dtype=left.dtype, device=left.device)
+    out = torch.empty((B, (2 if left is not None else 1) * C, nd, H, W), dtype=right.dtype, device=right.device)
     with torch.cuda.device(dev):
         call("ss_concat_sampled_fwd", ptr(left), ptr(right), ptr(disp), ptr(att), ptr(out), B, C, H, W, nd)
+    return out
+
+
+def stem_left(q, att):
+    """Left (broadcast) half of concat_stem by linearity (stem_left.hip): q [B, 27*Cout, H, W] = the 1x1
+    projections of the 2-D left features onto the stem's left-half weights, att [B,1,nd,H,W] or [B,nd,H,W]
+    -> [B, Cout, nd, H, W] = sum_tap att[pos + tap] * q[tap, :, (pos + tap).hw].  Inference only."""
+    q = _c(q)
+    att = _c(att.reshape(att.shape[0], att.shape[-3], att.shape[-2], att.shape[-1]))
+    dev = _lib.require_device(q, att)
+    B, nd, H, W = att.shape
+    assert q.shape[0] == B and q.shape[1] % 27 == 0 and tuple(q.shape[2:]) == (H, W)
+    Cout = q.shape[1] // 27
+    out = torch.empty((B, Cout, nd, H, W), dtype=q.dtype, device=q.device)
+    with torch.cuda.device(dev):
+        call("ss_stem_left_fwd", ptr(q), ptr(att), ptr(out), B, Cout, nd, H, W)
+    return out
+
+
+def stem_left_fused(left, wsplit, att, Cout, nterms=6):
+    """stem_left with q never materialised: left [B,32,H,W], wsplit = the pair-major packed left-half weights
+    (modules.stem_of_broadcast_and_volume builds them), att [B,1,nd,H,W] or [B,nd,H,W] -> [B,Cout,nd,H,W]."""
+    left = _c(left)
+    att = _c(att.reshape(att.shape[0], att.shape[-3], att.shape[-2], att.shape[-1]))
+    dev = _lib.require_device(left, att)
+    B, nd, H, W = att.shape
+    out = torch.empty((B, Cout, nd, H, W), dtype=left.dtype, device=left.device)
+    with torch.cuda.device(dev):
+        call("ss_stem_left_fused_fwd", ptr(left), ptr(wsplit), ptr(att), ptr(out), B, left.shape[1], Cout, nd, H, W, int(nterms))
     return out
 
 

@@ -43,6 +43,7 @@ class HotSegment(nn.Module):
     #: PyTorch glue in between) also in inference -- what a reference model gets from `install()` +
     #: `accelerate()` alone, with its forward() untouched.  True: the fused kernels of this file.
     FUSED = os.environ.get("SS_FUSED", "1") != "0"
+    STEM_BY_HALVES = os.environ.get("SS_STEM_HALVES", "1") != "0"      # concat_stem's broadcast half by linearity
 
     def __init__(self, maxdisp, c8=256, c4=128):
         super().__init__()
@@ -122,8 +123,14 @@ class HotSegment(nn.Module):
         fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, att_topk)
         if fast:
             cl, cr, gate4 = prelude if prelude is not None else HotSegment.matching_prelude(self, fl4, fr4)
-            volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                      # :316 + :318 fused
-            volume = self.concat_stem(volume, gate4)                                           # :319 + :320 fused
+            if M.CONV_ENGINE != "f32" and samples.shape[1] in (6, 24, 32) and HotSegment.STEM_BY_HALVES:
+                # the left half of the volume is the 2-D map `cl` broadcast over the candidates: neither built
+                # nor convolved (modules.stem_of_broadcast_and_volume); only the warped right half is a volume
+                right = ops.concat_volume_sampled(None, cr, samples, att_topk)                 # :316 + :318, right half
+                volume = M.stem_of_broadcast_and_volume(self.concat_stem, cl, att_topk, right, gate4)   # :319 + :320
+            else:
+                volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                  # :316 + :318 fused
+                volume = self.concat_stem(volume, gate4)                                       # :319 + :320 fused
         else:
             cl = self.concat_feature(fl4)                                                      # :314
             cr = self.concat_feature(fr4)                                                      # :315

@@ -423,6 +423,55 @@ def test_pointwise_split_bf16(sa, case, nterms):
     assert e <= (2e-6 if nterms == 6 else 4e-5), e
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 24, 9, 37), (1, 32, 6, 5, 70), (1, 32, 32, 3, 3)])
+def test_stem_by_halves_equals_the_full_convolution(sa, shape):
+    """concat_stem on cat(att * left broadcast over the candidates, right volume) (models/SemStereo.py:241-244,
+    316-320) computed by linearity -- 1x1 projection of the 2-D left map + 27 multiply-adds per output as the
+    residual of the right half's conv -- against the float64 convolution of the materialised 64-channel volume."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, C, nd, H, W = shape
+    left = dd.t_normalish((B, C, H, W), 301)
+    right = dd.t_normalish((B, C, nd, H, W), 302)
+    att = dd.t_uniform((B, 1, nd, H, W), 303, 0.0, 1.0)
+    gate = dd.t_normalish((B, C, H, W), 304)
+    stem = sa.modules.BasicConv(2 * C, C, is_3d=True, kernel_size=3, stride=1, padding=1)
+    with torch.no_grad():
+        stem.conv.weight.copy_(dd.t_uniform((C, 2 * C, 3, 3, 3), 305, -1, 1) * (3.0 / (2 * C * 27)) ** 0.5)
+        stem.bn.weight.copy_(dd.t_uniform((C,), 306, 0.6, 1.4)); stem.bn.bias.copy_(dd.t_uniform((C,), 307, -0.1, 0.1))
+        stem.bn.running_mean.copy_(dd.t_uniform((C,), 308, -0.1, 0.1)); stem.bn.running_var.copy_(dd.t_uniform((C,), 309, 0.6, 1.4))
+    stem = stem.cuda().eval()
+    vol = torch.cat((att * left.unsqueeze(2).expand(B, C, nd, H, W), right), dim=1)
+    sc, sh = sa.modules.fold_bn(stem.bn)
+    ref = F.conv3d(vol.double(), stem.conv.weight.detach().cpu().double(), None, 1, 1)
+    ref = F.relu(ref * sc.cpu().double().reshape(1, -1, 1, 1, 1) + sh.cpu().double().reshape(1, -1, 1, 1, 1))
+    ref = torch.sigmoid(gate.double()).unsqueeze(2) * ref
+    with torch.no_grad():
+        y = sa.modules.stem_of_broadcast_and_volume(stem, dev(left), dev(att), dev(right), dev(gate))
+        full = stem(dev(vol), dev(gate))
+    e_halves, e_full = float((y.double().cpu() - ref).abs().max()), float((full.double().cpu() - ref).abs().max())
+    REPORT[f"stem_halves/{shape}"] = e_halves
+    REPORT[f"stem_full/{shape}"] = e_full
+    assert e_halves <= 2.0 * e_full + 1e-6, (e_halves, e_full)
+    # the residual operand alone against the float64 convolution of the left half
+    wl = stem.conv.weight.detach().cpu().double()[:, :C] * sc.cpu().double().reshape(-1, 1, 1, 1, 1)
+    want = F.conv3d((att * left.unsqueeze(2)).double(), wl, None, 1, 1)
+    wq = (stem.conv.weight.detach().float()[:, :C].reshape(C, C, 27) * sc.reshape(C, 1, 1)).permute(2, 0, 1).reshape(27 * C, C)
+    q = sa.modules.conv3d_pointwise_bf16s_hip(dev(left), sa.modules.pack_pointwise_weight_bf16s(wq), 27 * C, None, None, False, 6)
+    got = sa.ops.stem_left(q, dev(att))
+    assert float((got.double().cpu() - want).abs().max()) <= 2e-6
+    # both forms of the residual (Q through HBM / on the fly) inside the whole stem
+    old = sa.modules.STEM_LEFT_FUSED
+    try:
+        for flag in (False, True):
+            sa.modules.STEM_LEFT_FUSED = flag
+            with torch.no_grad():
+                yy = sa.modules.stem_of_broadcast_and_volume(stem, dev(left), dev(att), dev(right), dev(gate))
+            assert float((yy.double().cpu() - ref).abs().max()) <= 2.0 * e_full + 1e-6, flag
+    finally:
+        sa.modules.STEM_LEFT_FUSED = old
+
+
 HEAD_CASES = [
     # (B, Cin, D, H, W, relu): the 32 -> 1 classifier heads; W not a multiple of 30, both tile shapes, tiny volumes
     (2, 32, 5, 9, 37, False),
