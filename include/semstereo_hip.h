@@ -182,6 +182,13 @@ int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const float* scale,
                         const float* residual, const float* gate, float* out,
                         int B, int Cin, int D, int H, int W, int Cout, int stride, int relu, int nterms,
                         ss_stream_t stream);
+/* The same convolution continuing a PARTIAL SUM: out = gate * relu?(scale * (partial + conv(in)) + shift), partial
+ * [B,Cout,D,H,W] = the contribution of input channels that are not in `in` (ss_stem_left_fused_fwd: the broadcast
+ * half of concat_stem's input).  It initialises the accumulators, read under the first chunk's staging. */
+int ss_conv3d_bf16s_partial_fwd(const float* in, const void* wsplit, const float* partial, const float* scale,
+                                const float* shift, const float* gate, float* out,
+                                int B, int Cin, int D, int H, int W, int Cout, int relu, int nterms,
+                                ss_stream_t stream);
 /* Conv3d weight [Cout,Cin,3,3,3] fp32 -> split/packed bf16 fragments
  * [ceil(Cin/8)][14 tap pairs][3 terms][2 halves][Cout][8] (ceil(Cin/8)*14*3*2*Cout*16 bytes). */
 int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);

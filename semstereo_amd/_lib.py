@@ -39,6 +39,7 @@ _SIGNATURES = {
     "ss_ssr_upsample_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_bf16s_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_conv3d_bf16s_partial_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_weights_bf16s": [_P, _P, _I, _I, _P],
     "ss_conv3d_head_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_head_weights_bf16s": [_P, _P, _I, _P],

@@ -109,11 +109,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     const int dzw = (wave * NT) / TH, hy0 = (wave * NT) % TH;
     const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + l31 * S;     // slot of this lane's first row, tap (0,0,0)
 
+    // relu bit 0: ReLU; bit 1: `residual` is added BEFORE the affine, i.e. it is the initial value of the accumulator
+    // (a partial sum of the same convolution computed elsewhere, stem_left.hip).  It is then read here, under the
+    // first chunk's staging, instead of in the epilogue where nothing hides its latency.
+    const bool res_pre = (relu & 2) != 0 && residual != nullptr;
     f32x16 acc[NT];
+    if (res_pre) {
+        const int ow_ = min(ow0 + l31, Wo - 1), od_ = min(od0 + dzw, Do - 1);
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i) {
+            const int oh_ = min(oh0 + hy0 + i, Ho - 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int co = min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
+                acc[i][r] = residual[(((size_t)b * Cout + co) * Do + od_) * ((size_t)Ho * Wo) + (size_t)oh_ * Wo + ow_];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
 
     const size_t in_plane = (size_t)H * W, chan = (size_t)D * in_plane;
     const float* inb = in + (size_t)b * Cin * chan;
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
             for (int i = 0; i < NT; ++i) {
                 const int oh = min(oh0 + hy0 + i, Ho - 1);
                 gv[q][i] = GATED ? gate[(((size_t)b * Cout + co) * Ho + oh) * Wo + ow] : 1.0f;
-                rv[q][i] = residual ? residual[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] : 0.0f;
+                rv[q][i] = (residual && !res_pre) ? residual[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] : 0.0f;
             }
         }
 #pragma unroll
@@ -319,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                 const int oh = oh0 + hy0 + i;
                 if (oh >= Ho) continue;
                 float v = ss::add_rn(ss::mul_rn(acc[i][r], sc[q]), sh[q]);
-                if (residual) v = ss::add_rn(v, rv[q][i]);
-                if (relu) v = fmaxf(v, 0.f);
+                if (residual && !res_pre) v = ss::add_rn(v, rv[q][i]);
+                if (relu & 1) v = fmaxf(v, 0.f);
                 if (GATED) v = ss::mul_rn(gv[q][i], v);     // channelAtt gate, broadcast over D
                 out[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] = v;
             }
@@ -378,7 +395,26 @@ int launch_b(const float* in, const void* wsplit, const float* scale, const floa
 
 }  // namespace
 
+static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* scale, const float* shift,
+                             const float* residual, const float* gate, float* out, int B, int Cin, int D, int H,
+                             int W, int Cout, int stride, int relu, int nterms, ss_stream_t stream);
+
 extern "C" int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                   const float* residual, const float* gate, float* out, int B, int Cin, int D, int H,
+                                   int W, int Cout, int stride, int relu, int nterms, ss_stream_t stream) {
+    return conv3d_bf16s_impl(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, stride, relu ? 1 : 0, nterms,
+                             stream);
+}
+
+extern "C" int ss_conv3d_bf16s_partial_fwd(const float* in, const void* wsplit, const float* partial, const float* scale,
+                                           const float* shift, const float* gate, float* out, int B, int Cin, int D,
+                                           int H, int W, int Cout, int relu, int nterms, ss_stream_t stream) {
+    SS_REQUIRE(partial != nullptr);
+    return conv3d_bf16s_impl(in, wsplit, scale, shift, partial, gate, out, B, Cin, D, H, W, Cout, 1, (relu ? 1 : 0) | 2, nterms,
+                             stream);
+}
+
+static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* scale, const float* shift,
                                    const float* residual, const float* gate, float* out, int B, int Cin, int D, int H,
                                    int W, int Cout, int stride, int relu, int nterms, ss_stream_t stream) {
     SS_REQUIRE(in && wsplit && out);

@@ -147,17 +147,23 @@ def pack_conv_weight_bf16s(w):
     return out
 
 
-def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None, gate=None):
-    """3x3x3 stride-1 Conv3d + affine + optional residual / ReLU on the split-bf16 engine."""
+def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None, gate=None, partial=None):
+    """3x3x3 stride-1 Conv3d + affine + optional residual / ReLU on the split-bf16 engine.  `partial`
+    [B,Cout,D,H,W]: a partial sum of the same convolution (other input channels), added BEFORE the affine."""
     x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, scale, shift, residual, gate)
+    dev = _lib.require_device(x, scale, shift, residual, gate, partial)
     B, Cin, D, H, W = x.shape
     out = torch.empty((B, Cout, D, H, W), dtype=x.dtype, device=x.device)
     if gate is not None:
         assert gate.shape == (B, Cout, H, W) and gate.is_contiguous()
     with torch.cuda.device(dev):
-        call("ss_conv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(gate), ptr(out),
-             B, Cin, D, H, W, Cout, 1, int(relu), int(nterms))
+        if partial is not None:
+            assert residual is None and partial.shape == out.shape and partial.is_contiguous()
+            call("ss_conv3d_bf16s_partial_fwd", ptr(x), ptr(wsplit), ptr(partial), ptr(scale), ptr(shift), ptr(gate), ptr(out),
+                 B, Cin, D, H, W, Cout, int(relu), int(nterms))
+        else:
+            call("ss_conv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(gate), ptr(out),
+                 B, Cin, D, H, W, Cout, 1, int(relu), int(nterms))
     return out
 
 
@@ -333,8 +339,8 @@ def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate_logits=None):
     """`stem` (a 3x3x3 stride-1 BasicConv with 2C input channels) applied to cat(att * left broadcast over the
     candidates, right_vol) WITHOUT building the left half of that volume or convolving it: by linearity its
     contribution is sum_tap att[pos+tap] * Q[tap](pos+tap), Q = a 1x1 projection of the 2-D map `left` [B,C,H,W]
-    (3.6 instead of 87 GFLOP on the bench shape), which enters the right half's convolution as its residual
-    operand (models/SemStereo.py:241-244, 316-320).  Split-bf16 engines, inference only."""
+    (3.6 instead of 87 GFLOP on the bench shape), which initialises the accumulators of the right half's
+    convolution (models/SemStereo.py:241-244, 316-320).  Split-bf16 engines, inference only."""
     assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, left, att, right_vol, gate_logits)
     conv, bn = stem.conv, stem.bn if stem.use_bn else None
     Cout, C = conv.out_channels, right_vol.shape[1]
@@ -343,10 +349,9 @@ def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate_logits=None):
     srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
     def build():
-        sc, sh = fold_bn(bn) if bn is not None else (torch.ones(Cout, device=conv.weight.device), None)
+        sc, sh = fold_bn(bn) if bn is not None else (None, None)
         w = conv.weight.detach().float()
-        # Q weights [tap * Cout + co][c] = scale[co] * W[co, c, tap]: the residual operand is added after the affine
-        wl = w[:, :C].reshape(Cout, C, 27) * sc.reshape(Cout, 1, 1)
+        wl = w[:, :C].reshape(Cout, C, 27)           # the left half's weights, unscaled: its sum joins the accumulator
         wq = wl.permute(2, 0, 1).reshape(27 * Cout, C)                           # row tap*Cout + co (two-launch form)
         # fused form: per pair of output channels 64 rows, row tap*2 + c = channel 2*pair + c, rows 54-63 zero
         wf = torch.zeros(Cout // 2, 64, C, dtype=w.dtype, device=w.device)
@@ -361,7 +366,7 @@ def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate_logits=None):
         q = conv3d_pointwise_bf16s_hip(left, wq, 27 * Cout, None, None, False, nterms)           # [B, 27*Cout, H, W]
         resid = ops.stem_left(q, att)
     g = None if gate_logits is None else torch.sigmoid(gate_logits).contiguous()
-    return conv3d_bf16s_hip(right_vol, wr, Cout, scale, shift, bool(stem.relu), nterms, resid, g)
+    return conv3d_bf16s_hip(right_vol, wr, Cout, scale, shift, bool(stem.relu), nterms, None, g, partial=resid)
 
 
 ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launches) | "fused" (one kernel per window)

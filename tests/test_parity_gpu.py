@@ -454,9 +454,9 @@ def test_stem_by_halves_equals_the_full_convolution(sa, shape):
     REPORT[f"stem_full/{shape}"] = e_full
     assert e_halves <= 2.0 * e_full + 1e-6, (e_halves, e_full)
     # the residual operand alone against the float64 convolution of the left half
-    wl = stem.conv.weight.detach().cpu().double()[:, :C] * sc.cpu().double().reshape(-1, 1, 1, 1, 1)
+    wl = stem.conv.weight.detach().cpu().double()[:, :C]
     want = F.conv3d((att * left.unsqueeze(2)).double(), wl, None, 1, 1)
-    wq = (stem.conv.weight.detach().float()[:, :C].reshape(C, C, 27) * sc.reshape(C, 1, 1)).permute(2, 0, 1).reshape(27 * C, C)
+    wq = stem.conv.weight.detach().float()[:, :C].reshape(C, C, 27).permute(2, 0, 1).reshape(27 * C, C)
     q = sa.modules.conv3d_pointwise_bf16s_hip(dev(left), sa.modules.pack_pointwise_weight_bf16s(wq), 27 * C, None, None, False, 6)
     got = sa.ops.stem_left(q, dev(att))
     assert float((got.double().cpu() - want).abs().max()) <= 2e-6
