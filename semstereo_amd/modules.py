@@ -335,17 +335,10 @@ class BasicConv(nn.Module):
 STEM_LEFT_FUSED = os.environ.get("SS_STEM_LEFT_FUSED", "1") != "0"     # Q of the broadcast half on the fly (one launch) or through HBM (two)
 
 
-def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate_logits=None):
-    """`stem` (a 3x3x3 stride-1 BasicConv with 2C input channels) applied to cat(att * left broadcast over the
-    candidates, right_vol) WITHOUT building the left half of that volume or convolving it: by linearity its
-    contribution is sum_tap att[pos+tap] * Q[tap](pos+tap), Q = a 1x1 projection of the 2-D map `left` [B,C,H,W]
-    (3.6 instead of 87 GFLOP on the bench shape), which initialises the accumulators of the right half's
-    convolution (models/SemStereo.py:241-244, 316-320).  Split-bf16 engines, inference only."""
-    assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, left, att, right_vol, gate_logits)
+def _stem_halves_params(stem, C):
     conv, bn = stem.conv, stem.bn if stem.use_bn else None
-    Cout, C = conv.out_channels, right_vol.shape[1]
-    assert conv.in_channels == 2 * C and left.shape[1] == C and _conv_geometry(conv) == (3, 1)
-    nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+    Cout = conv.out_channels
+    assert conv.in_channels == 2 * C and _conv_geometry(conv) == (3, 1)
     srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
     def build():
@@ -358,15 +351,40 @@ def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate_logits=None):
         wf[:, :54] = wl.reshape(Cout // 2, 2, C, 27).permute(0, 3, 1, 2).reshape(Cout // 2, 54, C)
         return (pack_pointwise_weight_bf16s(wq), pack_pointwise_weight_bf16s(wf.reshape(Cout // 2 * 64, C)),
                 pack_conv_weight_bf16s(w[:, C:].contiguous()), sc, sh)
-    wq, wf, wr, scale, shift = _cache(stem).get("bc/halves", srcs, build)
+    return _cache(stem).get("bc/halves", srcs, build)
+
+
+def stem_broadcast_half(stem, left, att):
+    """Partial sum of `stem` over its first C input channels when they are att * (the 2-D map `left` [B,C,H,W]
+    broadcast over the candidates): sum_tap att[pos+tap] * Q[tap](pos+tap), Q = a 1x1 projection of `left`
+    (3.6 instead of 87 GFLOP on the bench shape).  -> [B,Cout,nd,H,W], no BatchNorm / ReLU applied."""
+    assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, left, att)
+    C, Cout = left.shape[1], stem.conv.out_channels
+    nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+    wq, wf, _, _, _ = _stem_halves_params(stem, C)
     PATH_COUNTS["hip"] += 1
     if C == 32 and Cout % 2 == 0 and STEM_LEFT_FUSED:
-        resid = ops.stem_left_fused(left, wf, att, Cout, nterms)                                 # [B, Cout, nd, H, W]
-    else:
-        q = conv3d_pointwise_bf16s_hip(left, wq, 27 * Cout, None, None, False, nterms)           # [B, 27*Cout, H, W]
-        resid = ops.stem_left(q, att)
+        return ops.stem_left_fused(left, wf, att, Cout, nterms)
+    q = conv3d_pointwise_bf16s_hip(left, wq, 27 * Cout, None, None, False, nterms)               # [B, 27*Cout, H, W]
+    return ops.stem_left(q, att)
+
+
+def stem_volume_half(stem, right_vol, partial, gate_logits=None):
+    """`stem` over its last C input channels (`right_vol` [B,C,nd,H,W]) continuing `partial`, then BatchNorm, ReLU
+    and the optional channelAtt gate on the total."""
+    assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, right_vol, partial, gate_logits)
+    nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+    _, _, wr, scale, shift = _stem_halves_params(stem, right_vol.shape[1])
     g = None if gate_logits is None else torch.sigmoid(gate_logits).contiguous()
-    return conv3d_bf16s_hip(right_vol, wr, Cout, scale, shift, bool(stem.relu), nterms, None, g, partial=resid)
+    return conv3d_bf16s_hip(right_vol, wr, stem.conv.out_channels, scale, shift, bool(stem.relu), nterms, None, g, partial=partial)
+
+
+def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate_logits=None):
+    """`stem` (a 3x3x3 stride-1 BasicConv with 2C input channels) applied to cat(att * left broadcast over the
+    candidates, right_vol) WITHOUT building the left half of that volume or convolving it: by linearity its
+    contribution (stem_broadcast_half) initialises the accumulators of the right half's convolution
+    (stem_volume_half) (models/SemStereo.py:241-244, 316-320).  Split-bf16 engines, inference only."""
+    return stem_volume_half(stem, right_vol, stem_broadcast_half(stem, left, att), gate_logits)
 
 
 ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launches) | "fused" (one kernel per window)

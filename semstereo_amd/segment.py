@@ -126,8 +126,9 @@ class HotSegment(nn.Module):
             if M.CONV_ENGINE != "f32" and samples.shape[1] in (6, 24, 32) and HotSegment.STEM_BY_HALVES:
                 # the left half of the volume is the 2-D map `cl` broadcast over the candidates: neither built
                 # nor convolved (modules.stem_of_broadcast_and_volume); only the warped right half is a volume
-                right = ops.concat_volume_sampled(None, cr, samples, att_topk)                 # :316 + :318, right half
-                volume = M.stem_of_broadcast_and_volume(self.concat_stem, cl, att_topk, right, gate4)   # :319 + :320
+                partial = M.stem_broadcast_half(self.concat_stem, cl, att_topk)                # :319, broadcast half
+                right = ops.concat_volume_sampled(None, cr, samples, att_topk)                 # :316 + :318, warped half
+                volume = M.stem_volume_half(self.concat_stem, right, partial, gate4)           # :319 + :320
             else:
                 volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                  # :316 + :318 fused
                 volume = self.concat_stem(volume, gate4)                                       # :319 + :320 fused
