@@ -7,7 +7,7 @@
 // (models/SemStereo.py:241-244, 316-318) and the 5-sample matching-strength probe
 // `mean_c(left * warp(right))` (:291-292).  The reference materialises a [B,nd,H,W,2] grid, a
 // repeated copy of the left map, the cat and the product: four full passes over the volume; here
-// each output element is written exactly once, 16 B per lane along W.
+// each output element is written exactly once (one column per lane; a float4-per-lane form is kept behind SS_WARP_VEC=4).
 //
 // Coordinates follow the reference's fp32 round trip exactly: gx = (w - disp)/((W-1)/2) - 1,
 // then grid_sample's align_corners=True un-normalisation ix = (gx + 1) * ((W-1)/2) (the ATen
