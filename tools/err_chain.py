@@ -38,6 +38,16 @@ seg.concat_stem.register_forward_hook(hook("stem"))
 seg.hourglass.register_forward_hook(hook("hourglass"))
 seg.classif.register_forward_hook(hook("cost"))
 seg.hourglass_att.register_forward_hook(hook("hourglass_att"))
+real_half = M.stem_volume_half
+
+
+def spy_half(*a, **k):            # concat_stem by halves does not go through concat_stem.forward
+    r = real_half(*a, **k)
+    cap["stem"] = r.detach().clone()
+    return r
+
+
+M.stem_volume_half = spy_half
 real = {n: getattr(ops, n) for n in ("sample_strength", "build_gwc_volume_norm")}
 
 
@@ -55,6 +65,7 @@ with torch.no_grad():
     out = seg(fl4, fr4, fl8, fr8)
 for n in real:
     setattr(ops, n, real[n])
+M.stem_volume_half = real_half
 
 P = {k: v.detach().cpu() for k, v in seg.state_dict().items()}
 cin = [t.cpu() for t in (fl4, fr4, fl8, fr8)]
