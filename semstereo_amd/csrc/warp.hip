@@ -48,11 +48,23 @@ __device__ __forceinline__ Taps make_taps(float disp, int h, int w, int H, int W
     return t;
 }
 
+// the two taps of a row are neighbours in memory: one 8-byte load (4-byte aligned) when both are inside
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void row_pair(const float* __restrict__ plane, int o_w, int o_e, float& vw, float& ve) {
+    if (o_w >= 0 && o_e >= 0) {
+        const f2u v = *reinterpret_cast<const f2u*>(plane + o_w);
+        vw = v.x;
+        ve = v.y;
+    } else {
+        vw = (o_w >= 0) ? plane[o_w] : 0.f;
+        ve = (o_e >= 0) ? plane[o_e] : 0.f;
+    }
+}
+
 __device__ __forceinline__ float sample(const float* __restrict__ plane, const Taps& t) {
-    const float a = (t.o_nw >= 0) ? plane[t.o_nw] : 0.f;
-    const float b = (t.o_ne >= 0) ? plane[t.o_ne] : 0.f;
-    const float c = (t.o_sw >= 0) ? plane[t.o_sw] : 0.f;
-    const float d = (t.o_se >= 0) ? plane[t.o_se] : 0.f;
+    float a, b, c, d;
+    row_pair(plane, t.o_nw, t.o_ne, a, b);
+    row_pair(plane, t.o_sw, t.o_se, c, d);
     float r = ss::mul_rn(a, t.w_nw);
     r = ss::add_rn(r, ss::mul_rn(b, t.w_ne));
     r = ss::add_rn(r, ss::mul_rn(c, t.w_sw));
