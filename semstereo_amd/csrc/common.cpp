@@ -15,7 +15,7 @@ void note_hip_error(hipError_t e) {
 }
 }  // namespace ss
 
-extern "C" int ss_abi_version(void) { return 2; }
+extern "C" int ss_abi_version(void) { return 3; }   // 3: + head / pointwise / partial-sum convs, attention core, stem_left
 
 extern "C" const char* ss_status_string(int status) {
     switch (status) {
