@@ -220,6 +220,14 @@ int ss_deconv3d_fwd(const float* in, const float* wpack, const float* scale, con
                     const float* skip, const float* skip_wpack, const float* skip_scale, const float* skip_shift,
                     float* out, int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu,
                     ss_stream_t stream);
+/* The same layer on the split-bf16 engine (deconv3d_bf16s.hip): wsplit / skip_wsplit come from
+ * ss_pack_deconv3d_weights_bf16s applied to the fp32 packs of ss_deconv3d_fwd (wpack [Cin][27][Cout] with the
+ * BatchNorm scale folded, ntaps = 27; skip_wpack [Cs][Cout], ntaps = 1); only a common shift is applied.
+ * wsplit: ceil(Cin/16)*ntaps*3*2*Cout*16 bytes. */
+int ss_deconv3d_bf16s_fwd(const float* in, const void* wsplit, const float* shift, const float* skip,
+                          const void* skip_wsplit, float* out, int B, int Cin, int D, int H, int W, int Cout,
+                          int Cs, int relu, int nterms, ss_stream_t stream);
+int ss_pack_deconv3d_weights_bf16s(const float* wpack, void* wsplit, int Cin, int Cout, int ntaps, ss_stream_t stream);
 /* Weight re-layout helpers (device to device): Conv3d weight [Cout,Cin,k,k,k] or
  * ConvTranspose3d weight [Cin,Cout,k,k,k] (transposed != 0) -> [Cin][k^3][Cout]. */
 int ss_pack_conv3d_weights(const float* w, float* wpack, int Cout, int Cin, int k, int transposed,

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "ss_conv3d_pointwise_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_longlong, _I, _I, _P],
     "ss_pack_pointwise_weights_bf16s": [_P, _P, _I, _I, _P],
     "ss_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_deconv3d_bf16s_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_pack_deconv3d_weights_bf16s": [_P, _P, _I, _I, _I, _P],
     "ss_pack_conv3d_weights": [_P, _P, _I, _I, _I, _I, _P],
     "ss_depthwise_patch_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

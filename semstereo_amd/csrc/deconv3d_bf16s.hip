@@ -1,0 +1,369 @@
+// ConvTranspose3d(k=3, s=2, p=1, output_padding=1) + folded BatchNorm + 1x1x1 skip projection + ReLU of
+// hourglass.forward (reference models/SemStereo.py:124-130, 141-142 / 163-169, 180-181) on the bf16 matrix core
+// with split-bf16 fp32 emulation: the parity-class formulation of deconv3d.hip (every one of the 27 taps feeds
+// exactly one of the 8 output parity classes at a fixed input offset, an INPUT-space tile, 8 accumulators per
+// wave) with the operand machinery of conv3d_bf16s.hip (x = hi + mid + lo bf16 terms, 6 cross products on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulation; error below the exact-fp32 MFMA's).
+//
+// A K-step is ONE tap x 16 input channels (lanes 0-31: channels 0-7, lanes 32-63: channels 8-15), so a chunk of 16
+// channels is 27 K-steps; the taps are visited grouped by their input offset (8 groups), so the activation fragment
+// of an offset is read from LDS once per chunk and feeds up to 8 taps, whose MFMAs go to 8 different accumulators.
+// LDS image: [term][channel half][position] 16-byte slots of the (TD+1) x (TH+1) x 33 input halo tile.  Weight
+// fragments stream from L2 two K-steps ahead (buffer loads), the next chunk's activations are register-prefetched in
+// slices over the K-steps.  The skip projection (redir) is two more K-steps per 16 skip channels with the operand
+// read straight from global memory (each lane's 2x2x2 output cube as four float2 per channel) and split in registers.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {       // lo16 = bf16(x0), hi16 = bf16(x1), RNE
+    const f32x2_t v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+
+// taps (kd*9 + kh*3 + kw) grouped by input offset o = (kd==0)*4 + (kh==0)*2 + (kw==0); class = (kd!=1)*4 + (kh!=1)*2 + (kw!=1)
+__host__ __device__ constexpr int tap_of(int s) {
+    constexpr int T[27] = {13, 14, 16, 17, 22, 23, 25, 26, 12, 15, 21, 24, 10, 11, 19, 20, 9, 18, 4, 5, 7, 8, 3, 6, 1, 2, 0};
+    return T[s];
+}
+__host__ __device__ constexpr int cls_of(int s) {
+    constexpr int T[27] = {0, 1, 2, 3, 4, 5, 6, 7, 1, 3, 5, 7, 2, 3, 6, 7, 3, 7, 4, 5, 6, 7, 5, 7, 6, 7, 7};
+    return T[s];
+}
+__host__ __device__ constexpr int off_of(int s) {
+    constexpr int T[27] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 4, 5, 5, 6, 6, 7};
+    return T[s];
+}
+
+constexpr int KST = 27;           // K-steps per 16-channel chunk
+
+template <int TD, int TH>
+struct DB {
+    static constexpr int ID = TD + 1, IH = TH + 1, IW = 33;
+    static constexpr int CS = ID * IH * IW;                    // positions of the halo tile
+    static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
+    static constexpr size_t LDS_BYTES = (size_t)3 * 2 * CS * 16;
+    static_assert(TD * TH == 4, "4 waves x one input row each");
+};
+
+template <int TD, int TH, int NTERMS, bool HAS_SKIP>
+__global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
+                                                          const float* __restrict__ shift, const float* __restrict__ skip,
+                                                          const uint4* __restrict__ skip_wsplit, float* __restrict__ out,
+                                                          int Cin, int D, int H, int W, int Cout, int Cs, int tiles_w,
+                                                          int tiles_h, int relu) {
+    using C = DB<TD, TH>;
+    constexpr int NC = (NTERMS == 6) ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [3 terms][2 channel halves][CS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    int t = blockIdx.x;
+    const int tw = t % tiles_w; t /= tiles_w;
+    const int th = t % tiles_h; t /= tiles_h;
+    const int iw0 = tw * 32, ih0 = th * TH, id0 = t * TD;
+    const int co0 = blockIdx.y * 32;
+    const int b = blockIdx.z;
+    const int dzw = wave / TH, hyw = wave % TH;
+    const int lane_pos = (dzw * C::IH + hyw) * C::IW + l31;        // this lane's position, offset (0,0,0)
+
+    f32x16 acc[8];                        // index pd*4 + ph*2 + pw
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const size_t in_plane = (size_t)H * W, chan = (size_t)D * in_plane;
+    const float* inb = in + (size_t)b * Cin * chan;
+
+    // staging plan: this thread owns positions p = tid + 256*i of the halo tile, all 16 channels of the chunk
+    unsigned poff[C::NPOS];
+#pragma unroll
+    for (int i = 0; i < C::NPOS; ++i) {
+        const int p = tid + 256 * i;
+        const int wx = p % C::IW;
+        int r = p / C::IW;
+        const int hy = r % C::IH, dz = r / C::IH;
+        const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz;
+        const bool ok = (p < C::CS) && gd < D && gh < H && gw < W;
+        poff[i] = ok ? (unsigned)(((size_t)gd * in_plane + (size_t)gh * W + gw) * 4) : 0x80000000u;     // beyond the buffer: reads 0
+    }
+    constexpr int NQ = 16 * C::NPOS;
+    constexpr int QS = (NQ + 19) / 20;                         // the next chunk's loads are issued over the first 20 K-steps
+    float rin[NQ];
+
+    const int nchunks = (Cin + 15) / 16;
+    const int G = nchunks * KST;
+    const int wlane = (half * Cout + min(co0 + l31, Cout - 1)) * 16;
+    const int wstep = 3 * 2 * Cout * 16;                       // bytes per K-step
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(wsplit), 0, (int)min((long long)G * wstep, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(inb), 0, (int)min((long long)Cin * (long long)chan * 4, 0x7fffffffLL), 0x00020000);
+    const int chan_b = (int)(chan * 4);
+    auto load_a = [&](int g, int c) {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, wlane, g * wstep + c * 2 * Cout * 16, 0));
+    };
+    // channels beyond Cin (ragged last chunk) lie beyond the buffer for the LAST positions only; clamp and zero instead
+    auto load_in = [&](int ch, int i) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], min(ch, Cin - 1) * chan_b, 0));
+    };
+    uint4 aq[3][NC];                      // aq[g % 3]
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aq[k][c] = load_a(min(k, G - 1), c);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) rin[q] = load_in(q / C::NPOS, q % C::NPOS);
+
+    const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+    const size_t out_plane = (size_t)Ho * Wo;
+    // Half of the workgroups project the skip tensor BEFORE the main loop, half after it: a grid whose workgroups all
+    // start together otherwise alternates between a phase where every CU multiplies and one where every CU waits for
+    // HBM (measured on the last layer of hourglass2: 173 us of main loop + 61 us of skip reads + 29 us of stores = the
+    // 263 us of the whole kernel, nothing overlapped).  Same sums, deterministic per workgroup.
+    auto skip_phase = [&]() {
+        // ---- 1x1x1 projection of the skip tensor at the 8 output positions of every lane: per 16 skip channels one K-step
+        // per parity class; the operand (8 channels x this lane's 2x2x2 cube) comes straight from global memory ----
+        const size_t schan = (size_t)Do * out_plane;
+        const int jw_ = min(iw0 + l31, W - 1), jd_ = min(id0 + dzw, D - 1), jh_ = min(ih0 + hyw, H - 1);
+        const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(skip + (size_t)b * Cs * schan), 0, (int)min((long long)Cs * (long long)schan * 4, 0x7fffffffLL), 0x00020000);
+        const int nks = (Cs + 15) / 16;
+        const __amdgpu_buffer_rsrc_t swres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint4*>(skip_wsplit), 0, nks * wstep, 0x00020000);
+        const unsigned lane_s = (unsigned)(((size_t)(2 * jd_) * out_plane + (size_t)(2 * jh_) * Wo + 2 * jw_) * 4);
+        const unsigned schan_b = (unsigned)(schan * 4);
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            bf16x8 a[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * wstep + c * 2 * Cout * 16, 0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                  // (pd, ph); the float2 holds pw = 0, 1
+                const unsigned qo = (unsigned)(((size_t)(q >> 1) * out_plane + (size_t)(q & 1) * Wo) * 4);
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int cs = ks * 16 + 8 * half + j;     // channels beyond Cs: a clamped (valid) address, value zeroed
+                    v[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                          sres, (int)(lane_s + qo + (unsigned)min(cs, Cs - 1) * schan_b), 0, 0));
+                    if (cs >= Cs) v[j] = make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int pw = 0; pw < 2; ++pw) {
+                    unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        split3_pk(pw ? v[2 * c].y : v[2 * c].x, pw ? v[2 * c + 1].y : v[2 * c + 1].x, bh[c], bm[c], bl[c]);
+                    const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                    const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+                    const int cls = q * 2 + pw;
+                    if (NTERMS == 6) {
+                        const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                        acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], m8, acc[cls], 0, 0, 0);
+                        acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], l8, acc[cls], 0, 0, 0);
+                        acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NC - 1], h8, acc[cls], 0, 0, 0);
+                    }
+                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], m8, acc[cls], 0, 0, 0);
+                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], h8, acc[cls], 0, 0, 0);
+                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], h8, acc[cls], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+
+    const bool skip_first = HAS_SKIP && ((blockIdx.x ^ blockIdx.y) & 1);
+#ifndef SS_ABL_D_SKIP
+    if (HAS_SKIP && skip_first) skip_phase();
+#endif
+#ifdef SS_ABL_D_MAIN
+    const int nchunks_run = 0;
+#else
+    const int nchunks_run = nchunks;
+#endif
+    for (int ck = 0, g0 = 0; ck < nchunks_run; ++ck, g0 += KST) {
+        const int ci0 = ck * 16;
+        // ---- split + transpose: registers -> [term][half][position] ----
+#pragma unroll
+        for (int i = 0; i < C::NPOS; ++i) {
+            const int p = tid + 256 * i;
+            if (p >= C::CS) continue;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int c0 = hf * 8 + 2 * c;
+                    split3_pk((ci0 + c0 < Cin) ? rin[c0 * C::NPOS + i] : 0.f, (ci0 + c0 + 1 < Cin) ? rin[(c0 + 1) * C::NPOS + i] : 0.f,
+                              hh[c], mm[c], ll[c]);
+                }
+                lds[(0 * 2 + hf) * C::CS + p] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                lds[(1 * 2 + hf) * C::CS + p] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+                if (NC == 3) lds[(2 * 2 + hf) * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+            }
+        }
+        __syncthreads();
+        const bool more = ck + 1 < nchunks;
+
+        uint4 bcur[NC], bnxt[NC];
+        auto read_b = [&](uint4 (&dst)[NC], int o) {
+            const int slot = lane_pos + (((o >> 2) & 1) * C::IH + ((o >> 1) & 1)) * C::IW + (o & 1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dst[c] = lds[(c * 2 + half) * C::CS + slot];
+        };
+        read_b(bcur, 0);
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            if (g0 + s + 2 < G) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) aq[(s + 2) % 3][c] = load_a(g0 + s + 2, c);
+            }
+            if (more) {
+#pragma unroll
+                for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q) rin[q] = load_in(ci0 + 16 + q / C::NPOS, q % C::NPOS);
+            }
+            // first tap of an offset group: fetch the next group's activation fragment
+            if ((s == 0 || off_of(s) != off_of(s - 1)) && off_of(s) < 7) read_b(bnxt, off_of(s) + 1);
+            bf16x8 a[NC], bq[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                a[c] = __builtin_bit_cast(bf16x8, aq[s % 3][c]);
+                bq[c] = __builtin_bit_cast(bf16x8, bcur[c]);
+            }
+            const int cls = cls_of(s);
+            if (NTERMS == 6) {
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[NC - 1], acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NC - 1], bq[0], acc[cls], 0, 0, 0);
+            }
+            acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], acc[cls], 0, 0, 0);
+            acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], acc[cls], 0, 0, 0);
+            acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[cls], 0, 0, 0);
+            // last tap of an offset group: the prefetched fragment becomes current
+            if (s + 1 < KST && off_of(s + 1) != off_of(s)) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bcur[c] = bnxt[c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // steps 27, 28 of this chunk are steps 0, 1 of the next: re-base the fragment ring (27 % 3 == 0: already in place)
+        __syncthreads();
+    }
+
+#ifndef SS_ABL_D_SKIP
+    if (HAS_SKIP && !skip_first) skip_phase();
+#endif
+
+    // ---- epilogue: each lane owns the 2x2x2 output cube of its input position ----
+    const int jw = iw0 + l31, jd = id0 + dzw, jh = ih0 + hyw;
+    if (jw >= W || jd >= D || jh >= H) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= Cout) continue;
+        const float sh = shift ? shift[co] : 0.0f;
+#pragma unroll
+        for (int pdh = 0; pdh < 4; ++pdh) {
+            const int od = 2 * jd + (pdh >> 1), oh = 2 * jh + (pdh & 1);
+            float v0 = ss::add_rn(acc[pdh * 2 + 0][r], sh);
+            float v1 = ss::add_rn(acc[pdh * 2 + 1][r], sh);
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            float* op = out + (((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + 2 * jw;
+#ifdef SS_ABL_D_STORE
+            if (v0 == 123456.f)
+#endif
+            *reinterpret_cast<float2*>(op) = make_float2(v0, v1);
+        }
+    }
+}
+
+// wpack [Cin][27][Cout] fp32 (ss_pack_conv3d_weights, transposed form, BN scale folded by the caller) ->
+// [ceil(Cin/16)][27 K-steps in offset-grouped tap order][3 terms][2 channel halves][Cout][8] bf16
+__global__ void pack_deconv_weights_kernel(const float* __restrict__ wpack, unsigned short* __restrict__ wsplit, int Cin,
+                                           int Cout, int ntaps, long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % 8);
+    long long r = i / 8;
+    const int co = (int)(r % Cout); r /= Cout;
+    const int hf = (int)(r % 2); r /= 2;
+    const int term = (int)(r % 3); r /= 3;
+    const int s = (int)(r % ntaps);
+    const int chunk = (int)(r / ntaps);
+    const int ci = chunk * 16 + hf * 8 + j;
+    const int tap = (ntaps == 27) ? tap_of(s) : 0;
+    const float x = (ci < Cin) ? wpack[((size_t)ci * ntaps + tap) * Cout + co] : 0.f;
+    unsigned h, m, l;
+    split3_pk(x, 0.f, h, m, l);
+    wsplit[i] = (unsigned short)((term == 0 ? h : (term == 1 ? m : l)) & 0xffffu);
+}
+
+template <int TD, int TH, int NTERMS, bool HAS_SKIP>
+int launch_db(const float* in, const void* wsplit, const float* shift, const float* skip, const void* skip_wsplit, float* out,
+              int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu, hipStream_t st) {
+    using C = DB<TD, TH>;
+    const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, TH), tiles_d = ss::ceil_div(D, TD);
+    const long long nt = (long long)tiles_w * tiles_h * tiles_d;
+    if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
+    auto kern = deconv3d_bf16s<TD, TH, NTERMS, HAS_SKIP>;
+    if (C::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+    }
+    dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32), B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), shift, skip,
+                       reinterpret_cast<const uint4*>(skip_wsplit), out, Cin, D, H, W, Cout, Cs, tiles_w, tiles_h, relu);
+    return ss::check_launch();
+}
+
+template <int TD, int TH>
+int launch_db_all(const float* in, const void* wsplit, const float* shift, const float* skip, const void* skip_wsplit,
+                  float* out, int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu, int nterms, hipStream_t st) {
+    if (skip != nullptr)
+        return nterms == 6 ? launch_db<TD, TH, 6, true>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st)
+                           : launch_db<TD, TH, 3, true>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st);
+    return nterms == 6 ? launch_db<TD, TH, 6, false>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st)
+                       : launch_db<TD, TH, 3, false>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st);
+}
+
+}  // namespace
+
+extern "C" int ss_pack_deconv3d_weights_bf16s(const float* wpack, void* wsplit, int Cin, int Cout, int ntaps, ss_stream_t stream) {
+    SS_REQUIRE(wpack && wsplit && Cin > 0 && Cout > 0 && (ntaps == 27 || ntaps == 1));
+    const long long total = (long long)((Cin + 15) / 16) * ntaps * 3 * 2 * Cout * 8;
+    hipLaunchKernelGGL(pack_deconv_weights_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0, ss::as_stream(stream),
+                       wpack, reinterpret_cast<unsigned short*>(wsplit), Cin, Cout, ntaps, total);
+    return ss::check_launch();
+}
+
+extern "C" int ss_deconv3d_bf16s_fwd(const float* in, const void* wsplit, const float* shift, const float* skip,
+                                     const void* skip_wsplit, float* out, int B, int Cin, int D, int H, int W, int Cout,
+                                     int Cs, int relu, int nterms, ss_stream_t stream) {
+    SS_REQUIRE(in && wsplit && out);
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE((skip == nullptr) || (skip_wsplit != nullptr && Cs > 0));
+    SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0 && (reinterpret_cast<uintptr_t>(skip_wsplit) & 15) == 0);
+    if ((reinterpret_cast<uintptr_t>(out) & 7) != 0) return SS_ERR_INVALID;
+    if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    if (skip != nullptr && (long long)Cs * 8 * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipStream_t st = ss::as_stream(stream);
+    if (D >= 2 && H < 4)
+        return launch_db_all<2, 2>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, nterms, st);
+    return launch_db_all<1, 4>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, nterms, st);
+}

@@ -127,12 +127,43 @@ def deconv3d_hip(x, wpack, shift, relu, skip=None, skip_wpack=None):
     return out
 
 
+def pack_deconv_weight_bf16s(wpack):
+    """fp32 pack [Cin][ntaps][Cout] (ntaps 27: transposed conv, BN scale folded; or [Cs][Cout]: the skip projection)
+    -> split-bf16 fragments for ss_deconv3d_bf16s_fwd."""
+    wpack = wpack.detach().float().contiguous()
+    _lib.require_device(wpack)
+    Cin, Cout = wpack.shape[0], wpack.shape[-1]
+    ntaps = 1 if wpack.dim() == 2 else wpack.shape[1]
+    out = torch.empty(((Cin + 15) // 16) * ntaps * 3 * 2 * Cout * 8, dtype=torch.int16, device=wpack.device)
+    with torch.cuda.device(wpack.device):
+        call("ss_pack_deconv3d_weights_bf16s", ptr(wpack), ptr(out), Cin, Cout, ntaps)
+    return out
+
+
+def deconv3d_bf16s_hip(x, wsplit, Cout, shift, relu, nterms, skip=None, skip_wsplit=None):
+    """deconv3d_hip on the split-bf16 engine."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, shift, skip)
+    B, Cin, D, H, W = x.shape
+    out = torch.empty((B, Cout, 2 * D, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+    Cs = 0
+    if skip is not None:
+        skip = skip if skip.is_contiguous() else skip.contiguous()
+        Cs = skip.shape[1]
+        assert skip.shape == (B, Cs, 2 * D, 2 * H, 2 * W)
+    with torch.cuda.device(dev):
+        call("ss_deconv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(shift), ptr(skip), ptr(skip_wsplit), ptr(out),
+             B, Cin, D, H, W, Cout, Cs, int(relu), int(nterms))
+    return out
+
+
 #: matrix-core engine of the 3x3x3 stride-1 convolutions: "f32" = exact-fp32 MFMA (conv3d.hip);
 #: "bf16x6" / "bf16x3" = split-bf16 (conv3d_bf16s.hip, fp32 operands as 3 bf16 terms, 6 or 3 cross
 #: products).  Everything else (stride 2, 1x1x1, transposed, Cout = 1) always runs the fp32 engine.
 #: Default bf16x6: its measured error against fp64 is BELOW the exact-fp32 MFMA's (1.1e-7 vs 1.8e-7 of
 #: sum|a*b|, tools/exp_split_bf16.hip) at ~1.5x its speed; SS_CONV_ENGINE=f32 selects the exact engine.
 CONV_ENGINE = os.environ.get("SS_CONV_ENGINE", "bf16x6")
+DECONV_BF16S = os.environ.get("SS_DECONV_BF16S", "1") != "0"     # transposed convs on the split engine too (else exact fp32 MFMA)
 
 
 def pack_conv_weight_bf16s(w):
@@ -533,8 +564,19 @@ class hourglass(nn.Module):
             rs, rb = fold_bn(rbn)
             wd = pack_conv_weight(dc.weight, transposed=True) * ds.reshape(1, 1, -1)
             wr = pack_conv_weight(rc.weight).reshape(rc.weight.shape[1], rc.weight.shape[0]) * rs.reshape(1, -1)
-            return wd.contiguous(), wr.contiguous(), (db + rb).contiguous()
+            wd, wr = wd.contiguous(), wr.contiguous()
+            return wd, wr, (db + rb).contiguous(), pack_deconv_weight_bf16s(wd), pack_deconv_weight_bf16s(wr)
         return _cache(self).get(key, srcs, build)
+
+    def _up(self, key, deconv_seq, redir_seq, x, skip):
+        wd, wr, shift, wds, wrs = self._up_params(key, deconv_seq, redir_seq)
+        B, _, D, H, W = x.shape
+        workgroups = B * D * ((H + 3) // 4) * ((W + 31) // 32) * ((wd.shape[2] + 31) // 32)
+        # layers with fewer workgroups than CUs: the exact-fp32 kernel's even/odd-plane split doubles them (67 vs 88 us on
+        # the bench's smallest layer); everything else: split-bf16
+        if CONV_ENGINE != "f32" and DECONV_BF16S and workgroups >= 256:
+            return deconv3d_bf16s_hip(x, wds, wd.shape[2], shift, True, 3 if CONV_ENGINE == "bf16x3" else 6, skip, wrs)
+        return deconv3d_hip(x, wd, shift, relu=True, skip=skip, skip_wpack=wr)
 
     def forward(self, x):
         if not _inference(self, x):
@@ -551,10 +593,8 @@ class hourglass(nn.Module):
         c3 = run_convbn(self, "c3", self.conv3[0][0], self.conv3[0][1], c2, relu=True)
         c4 = run_convbn(self, "c4", self.conv4[0][0], self.conv4[0][1], c3, relu=True)
         c4 = self.attention_block(c4)
-        w5, r2, s5 = self._up_params("u5", self.conv5, self.redir2)
-        c5 = deconv3d_hip(c4, w5, s5, relu=True, skip=c2, skip_wpack=r2)
-        w6, r1, s6 = self._up_params("u6", self.conv6, self.redir1)
-        return deconv3d_hip(c5, w6, s6, relu=True, skip=x, skip_wpack=r1)
+        c5 = self._up("u5", self.conv5, self.redir2, c4, c2)
+        return self._up("u6", self.conv6, self.redir1, c5, x)
 
 
 class hourglass2(hourglass):

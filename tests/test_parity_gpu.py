@@ -603,6 +603,36 @@ def test_deconv3d_kernel(sa, case, split, monkeypatch):
     check(f"deconv3d/{case}/split{split}", y, ref, 2e-4)
 
 
+@pytest.mark.parametrize("nterms", [6, 3])
+@pytest.mark.parametrize("case", [(128, 64, 2, 3, 5, 64), (64, 32, 3, 9, 33, 32), (32, 32, 2, 4, 40, 0), (8, 24, 2, 3, 6, 6), (20, 40, 1, 5, 34, 10)])
+def test_deconv3d_split_bf16_engine(sa, case, nterms):
+    """ConvTranspose3d + 1x1x1 skip projection + shift + ReLU on the split-bf16 engine (ragged channel chunks, Cout not a
+    multiple of 32, D = 1): the 6-product form as close to float64 as the exact-fp32 kernel, the 3-product form within 4e-5."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin, Cout, D, H, W, Cs = case
+    x = dd.t_normalish((2, Cin, D, H, W), 391)
+    w = dd.t_uniform((Cin, Cout, 3, 3, 3), 392, -1, 1) * (3.0 / (Cin * 27 / 8)) ** 0.5
+    shift = dd.t_uniform((Cout,), 393, -0.2, 0.2)
+    ref = F.conv_transpose3d(x.double(), w.double(), None, stride=2, padding=1, output_padding=1) + shift.double().reshape(1, -1, 1, 1, 1)
+    skip = ws = None
+    if Cs:
+        skip = dd.t_normalish((2, Cs, 2 * D, 2 * H, 2 * W), 394)
+        ws = dd.t_uniform((Cout, Cs, 1, 1, 1), 395, -1, 1) * (3.0 / Cs) ** 0.5
+        ref = ref + F.conv3d(skip.double(), ws.double())
+    ref = F.relu(ref)
+    wp = sa.modules.pack_conv_weight(dev(w), transposed=True)
+    wsp = None if ws is None else sa.modules.pack_conv_weight(dev(ws)).reshape(Cs, Cout).contiguous()
+    y32 = sa.modules.deconv3d_hip(dev(x), wp, dev(shift), True, None if skip is None else dev(skip), wsp)
+    y = sa.modules.deconv3d_bf16s_hip(dev(x), sa.modules.pack_deconv_weight_bf16s(wp), Cout, dev(shift), True, nterms,
+                                      None if skip is None else dev(skip),
+                                      None if wsp is None else sa.modules.pack_deconv_weight_bf16s(wsp))
+    e_split, e_f32 = float((y.double().cpu() - ref).abs().max()), float((y32.double().cpu() - ref).abs().max())
+    REPORT[f"deconv3d_bf16x{nterms}/{case}"] = e_split
+    REPORT[f"deconv3d_f32_vs_f64/{case}"] = e_f32
+    assert e_split <= (1.5 * e_f32 + 1e-6 if nterms == 6 else 4e-5), (e_split, e_f32)
+
+
 def test_patch_and_gate_fusion(sa):
     from oracle import detdata as dd
     P = oseg.deterministic_params()

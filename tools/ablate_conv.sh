@@ -14,3 +14,12 @@ for v in SPLIT A IN B "SPLIT -DSS_ABL_IN" "SPLIT -DSS_ABL_IN -DSS_ABL_A" "SPLIT 
   hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_abl_$name.so /tmp/abl_$name.o $objs
   echo built $OUT/lib_abl_$name.so
 done
+# the split-bf16 transposed conv: main loop / skip projection / output stores compiled out
+# (then: SS_TOOL_LIB=tools/_build/lib_dabl_X.so python tools/run_deconv.py bf16x6)
+for v in MAIN SKIP STORE "MAIN -DSS_ABL_D_SKIP"; do
+  name=$(echo "$v" | sed 's/ -DSS_ABL_D_/_/g')
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSS_ABL_D_$v -c deconv3d_bf16s.hip -o /tmp/dabl_$name.o
+  objs=$(ls *.o | grep -v deconv3d_bf16s.o)
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_dabl_$name.so /tmp/dabl_$name.o $objs
+  echo built $OUT/lib_dabl_$name.so
+done
