@@ -177,7 +177,7 @@ int ss_conv3d_fwd(const float* in, const float* wpack, const float* scale, const
  * operand split exactly into three bf16 terms ("split-bf16"): nterms = 6 keeps all cross terms down to
  * 2^-24 (measured error below the exact-fp32 MFMA's, tools/exp_split_bf16.hip), nterms = 3 keeps
  * hi*hi + hi*mid + mid*hi.  wsplit comes from ss_pack_conv3d_weights_bf16s (16-byte aligned).
- * stride 2 returns SS_ERR_UNSUPPORTED (use ss_conv3d_fwd). */
+ * stride in {1, 2}. */
 int ss_conv3d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                         const float* residual, const float* gate, float* out,
                         int B, int Cin, int D, int H, int W, int Cout, int stride, int relu, int nterms,

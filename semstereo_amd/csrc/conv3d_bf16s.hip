@@ -434,9 +434,10 @@ static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* s
 #define SS_B(S, NT, TD, TH)                                                                                              \
     return (nterms == 6) ? launch_b<S, NT, TD, TH, 6>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st) \
                          : launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st)
-    // stride 2 would need a 65-column halo tile per row (> 80 KB of split operands): those layers
-    // (9 % of the FLOPs) stay on the exact-fp32 engine of conv3d.hip.
-    if (stride != 1) return SS_ERR_UNSUPPORTED;
+    // stride 2 needs a 65-column halo tile per row.  A 1 x 4 output tile is 84 KB of split operands: one workgroup per
+    // CU, slower than the exact-fp32 kernel (283 vs 229 us on the largest layer).  A 2 x 2 tile is 78 KB: two
+    // workgroups per CU, faster on every stride-2 layer of the model (190 / 95 / 68 / 41 us vs 229 / 122 / 81 / 62).
+    if (stride == 2) { SS_B(2, 1, 2, 2); }     // 5 x 5 x 65 halo positions: 78 KB of split operands, two workgroups per CU
     if (tile == 0) { SS_B(1, 4, 2, 8); }
     if (tile == 1) { SS_B(1, 2, 1, 8); }
     SS_B(1, 1, 1, 4);

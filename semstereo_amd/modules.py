@@ -159,7 +159,8 @@ def deconv3d_bf16s_hip(x, wsplit, Cout, shift, relu, nterms, skip=None, skip_wsp
 
 #: matrix-core engine of the 3x3x3 stride-1 convolutions: "f32" = exact-fp32 MFMA (conv3d.hip);
 #: "bf16x6" / "bf16x3" = split-bf16 (conv3d_bf16s.hip, fp32 operands as 3 bf16 terms, 6 or 3 cross
-#: products).  Everything else (stride 2, 1x1x1, transposed, Cout = 1) always runs the fp32 engine.
+#: products) for every 3x3x3 conv (stride 1 and 2), the transposed convs, the 32 -> 1 heads and the 1x1x1
+#: projections of the attention blocks.
 #: Default bf16x6: its measured error against fp64 is BELOW the exact-fp32 MFMA's (1.1e-7 vs 1.8e-7 of
 #: sum|a*b|, tools/exp_split_bf16.hip) at ~1.5x its speed; SS_CONV_ENGINE=f32 selects the exact engine.
 CONV_ENGINE = os.environ.get("SS_CONV_ENGINE", "bf16x6")
@@ -178,23 +179,24 @@ def pack_conv_weight_bf16s(w):
     return out
 
 
-def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None, gate=None, partial=None):
-    """3x3x3 stride-1 Conv3d + affine + optional residual / ReLU on the split-bf16 engine.  `partial`
+def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None, gate=None, partial=None, stride=1):
+    """3x3x3 Conv3d (stride 1 or 2) + affine + optional residual / ReLU on the split-bf16 engine.  `partial`
     [B,Cout,D,H,W]: a partial sum of the same convolution (other input channels), added BEFORE the affine."""
     x = x if x.is_contiguous() else x.contiguous()
     dev = _lib.require_device(x, scale, shift, residual, gate, partial)
     B, Cin, D, H, W = x.shape
-    out = torch.empty((B, Cout, D, H, W), dtype=x.dtype, device=x.device)
+    Do, Ho, Wo = [(n - 1) // stride + 1 for n in (D, H, W)]
+    out = torch.empty((B, Cout, Do, Ho, Wo), dtype=x.dtype, device=x.device)
     if gate is not None:
-        assert gate.shape == (B, Cout, H, W) and gate.is_contiguous()
+        assert gate.shape == (B, Cout, Ho, Wo) and gate.is_contiguous()
     with torch.cuda.device(dev):
         if partial is not None:
-            assert residual is None and partial.shape == out.shape and partial.is_contiguous()
+            assert residual is None and stride == 1 and partial.shape == out.shape and partial.is_contiguous()
             call("ss_conv3d_bf16s_partial_fwd", ptr(x), ptr(wsplit), ptr(partial), ptr(scale), ptr(shift), ptr(gate), ptr(out),
                  B, Cin, D, H, W, Cout, int(relu), int(nterms))
         else:
             call("ss_conv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(gate), ptr(out),
-                 B, Cin, D, H, W, Cout, 1, int(relu), int(nterms))
+                 B, Cin, D, H, W, Cout, int(stride), int(relu), int(nterms))
     return out
 
 
@@ -269,7 +271,7 @@ def _conv_geometry(conv):
 def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
     """Fused Conv3d -> BN(eval) [-> +residual] [-> ReLU] [-> * sigmoid(gate)] on the selected engine."""
     k, s = _conv_geometry(conv)
-    if CONV_ENGINE != "f32" and k == 3 and s == 1 and conv.out_channels > 1:
+    if CONV_ENGINE != "f32" and k == 3 and s in (1, 2) and conv.out_channels > 1:
         nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
         srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
@@ -277,7 +279,7 @@ def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
             sc, sh = fold_bn(bn) if bn is not None else (None, None)
             return pack_conv_weight_bf16s(conv.weight), sc, sh
         ws, scale, shift = _cache(owner).get(key + "/bf16s", srcs, build)
-        return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual, gate)
+        return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual, gate, stride=s)
     if (CONV_ENGINE != "f32" and k == 3 and s == 1 and conv.out_channels == 1 and conv.in_channels in (16, 32, 64)
             and residual is None and gate is None):
         nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]

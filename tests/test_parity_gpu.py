@@ -509,6 +509,24 @@ def test_conv3d_head_split_bf16(sa, case, nterms):
     assert float((yn.double().cpu() - refn).abs().max()) <= (4e-6 if nterms == 6 else 4e-5)
 
 
+@pytest.mark.parametrize("case", [(64, 128, 4, 7, 40), (32, 64, 6, 10, 34), (20, 40, 3, 5, 9), (64, 128, 16, 64, 64)])
+def test_conv3d_split_bf16_stride2(sa, case):
+    """the stride-2 instantiation of the split-bf16 conv (odd sizes, ragged channels) against float64 and the exact-fp32 kernel"""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin, Cout, D, H, W = case
+    x = dd.t_normalish((1, Cin, D, H, W), 481)
+    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 482, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    scale, shift = dd.t_uniform((Cout,), 483, 0.5, 1.5), dd.t_uniform((Cout,), 484, -0.2, 0.2)
+    ref = F.relu(F.conv3d(x.double(), w.double(), None, 2, 1) * scale.double().reshape(1, -1, 1, 1, 1) + shift.double().reshape(1, -1, 1, 1, 1))
+    y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w)), Cout, dev(scale), dev(shift), True, 6, stride=2)
+    y32 = sa.modules.conv3d_hip(dev(x), sa.modules.pack_conv_weight(dev(w)), dev(scale), dev(shift), 3, 2, True)
+    assert y.shape == ref.shape
+    e_split, e_f32 = float((y.double().cpu() - ref).abs().max()), float((y32.double().cpu() - ref).abs().max())
+    REPORT[f"conv3d_s2_bf16x6/{case}"] = e_split
+    assert e_split <= 1.5 * e_f32 + 1e-6, (e_split, e_f32)
+
+
 BF16S_CASES = [
     # (Cin, Cout, D, H, W, relu, residual)
     (32, 32, 5, 9, 37, True, False),
