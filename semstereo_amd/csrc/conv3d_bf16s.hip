@@ -86,7 +86,9 @@ struct BCfg {
 
 // GATED: the channelAtt gate is fused into the epilogue (only concat_stem has one, so its launches also carry
 // their own kernel symbol in a profile: conv3d_bf16s<..., true>)
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED>
+// MT: 32-channel output tiles per wave (the activation fragments of a row then feed MT x 6 MFMAs: used by the stride-2
+// layers, whose staging is 8x dearer per MFMA and whose 2-4 output tiles would otherwise each stage the same input)
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     const int tw = t % tiles_w; t /= tiles_w;
     const int th = t % tiles_h; t /= tiles_h;
     const int ow0 = tw * 32, oh0 = th * TH, od0 = t * TD;
-    const int co0 = blockIdx.y * 32;
+    const int co0 = blockIdx.y * 32 * MT;
     const int b = blockIdx.z;
     const int iw0 = ow0 * S - 1, ih0 = oh0 * S - 1, id0 = od0 * S - 1;
     const int dzw = (wave * NT) / TH, hy0 = (wave * NT) % TH;
@@ -113,21 +115,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     // (a partial sum of the same convolution computed elsewhere, stem_left.hip).  It is then read here, under the
     // first chunk's staging, instead of in the epilogue where nothing hides its latency.
     const bool res_pre = (relu & 2) != 0 && residual != nullptr;
-    f32x16 acc[NT];
+    f32x16 acc[MT * NT];                  // index mt * NT + row
     if (res_pre) {
         const int ow_ = min(ow0 + l31, Wo - 1), od_ = min(od0 + dzw, Do - 1);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int oh_ = min(oh0 + hy0 + i, Ho - 1);
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
-                acc[i][r] = residual[(((size_t)b * Cout + co) * Do + od_) * ((size_t)Ho * Wo) + (size_t)oh_ * Wo + ow_];
+            for (int i = 0; i < NT; ++i) {
+                const int oh_ = min(oh0 + hy0 + i, Ho - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = min(co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
+                    acc[mt * NT + i][r] = residual[(((size_t)b * Cout + co) * Do + od_) * ((size_t)Ho * Wo) + (size_t)oh_ * Wo + ow_];
+                }
             }
-        }
     } else {
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < MT * NT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     }
@@ -165,15 +169,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     // output channels beyond Cout read a clamped (valid) column and are dropped in the epilogue
     // Both operands are fetched with buffer loads: wave-uniform base (SGPR descriptor) + uniform
     // scalar offset + one 32-bit per-lane offset, so no 64-bit per-lane addresses are kept live.
-    const int wlane = (half * Cout + min(co0 + l31, Cout - 1)) * 16;          // byte offset of this lane's column
+    int wlane[MT];                                                            // byte offset of this lane's column, per output tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wlane[mt] = (half * Cout + min(co0 + mt * 32 + l31, Cout - 1)) * 16;
     const int wstep = 3 * 2 * Cout * 16;                                      // bytes per K-step
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(wsplit), 0, (int)min((long long)((Cin + 7) / 8) * KSTEPS * wstep, 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(inb), 0, (int)min((long long)Cin * (long long)chan * 4, 0x7fffffffLL), 0x00020000);
     const int chan_b = (int)(chan * 4);                                       // bytes per input channel
-    auto load_a = [&](int g, int c) {
-        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, wlane, g * wstep + c * 2 * Cout * 16, 0));
+    auto load_a = [&](int g, int c, int mt) {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, wlane[mt], g * wstep + c * 2 * Cout * 16, 0));
     };
     auto load_in = [&](int ch, int i) {                                       // channel ch (absolute), position slot i
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, SS_IN_AUX));
@@ -182,11 +188,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     // Ring of weight fragments, AP steps ahead: vmcnt retires in order, so a wait for a fragment also
     // waits for every input (HBM) load issued before it -- the distance must cover HBM latency, not L2's.
     constexpr int AP = SS_A_AHEAD, AR = AP + 1;
-    uint4 aq[AR][NC];                                          // aq[s % AR] = fragments of step s of the chunk
+    uint4 aq[AR][MT][NC];                                      // aq[s % AR] = fragments of step s of the chunk
 #pragma unroll
     for (int k = 0; k < AP; ++k)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) aq[k][c] = load_a(min(k, G - 1), c);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) aq[k][mt][c] = load_a(min(k, G - 1), c, mt);
     {   // first chunk: plain load of every slice
 #pragma unroll
         for (int q = 0; q < NQ; ++q) rin[q] = load_in(min(q / C::NPOS, nlive - 1), q % C::NPOS);
@@ -237,7 +245,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #ifndef SS_ABL_A
             if (g0 + s + AP < G) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) aq[(s + AP) % AR][c] = load_a(g0 + s + AP, c);
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) aq[(s + AP) % AR][mt][c] = load_a(g0 + s + AP, c, mt);
             }
 #endif
 #ifndef SS_ABL_IN
@@ -247,9 +257,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                     rin[q] = load_in(ci0 + 8 + min(q / C::NPOS, nlive_next - 1), q % C::NPOS);
             }
 #endif
-            bf16x8 a[NC];
+            bf16x8 a[MT][NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) a[c] = __builtin_bit_cast(bf16x8, aq[s % AR][c]);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) a[mt][c] = __builtin_bit_cast(bf16x8, aq[s % AR][mt][c]);
 #pragma unroll
             for (int i0 = 0; i0 < NT; i0 += RP) {
 #pragma unroll
@@ -268,9 +280,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #pragma unroll
                 for (int p = 6 - NP; p < 6; ++p)
 #pragma unroll
-                    for (int r = 0; r < RP; ++r)
-                        acc[i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            a[pa[p]], __builtin_bit_cast(bf16x8, bcur[r][pb[p]]), acc[i0 + r], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < RP; ++r)
+                            acc[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                a[mt][pa[p]], __builtin_bit_cast(bf16x8, bcur[r][pb[p]]), acc[mt * NT + i0 + r], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < RP; ++r)
 #pragma unroll
@@ -280,22 +294,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                 // group's MFMAs (the scheduler otherwise sinks them next to their use and every row
                 // starts with an exposed LDS latency)
                 __builtin_amdgcn_sched_group_barrier(0x100, NC * RP, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NP * RP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NP * RP * MT, 0);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);     // keep each step's loads inside the step
         }
         // steps 14 .. 14+AP-1 of this chunk are steps 0 .. AP-1 of the next: re-base the fragment ring
         {
-            uint4 tq[AP][NC];
+            uint4 tq[AP][MT][NC];
 #pragma unroll
             for (int k = 0; k < AP; ++k)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) tq[k][c] = aq[(KSTEPS + k) % AR][c];
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) tq[k][mt][c] = aq[(KSTEPS + k) % AR][mt][c];
 #pragma unroll
             for (int k = 0; k < AP; ++k)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) aq[k][c] = tq[k][c];
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) aq[k][mt][c] = tq[k][mt][c];
         }
         nlive = nlive_next;
 #ifndef SS_ABL_BAR2
@@ -311,12 +329,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     // the side inputs (affine, gate, residual) of a group of 4 fragment rows are fetched first, with
     // clamped (always valid) addresses and no branches, so their latencies overlap instead of chaining
 #pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
     for (int r0 = 0; r0 < 16; r0 += 4) {
         float sc[4], sh[4], gv[4][NT], rv[4][NT];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = r0 + q;
-            const int co = min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
+            const int co = min(co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
             sc[q] = scale ? scale[co] : 1.0f;
             sh[q] = shift ? shift[co] : 0.0f;
 #pragma unroll
@@ -329,13 +349,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = r0 + q;
-            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (co >= Cout) continue;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int oh = oh0 + hy0 + i;
                 if (oh >= Ho) continue;
-                float v = ss::add_rn(ss::mul_rn(acc[i][r], sc[q]), sh[q]);
+                float v = ss::add_rn(ss::mul_rn(acc[mt * NT + i][r], sc[q]), sh[q]);
                 if (residual && !res_pre) v = ss::add_rn(v, rv[q][i]);
                 if (relu & 1) v = fmaxf(v, 0.f);
                 if (GATED) v = ss::mul_rn(gv[q][i], v);     // channelAtt gate, broadcast over D
@@ -365,24 +385,37 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned 
     wsplit[i] = (unsigned short)(term == 0 ? h : (term == 1 ? m : l));
 }
 
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED>
-int launch_bg(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT>
+int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
     using C = BCfg<S, NT, TD, TH>;
     const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED>;
+    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT>;
     if (C::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)C::LDS_BYTES);
         if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
     }
-    dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32), B);
+    dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32 * MT), B);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
                        residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
     return ss::check_launch();
+}
+
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED>
+int launch_bg(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
+              const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
+    // stride 2: two output tiles per wave (the activation staging is then shared: 154 vs 191 us on the largest layer)
+    // unless that leaves fewer workgroups than CUs (57 vs 41 us on the smallest)
+    const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+    const long long wg2 = (long long)ss::ceil_div(Wo, 32) * ss::ceil_div(Ho, TH) * ss::ceil_div(Do, TD) * ss::ceil_div(Cout, 64) * B;
+    if (S == 2 && Cout > 32 && wg2 >= 256 && getenv("SS_CONV_S2_MT1") == nullptr)
+        return launch_bgm<S, NT, TD, TH, NTERMS, GATED, (S == 2) ? 2 : 1>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W,
+                                                                          Cout, relu, st);
+    return launch_bgm<S, NT, TD, TH, NTERMS, GATED, 1>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
 }
 
 template <int S, int NT, int TD, int TH, int NTERMS>
