@@ -192,6 +192,13 @@ int ss_conv3d_bf16s_partial_fwd(const float* in, const void* wsplit, const float
 /* Conv3d weight [Cout,Cin,3,3,3] fp32 -> split/packed bf16 fragments
  * [ceil(Cin/8)][14 tap pairs][3 terms][2 halves][Cout][8] (ceil(Cin/8)*14*3*2*Cout*16 bytes). */
 int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
+/* The 2-D form of the split-bf16 conv: Conv2d(k3, s1, p1, bias=False) + affine (+residual) + ReLU on [B,Cin,H,W] maps
+ * (concat_feature, models/SemStereo.py:222-226): out [B,Cout,H,W]; w [Cout,Cin,3,3] -> wsplit
+ * [ceil(Cin/8)][5 tap pairs][3 terms][2 halves][Cout][8] (ceil(Cin/8)*5*3*2*Cout*16 bytes). */
+int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                        const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int relu,
+                        int nterms, ss_stream_t stream);
+int ss_pack_conv2d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
 /* The single-output-channel classifier heads, nn.Conv3d(C, 1, 3, padding=1, bias=False)
  * (models/SemStereo.py:228-234, classif.2 / classif_att_.2), on the split-bf16 engine with the 27 taps as
  * the matrix rows:  out [B,1,D,H,W] = relu?(scale[0] * conv(in [B,Cin,D,H,W]) + shift[0]);

@@ -29,7 +29,7 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
-constexpr int KSTEPS = 14;        // ceil(27 taps / 2)
+constexpr int KSTEPS = 14;        // ceil(27 taps / 2): the 3-D kernels (BCfg::KSTEPS is the general form)
 #ifndef SS_IN_STEPS
 #define SS_IN_STEPS 10            // K-steps over which the next chunk's input loads are issued
 #endif
@@ -74,9 +74,12 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsig
     l = cvt_pk_bf16(s0, s1);
 }
 
-template <int S, int NT, int TD, int TH>
+// KD: kernel depth, 3 (3x3x3) or 1 (3x3 over [B,C,H,W] maps seen as depth-1 volumes: 9 taps, 5 K-steps)
+template <int S, int NT, int TD, int TH, int KD = 3>
 struct BCfg {
-    static constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
+    static constexpr int KT = KD * 9, KSTEPS = (KT + 1) / 2;
+    static constexpr int ID = (TD - 1) * S + KD, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
+    static_assert(KD == 3 || (KD == 1 && TD == 1), "2-D form: depth-1 tiles");
     static constexpr int CS = ID * IH * IW;                    // positions in the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
     static constexpr int SLOTS = 3 * CS + 1;                   // + one all-zero slot (the 28th half-step)
@@ -88,14 +91,15 @@ struct BCfg {
 // their own kernel symbol in a profile: conv3d_bf16s<..., true>)
 // MT: 32-channel output tiles per wave (the activation fragments of a row then feed MT x 6 MFMAs: used by the stride-2
 // layers, whose staging is 8x dearer per MFMA and whose 2-4 output tiles would otherwise each stage the same input)
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT>
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
                                                         float* __restrict__ out,
                                                         int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
                                                         int tiles_w, int tiles_h, int relu) {
-    using C = BCfg<S, NT, TD, TH>;
+    using C = BCfg<S, NT, TD, TH, KD>;
+    constexpr int KSTEPS = C::KSTEPS;                          // shadows the 3-D constant
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [3][CS] slots + zero slot
 
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     const int ow0 = tw * 32, oh0 = th * TH, od0 = t * TD;
     const int co0 = blockIdx.y * 32 * MT;
     const int b = blockIdx.z;
-    const int iw0 = ow0 * S - 1, ih0 = oh0 * S - 1, id0 = od0 * S - 1;
+    const int iw0 = ow0 * S - 1, ih0 = oh0 * S - 1, id0 = od0 * S - KD / 2;
     const int dzw = (wave * NT) / TH, hy0 = (wave * NT) % TH;
     const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + l31 * S;     // slot of this lane's first row, tap (0,0,0)
 
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     constexpr int NQ = 8 * C::NPOS;
     // ... all of them within the first SS_IN_STEPS steps: the split phase at the end of the chunk waits
     // for the youngest slice, which needs a few K-steps (HBM latency) to land
-    constexpr int IN_STEPS = SS_IN_STEPS;
+    constexpr int IN_STEPS = (SS_IN_STEPS < KSTEPS) ? SS_IN_STEPS : KSTEPS;
     constexpr int QS = (NQ + IN_STEPS - 1) / IN_STEPS;
     float rin[NQ];
     int nlive = min(8, Cin), nlive_next = 8;                 // channels that exist in the staged / prefetched chunk
@@ -232,10 +236,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
         auto read_b = [&](uint4 (&dst)[NC], int s, int i) {
             const int ta = 2 * s, tb = 2 * s + 1;
             const int offa = ((ta / 9) * C::IH + (ta / 3) % 3) * C::IW + ta % 3;
-            const int offb = (tb < 27) ? ((tb / 9) * C::IH + (tb / 3) % 3) * C::IW + tb % 3 : 0;
+            const int offb = (tb < C::KT) ? ((tb / 9) * C::IH + (tb / 3) % 3) * C::IW + tb % 3 : 0;
             const int slot = lane_pos + i * S * C::IW + (half ? offb : offa);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) dst[c] = lds[(tb >= 27 && half) ? 3 * C::CS : c * C::CS + slot];
+            for (int c = 0; c < NC; ++c) dst[c] = lds[(tb >= C::KT && half) ? 3 * C::CS : c * C::CS + slot];
         };
 #pragma unroll
         for (int r = 0; r < RP; ++r) read_b(bcur[r], 0, r);
@@ -367,7 +371,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 
 // [Cout,Cin,3,3,3] fp32 -> [ceil(Cin/8)][14 steps][3 terms][2 halves][Cout][8] bf16 (zero padded)
 __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit, int Cout,
-                                          int Cin, long long total) {
+                                          int Cin, int ktaps, long long total) {
+    const int KSTEPS = (ktaps + 1) / 2;                        // 14 (3x3x3) or 5 (3x3)
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int j = (int)(i % 8);
@@ -379,21 +384,21 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned 
     const int blk = (int)(r / KSTEPS);
     const int tap = 2 * s + half, ci = blk * 8 + j;
     float x = 0.f;
-    if (tap < 27 && ci < Cin) x = w[((long long)co * Cin + ci) * 27 + tap];
+    if (tap < ktaps && ci < Cin) x = w[((long long)co * Cin + ci) * ktaps + tap];
     unsigned h, m, l;
     split3(x, h, m, l);
     wsplit[i] = (unsigned short)(term == 0 ? h : (term == 1 ? m : l));
 }
 
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT>
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
-    using C = BCfg<S, NT, TD, TH>;
-    const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+    using C = BCfg<S, NT, TD, TH, KD>;
+    const int Do = (D + 2 * (KD / 2) - KD) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT>;
+    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD>;
     if (C::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)C::LDS_BYTES);
@@ -481,6 +486,35 @@ extern "C" int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Co
     SS_REQUIRE(w && wsplit && Cout > 0 && Cin > 0);
     const long long total = (long long)ss::ceil_div(Cin, 8) * KSTEPS * 3 * 2 * Cout * 8;
     hipLaunchKernelGGL(pack_weights_bf16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
-                       ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), Cout, Cin, total);
+                       ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), Cout, Cin, 27, total);
     return ss::check_launch();
+}
+
+// ---- the 2-D form: Conv2d(k3, s1, p1, bias=False) + affine + optional residual + ReLU on [B,C,H,W] maps (concat_feature of
+// the reference model, models/SemStereo.py:222-226): the same kernel with a depth-1 volume and 9 taps (5 K-steps) ----
+extern "C" int ss_pack_conv2d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream) {
+    SS_REQUIRE(w && wsplit && Cout > 0 && Cin > 0);
+    const long long total = (long long)ss::ceil_div(Cin, 8) * 5 * 3 * 2 * Cout * 8;
+    hipLaunchKernelGGL(pack_weights_bf16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
+                       ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), Cout, Cin, 9, total);
+    return ss::check_launch();
+}
+
+extern "C" int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                   const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int relu,
+                                   int nterms, ss_stream_t stream) {
+    SS_REQUIRE(in && wsplit && out);
+    SS_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
+    if ((long long)Cin * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipStream_t st = ss::as_stream(stream);
+    auto blocks = [&](int th) { return (long long)ss::ceil_div(W, 32) * ss::ceil_div(H, th) * ss::ceil_div(Cout, 32) * B; };
+    const int r = relu ? 1 : 0;
+#define SS_B2(NT, TH)                                                                                                      \
+    return (nterms == 6) ? launch_bgm<1, NT, 1, TH, 6, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st) \
+                         : launch_bgm<1, NT, 1, TH, 3, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st)
+    if (blocks(16) >= 512) { SS_B2(4, 16); }
+    if (blocks(8) >= 512) { SS_B2(2, 8); }
+    SS_B2(1, 4);
+#undef SS_B2
 }

@@ -200,6 +200,56 @@ def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None,
     return out
 
 
+def pack_conv2d_weight_bf16s(w):
+    """[Cout,Cin,3,3] fp32 -> split-bf16 fragments for ss_conv2d_bf16s_fwd."""
+    w = w.detach().float().contiguous()
+    _lib.require_device(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3)
+    out = torch.empty(((Cin + 7) // 8) * 5 * 3 * 2 * Cout * 8, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        call("ss_pack_conv2d_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
+    return out
+
+
+def conv2d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None):
+    """Conv2d(k3, s1, p1, bias=False) + affine + optional residual / ReLU on the split-bf16 engine."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, scale, shift, residual)
+    B, Cin, H, W = x.shape
+    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(dev):
+        call("ss_conv2d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(out), B, Cin, H, W, Cout,
+             int(relu), int(nterms))
+    return out
+
+
+def _is_plain_3x3(conv):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros")
+
+
+#: concat_feature's 3x3 2-D convs on the split engine instead of MIOpen.  The kernels are faster (110 + 38 us against
+#: 170 + 58 us of Winograd + BatchNorm + clamp) but run on the second stream UNDER the attention branch, where they now
+#: compete for the same matrix pipe: the step is 1 % slower at batch 1 and 1 % faster at batch 4, so it is opt-in
+#: (it also takes MIOpen's per-box algorithm choice out of the matching branch).
+CONV2D_HIP = os.environ.get("SS_CONV2D_HIP", "0") != "0"
+
+
+def run_conv2d(owner, key, conv, bn, x, relu):
+    """Conv2d(3x3, s1, p1, no bias) [+ BN(eval)] [+ ReLU] of a 2-D map on the split-bf16 engine; None when it does not apply."""
+    if not (CONV2D_HIP and CONV_ENGINE != "f32" and _is_plain_3x3(conv) and x.is_cuda):
+        return None
+    nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+    srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+    def build():
+        sc, sh = fold_bn(bn) if bn is not None else (None, None)
+        return pack_conv2d_weight_bf16s(conv.weight), sc, sh
+    ws, scale, shift = _cache(owner).get(key + "/2d_bf16s", srcs, build)
+    return conv2d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms)
+
+
 def pack_head_weight_bf16s(w):
     """[1,Cin,3,3,3] fp32 -> split-bf16 fragments (taps as matrix rows) for ss_conv3d_head_bf16s_fwd."""
     w = w.detach().float().contiguous()
@@ -355,6 +405,10 @@ class BasicConv(nn.Module):
             return run_convbn(self, "bc", self.conv, self.bn if self.use_bn else None, x, relu=bool(self.relu), gate=g)
         if self.is_3d:
             PATH_COUNTS["torch"] += 1
+        elif not self.deconv and gate_logits is None and _inference(self, x):
+            y = run_conv2d(self, "bc2d", self.conv, self.bn if self.use_bn else None, x, bool(self.relu))
+            if y is not None:
+                return y
         x = self.conv(x)
         if self.use_bn:
             x = self.bn(x)

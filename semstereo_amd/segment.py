@@ -116,7 +116,20 @@ class HotSegment(nn.Module):
         """:314-315 and the image half of :320 -- the 2-D convolutions that do not depend on the attention
         branch (fast path only): concat features of both views in one batch (shared weights) and the logits
         of the concat_feature_att_4 gate."""
-        cl, cr = self.concat_feature(torch.cat((fl4, fr4), dim=0)).split(fl4.shape[0], dim=0)
+        both = torch.cat((fl4, fr4), dim=0)
+        cf = self.concat_feature
+        y = None
+        # conv3x3 + BN + ReLU, conv3x3 (models/SemStereo.py:222-226), reference-built or twin: both on the split engine
+        if (len(cf) == 2 and isinstance(cf[1], nn.Conv2d) and isinstance(getattr(cf[0], "conv", None), nn.Conv2d)
+                and getattr(cf[0], "relu", False) and M._inference(cf, both)):
+            bn = cf[0].bn if getattr(cf[0], "use_bn", True) else None
+            y = M.run_conv2d(cf[0], "bc2d", cf[0].conv, bn, both, True)
+            if y is not None:
+                z = M.run_conv2d(cf, "cf1", cf[1], None, y, False)
+                y = z if z is not None else cf[1](y)
+        if y is None:
+            y = cf(both)
+        cl, cr = y.split(fl4.shape[0], dim=0)
         return cl, cr, self.concat_feature_att_4.logits(fl4)
 
     def matching_branch(self, fl4, fr4, att_topk, samples, prelude=None):
