@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--maxdisp", type=int, default=128)
-    ap.add_argument("--engine", default=None, help="conv engine of the timed run: f32 | bf16x6 | bf16x3 "
+    ap.add_argument("--engine", default=None, help="conv engine of the timed run: f32 | bf16x6 | bf16x3 | f16x3 "
                                                    "(default: semstereo_amd.modules.CONV_ENGINE)")
     ap.add_argument("--no-other-engines", action="store_true", help="skip the extra timings of the other engines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,7 +185,7 @@ def main():
 
     by_engine, outs = {engine: pairs / tmax}, {engine: out}
     if not args.no_other_engines:
-        for e in ("f32", "bf16x6", "bf16x3"):
+        for e in ("f32", "bf16x6", "bf16x3", "f16x3"):
             if e != engine:
                 M.CONV_ENGINE = e
                 o, p_, t_ = timed_run(max(3, args.steps // 2), 2)
@@ -212,6 +212,10 @@ def main():
         "bf16x6": "3x3x3 stride-1 convs: fp32 operands split into 3 bf16 terms, 6 cross products on v_mfma_f32_32x32x16_bf16, "
                   "fp32 accumulate (measured error vs fp64 below the exact-fp32 MFMA's); other layers exact-fp32 MFMA",
         "bf16x3": "as bf16x6 with 3 cross products (hi*hi + hi*mid + mid*hi)",
+        "f16x3": "3x3x3 convs (stride 1, 2) and transposed convs: fp32 operands as TWO fp16 terms with block-floating power-of-two "
+                 "scales (per output channel for weights, per staged tile chunk for activations), 3 cross products on "
+                 "v_mfma_f32_32x32x16_f16, fp32 accumulate (measured error vs fp64 at or below the exact-fp32 MFMA's, "
+                 "tools/check_engines.py); heads, 1x1x1 projections, broadcast half of the stem: bf16x6",
     }[engine]
     res = {
         "metric": "stereo pairs/sec, hot segment (gwc+concat volumes, 3-D hourglass stack, soft-argmax), "
@@ -240,14 +244,16 @@ def main():
                                "algorithmic_flop_per_launch": flops}
         else:
             nterms = 6 if engine == "bf16x6" else 3
-            ex = nterms * eq                                   # bf16 MFMA flops actually issued per second
-            res["roofline"] = {"kernel": f"conv3d_bf16s<1,4,2,8,{nterms},true> (concat_stem: {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]"
+            code = 19 if engine == "f16x3" else nterms         # the kernel's NTERMS template argument
+            typ = "fp16" if engine == "f16x3" else "bf16"
+            ex = nterms * eq                                   # 16-bit MFMA flops actually issued per second
+            res["roofline"] = {"kernel": f"conv3d_bf16s<1,4,2,8,{code},true> (concat_stem: {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]"
                                          + (", the warped half of the volume; + residual (the broadcast half, by linearity) + ReLU + channelAtt gate)" if halves
                                             else " + ReLU + channelAtt gate)"),
                                "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ex / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
                                "algorithmic_flop_per_launch": nterms * flops,
-                               "note": f"{nterms} bf16 products per fp32 product; fp32-equivalent rate {eq:.1f} TFLOP/s = "
+                               "note": f"{nterms} {typ} products per fp32 product (fp16 and bf16 MFMA peaks are equal); fp32-equivalent rate {eq:.1f} TFLOP/s = "
                                        f"{eq / MFMA_F32_PEAK_TFLOPS:.2f} x the {MFMA_F32_PEAK_TFLOPS} TFLOP/s fp32-MFMA peak",
                                "fp32_equivalent_tflops": eq}
     ms = timer.mean_ms("gwc")

@@ -192,6 +192,15 @@ int ss_conv3d_bf16s_partial_fwd(const float* in, const void* wsplit, const float
 /* Conv3d weight [Cout,Cin,3,3,3] fp32 -> split/packed bf16 fragments
  * [ceil(Cin/8)][14 tap pairs][3 terms][2 halves][Cout][8] (ceil(Cin/8)*14*3*2*Cout*16 bytes). */
 int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
+/* The two-term fp16 form of the same layers (same reference lines): ss_conv3d_bf16s_fwd / _partial_fwd with
+ * nterms = 19 ("f16x3": hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, half the matrix-core time of nterms = 6).
+ * fp16 has 5 exponent bits, so the operands are block floating point: this packer scales each output channel's weights
+ * by a power of two (stored behind the terms and undone in the epilogue), the kernel scales every staged 8-channel chunk
+ * of its halo tile by a power of two taken from the tile's running |max| and rescales its fp32 accumulators when it
+ * changes.  Error vs exact: representation <= 2^-23 per operand + the dropped lo*lo <= 2^-22 per product, i.e. below
+ * the fp32 accumulation error of any K >= 64 (measured in DESIGN.md section 4).  wsplit:
+ * [ceil(Cin/8)][14][2 terms][2 halves][Cout][8] fp16 + float[Cout]  (ceil(Cin/8)*14*2*2*Cout*16 + 4*Cout bytes). */
+int ss_pack_conv3d_weights_f16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
 /* The 2-D form of the split-bf16 conv: Conv2d(k3, s1, p1, bias=False) + affine (+residual) + ReLU on [B,Cin,H,W] maps
  * (concat_feature, models/SemStereo.py:222-226): out [B,Cout,H,W]; w [Cout,Cin,3,3] -> wsplit
  * [ceil(Cin/8)][5 tap pairs][3 terms][2 halves][Cout][8] (ceil(Cin/8)*5*3*2*Cout*16 bytes). */
@@ -235,6 +244,10 @@ int ss_deconv3d_bf16s_fwd(const float* in, const void* wsplit, const float* shif
                           const void* skip_wsplit, float* out, int B, int Cin, int D, int H, int W, int Cout,
                           int Cs, int relu, int nterms, ss_stream_t stream);
 int ss_pack_deconv3d_weights_bf16s(const float* wpack, void* wsplit, int Cin, int Cout, int ntaps, ss_stream_t stream);
+/* Two-term fp16 form of the MAIN weights (ntaps = 27) for nterms = 19 of ss_deconv3d_bf16s_fwd -- the block-floating
+ * scheme described at ss_pack_conv3d_weights_f16s; the skip projection keeps its bf16 pack.
+ * wsplit: ceil(Cin/16)*27*2*2*Cout*16 + 4*Cout bytes. */
+int ss_pack_deconv3d_weights_f16s(const float* wpack, void* wsplit, int Cin, int Cout, ss_stream_t stream);
 /* Weight re-layout helpers (device to device): Conv3d weight [Cout,Cin,k,k,k] or
  * ConvTranspose3d weight [Cin,Cout,k,k,k] (transposed != 0) -> [Cin][k^3][Cout]. */
 int ss_pack_conv3d_weights(const float* w, float* wpack, int Cout, int Cin, int k, int transposed,

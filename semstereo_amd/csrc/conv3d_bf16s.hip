@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -61,7 +62,6 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 // the same split for two values at once on gfx950's packed converter: v_cvt_pk_bf16_f32 (RNE) gives
 // lo16 = bf16(x0), hi16 = bf16(x1) -- exactly the LDS slot layout -- and the residuals are one v_pk_add_f32
 using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
-using f32x2_t = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
     const f32x2_t v = {x0, x1};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
@@ -75,14 +75,14 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsig
 }
 
 // KD: kernel depth, 3 (3x3x3) or 1 (3x3 over [B,C,H,W] maps seen as depth-1 volumes: 9 taps, 5 K-steps)
-template <int S, int NT, int TD, int TH, int KD = 3>
+template <int S, int NT, int TD, int TH, int KD = 3, int LT = 3>      // LT: operand terms kept in LDS
 struct BCfg {
     static constexpr int KT = KD * 9, KSTEPS = (KT + 1) / 2;
     static constexpr int ID = (TD - 1) * S + KD, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
     static_assert(KD == 3 || (KD == 1 && TD == 1), "2-D form: depth-1 tiles");
     static constexpr int CS = ID * IH * IW;                    // positions in the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
-    static constexpr int SLOTS = 3 * CS + 1;                   // + one all-zero slot (the 28th half-step)
+    static constexpr int SLOTS = LT * CS + 2;                  // + one all-zero slot (the 28th half-step) + the waves' maxima (f16 form)
     static constexpr size_t LDS_BYTES = (size_t)SLOTS * 16;
     static_assert(TD * TH == 4 * NT && TH % NT == 0, "4 waves x NT rows tile TD x TH");
 };
@@ -98,10 +98,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                                                         float* __restrict__ out,
                                                         int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
                                                         int tiles_w, int tiles_h, int relu) {
-    using C = BCfg<S, NT, TD, TH, KD>;
-    constexpr int KSTEPS = C::KSTEPS;                          // shadows the 3-D constant
+    constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [3][CS] slots + zero slot
+    constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed weights
+    using C = BCfg<S, NT, TD, TH, KD, NC>;
+    constexpr int KSTEPS = C::KSTEPS;                          // shadows the 3-D constant
+    constexpr int ZSLOT = NC * C::CS;                          // the all-zero slot; ZSLOT + 1: the four waves' maxima
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [NC][CS] slots + zero slot + maxima
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -119,6 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     // (a partial sum of the same convolution computed elsewhere, stem_left.hip).  It is then read here, under the
     // first chunk's staging, instead of in the epilogue where nothing hides its latency.
     const bool res_pre = (relu & 2) != 0 && residual != nullptr;
+    // f16 form: float[Cout] of 2^-(weight scale of the channel), stored behind the packed terms
+    const float* wunscale = reinterpret_cast<const float*>(
+        reinterpret_cast<const char*>(wsplit) + (size_t)((Cin + 7) / 8) * C::KSTEPS * ((NTERMS == F16X3 ? 2 : 3) * 2 * Cout * 16));
     f32x16 acc[MT * NT];                  // index mt * NT + row
     if (res_pre) {
         const int ow_ = min(ow0 + l31, Wo - 1), od_ = min(od0 + dzw, Do - 1);
@@ -131,6 +137,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                 for (int r = 0; r < 16; ++r) {
                     const int co = min(co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
                     acc[mt * NT + i][r] = residual[(((size_t)b * Cout + co) * Do + od_) * ((size_t)Ho * Wo) + (size_t)oh_ * Wo + ow_];
+                    // f16 form: the accumulator carries the channel's weight scale (a power of two: exact)
+                    if (F16) acc[mt * NT + i][r] *= __uint_as_float((254u << 23) - __float_as_uint(wunscale[co]));
                 }
             }
     } else {
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     constexpr int QS = (NQ + IN_STEPS - 1) / IN_STEPS;
     float rin[NQ];
     int nlive = min(8, Cin), nlive_next = 8;                 // channels that exist in the staged / prefetched chunk
-    if (tid == 0) lds[3 * C::CS] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) lds[ZSLOT] = make_uint4(0u, 0u, 0u, 0u);
 
     // weight fragments: [global K-step g = blk*14 + s][term][half][Cout][8 bf16] as uint4 slots; lanes of
     // output channels beyond Cout read a clamped (valid) column and are dropped in the epilogue
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     int wlane[MT];                                                            // byte offset of this lane's column, per output tile
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) wlane[mt] = (half * Cout + min(co0 + mt * 32 + l31, Cout - 1)) * 16;
-    const int wstep = 3 * 2 * Cout * 16;                                      // bytes per K-step
+    const int wstep = NCW * 2 * Cout * 16;                                    // bytes per K-step
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(wsplit), 0, (int)min((long long)((Cin + 7) / 8) * KSTEPS * wstep, 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
@@ -203,20 +211,60 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #pragma unroll
         for (int q = 0; q < NQ; ++q) rin[q] = load_in(min(q / C::NPOS, nlive - 1), q % C::NPOS);
     }
+    // f16 form: block-floating scale of the staged chunk.  e_cur = biased exponent the accumulators are scaled for
+    // (scale 2^(E_ONE - e)); e_run = that of the running maximum of the tile (monotone: the accumulators only scale DOWN
+    // after the first chunk, so they cannot overflow)
+    int e_cur = E_ONE, e_run = E_MIN;
+    auto publish_max = [&](float m) {                                         // this wave's max(m, |rin|) -> LDS
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) m = fmaxf(m, fabsf(rin[q]));
+        const unsigned wm = wave_max_bits(__float_as_uint(m));
+        if (lane == 0) reinterpret_cast<unsigned*>(&lds[ZSLOT + 1])[wave] = wm;
+    };
+    if (F16) {
+        float m0 = 0.f;
+        if (res_pre) {                                                        // see E_INIT_SHIFT
+#pragma unroll
+            for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, fabsf(acc[i][r]));
+            m0 *= __uint_as_float((unsigned)(127 - E_INIT_SHIFT) << 23);
+        }
+        publish_max(m0);
+        __syncthreads();
+    }
 
     for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
         // ---- split + transpose: registers -> [term][position][8 ch] ----
         // (SS_ABL_*: timing ablations built by tools/ablate_conv.sh only -- results are wrong with them)
 #ifndef SS_ABL_SPLIT
+        float in_scale = 1.f;
+        if (F16) {
+            const uint4 wm = lds[ZSLOT + 1];
+            const int e_new = max(e_run, (int)(max(max(wm.x, wm.y), max(wm.z, wm.w)) >> 23));     // inf/NaN: 255
+            e_run = e_new;
+            if (e_new != e_cur) {                              // wave-uniform; exact power-of-two rescale
+                const float ratio = __uint_as_float((unsigned)max(127 + e_cur - e_new, 0) << 23);
+#pragma unroll
+                for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= ratio;
+                e_cur = e_new;
+            }
+            in_scale = __uint_as_float((unsigned)(127 + E_ONE - e_cur) << 23);
+        }
 #pragma unroll
         for (int i = 0; i < C::NPOS; ++i) {
             const int p = tid + 256 * i;
             if (p >= C::CS) continue;
             unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                split3_pk((2 * c < nlive) ? rin[(2 * c) * C::NPOS + i] : 0.f,
-                          (2 * c + 1 < nlive) ? rin[(2 * c + 1) * C::NPOS + i] : 0.f, hh[c], mm[c], ll[c]);
+            for (int c = 0; c < 4; ++c) {
+                const float x0 = (2 * c < nlive) ? rin[(2 * c) * C::NPOS + i] : 0.f;
+                const float x1 = (2 * c + 1 < nlive) ? rin[(2 * c + 1) * C::NPOS + i] : 0.f;
+                if (F16) split2_pk_f16(x0 * in_scale, x1 * in_scale, hh[c], mm[c]);
+                else split3_pk(x0, x1, hh[c], mm[c], ll[c]);
+            }
             lds[0 * C::CS + p] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
             lds[1 * C::CS + p] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
             if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
@@ -239,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
             const int offb = (tb < C::KT) ? ((tb / 9) * C::IH + (tb / 3) % 3) * C::IW + tb % 3 : 0;
             const int slot = lane_pos + i * S * C::IW + (half ? offb : offa);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) dst[c] = lds[(tb >= C::KT && half) ? 3 * C::CS : c * C::CS + slot];
+            for (int c = 0; c < NC; ++c) dst[c] = lds[(tb >= C::KT && half) ? ZSLOT : c * C::CS + slot];
         };
 #pragma unroll
         for (int r = 0; r < RP; ++r) read_b(bcur[r], 0, r);
@@ -261,11 +309,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                     rin[q] = load_in(ci0 + 8 + min(q / C::NPOS, nlive_next - 1), q % C::NPOS);
             }
 #endif
-            bf16x8 a[MT][NC];
+            uint4 a[MT][NC];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) a[mt][c] = __builtin_bit_cast(bf16x8, aq[s % AR][mt][c]);
+                for (int c = 0; c < NC; ++c) a[mt][c] = aq[s % AR][mt][c];
 #pragma unroll
             for (int i0 = 0; i0 < NT; i0 += RP) {
 #pragma unroll
@@ -286,9 +334,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int r = 0; r < RP; ++r)
-                            acc[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                a[mt][pa[p]], __builtin_bit_cast(bf16x8, bcur[r][pb[p]]), acc[mt * NT + i0 + r], 0, 0, 0);
+                        for (int r = 0; r < RP; ++r) {
+                            if (F16)
+                                acc[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    __builtin_bit_cast(f16x8, a[mt][pa[p]]), __builtin_bit_cast(f16x8, bcur[r][pb[p]]),
+                                    acc[mt * NT + i0 + r], 0, 0, 0);
+                            else
+                                acc[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(bf16x8, a[mt][pa[p]]), __builtin_bit_cast(bf16x8, bcur[r][pb[p]]),
+                                    acc[mt * NT + i0 + r], 0, 0, 0);
+                        }
 #pragma unroll
                 for (int r = 0; r < RP; ++r)
 #pragma unroll
@@ -320,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                     for (int c = 0; c < NC; ++c) aq[k][mt][c] = tq[k][mt][c];
         }
         nlive = nlive_next;
+        if (F16 && more) publish_max(0.f);                        // of the chunk staged next (its loads were issued >= 4 K-steps ago)
 #ifndef SS_ABL_BAR2
         __syncthreads();
 #endif
@@ -330,19 +386,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     const int od = od0 + dzw;
     if (ow >= Wo || od >= Do) return;
     const size_t out_plane = (size_t)Ho * Wo;
+    // f16 form: 2^-(activation scale) and the per-channel 2^-(weight scale) stored behind the packed weights
+    const float acc_unscale = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
     // the side inputs (affine, gate, residual) of a group of 4 fragment rows are fetched first, with
     // clamped (always valid) addresses and no branches, so their latencies overlap instead of chaining
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += 4) {
-        float sc[4], sh[4], gv[4][NT], rv[4][NT];
+        float sc[4], sh[4], un[4], gv[4][NT], rv[4][NT];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = r0 + q;
             const int co = min(co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
             sc[q] = scale ? scale[co] : 1.0f;
             sh[q] = shift ? shift[co] : 0.0f;
+            if (F16) un[q] = wunscale[co] * acc_unscale;       // powers of two: the products below are exact
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int oh = min(oh0 + hy0 + i, Ho - 1);
@@ -359,7 +418,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
             for (int i = 0; i < NT; ++i) {
                 const int oh = oh0 + hy0 + i;
                 if (oh >= Ho) continue;
-                float v = ss::add_rn(ss::mul_rn(acc[mt * NT + i][r], sc[q]), sh[q]);
+                const float a0 = F16 ? acc[mt * NT + i][r] * un[q] : acc[mt * NT + i][r];
+                float v = ss::add_rn(ss::mul_rn(a0, sc[q]), sh[q]);
                 if (residual && !res_pre) v = ss::add_rn(v, rv[q][i]);
                 if (relu & 1) v = fmaxf(v, 0.f);
                 if (GATED) v = ss::mul_rn(gv[q][i], v);     // channelAtt gate, broadcast over D
@@ -390,10 +450,48 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned 
     wsplit[i] = (unsigned short)(term == 0 ? h : (term == 1 ? m : l));
 }
 
+// f16 form, pass 1: per output channel, the power of two that brings max |w| into [2^14, 2^15); its inverse is stored
+// behind the packed terms (float[Cout]) for the conv kernel's epilogue.  One workgroup per channel.
+__global__ __launch_bounds__(256) void weight_unscale_f16s_kernel(const float* __restrict__ w, float* __restrict__ wunscale,
+                                                                   int per_co) {
+    __shared__ unsigned wmax[4];
+    const float* wc = w + (size_t)blockIdx.x * per_co;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < per_co; i += 256) m = fmaxf(m, fabsf(wc[i]));
+    const unsigned wm = wave_max_bits(__float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int e = max((int)(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])) >> 23), E_MIN);
+        wunscale[blockIdx.x] = __uint_as_float((unsigned)(127 - E_ONE + e) << 23);
+    }
+}
+
+// pass 2: [Cout,Cin,taps] fp32 -> [ceil(Cin/8)][steps][2 terms][2 halves][Cout][8] fp16 of w / wunscale[co]
+__global__ void pack_weights_f16s_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit,
+                                         const float* __restrict__ wunscale, int Cout, int Cin, int ktaps, long long total) {
+    const int KSTEPS = (ktaps + 1) / 2;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % 8);
+    long long r = i / 8;
+    const int co = (int)(r % Cout); r /= Cout;
+    const int half = (int)(r % 2); r /= 2;
+    const int term = (int)(r % 2); r /= 2;
+    const int s = (int)(r % KSTEPS);
+    const int blk = (int)(r / KSTEPS);
+    const int tap = 2 * s + half, ci = blk * 8 + j;
+    float x = 0.f;
+    if (tap < ktaps && ci < Cin) x = w[((long long)co * Cin + ci) * ktaps + tap] / wunscale[co];   // exact: a power of two
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
+}
+
 template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
-    using C = BCfg<S, NT, TD, TH, KD>;
+    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2>;
     const int Do = (D + 2 * (KD / 2) - KD) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
@@ -457,7 +555,7 @@ static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* s
                                    int W, int Cout, int stride, int relu, int nterms, ss_stream_t stream) {
     SS_REQUIRE(in && wsplit && out);
     SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0);
-    SS_REQUIRE((stride == 1 || stride == 2) && (nterms == 3 || nterms == 6));
+    SS_REQUIRE((stride == 1 || stride == 2) && (nterms == 3 || nterms == 6 || nterms == F16X3));
     SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
     // operands are addressed through 32-bit buffer offsets: one batch element's input must stay below 2 GiB
     if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
@@ -471,7 +569,8 @@ static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* s
     if (forced && forced[0] >= '0' && forced[0] <= '2') tile = forced[0] - '0';
 #define SS_B(S, NT, TD, TH)                                                                                              \
     return (nterms == 6) ? launch_b<S, NT, TD, TH, 6>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st) \
-                         : launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st)
+         : (nterms == 3) ? launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st) \
+                         : launch_b<S, NT, TD, TH, F16X3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st)
     // stride 2 needs a 65-column halo tile per row.  A 1 x 4 output tile is 84 KB of split operands: one workgroup per
     // CU, slower than the exact-fp32 kernel (283 vs 229 us on the largest layer).  A 2 x 2 tile is 78 KB: two
     // workgroups per CU, faster on every stride-2 layer of the model (190 / 95 / 68 / 41 us vs 229 / 122 / 81 / 62).
@@ -487,6 +586,17 @@ extern "C" int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Co
     const long long total = (long long)ss::ceil_div(Cin, 8) * KSTEPS * 3 * 2 * Cout * 8;
     hipLaunchKernelGGL(pack_weights_bf16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
                        ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), Cout, Cin, 27, total);
+    return ss::check_launch();
+}
+
+// the two-term fp16 form of the same weights (nterms = 19 of ss_conv3d_bf16s_fwd): see the top of this file
+extern "C" int ss_pack_conv3d_weights_f16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream) {
+    SS_REQUIRE(w && wsplit && Cout > 0 && Cin > 0);
+    const long long total = (long long)ss::ceil_div(Cin, 8) * KSTEPS * 2 * 2 * Cout * 8;
+    float* wunscale = reinterpret_cast<float*>(reinterpret_cast<char*>(wsplit) + total * 2);
+    hipLaunchKernelGGL(weight_unscale_f16s_kernel, dim3(Cout), dim3(256), 0, ss::as_stream(stream), w, wunscale, Cin * 27);
+    hipLaunchKernelGGL(pack_weights_f16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
+                       ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), wunscale, Cout, Cin, 27, total);
     return ss::check_launch();
 }
 

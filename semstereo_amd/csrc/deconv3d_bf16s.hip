@@ -15,13 +15,13 @@
 #include <algorithm>
 
 #include "common.h"
+#include "split_f16.h"
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
-using f32x2_t = __attribute__((ext_vector_type(2))) float;
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {       // lo16 = bf16(x0), hi16 = bf16(x1), RNE
     const f32x2_t v = {x0, x1};
@@ -51,12 +51,12 @@ __host__ __device__ constexpr int off_of(int s) {
 
 constexpr int KST = 27;           // K-steps per 16-channel chunk
 
-template <int TD, int TH>
+template <int TD, int TH, int LT = 3>      // LT: operand terms kept in LDS
 struct DB {
     static constexpr int ID = TD + 1, IH = TH + 1, IW = 33;
     static constexpr int CS = ID * IH * IW;                    // positions of the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
-    static constexpr size_t LDS_BYTES = (size_t)3 * 2 * CS * 16;
+    static constexpr size_t LDS_BYTES = (size_t)(LT * 2 * CS + 1) * 16;     // + the four waves' maxima (fp16 form)
     static_assert(TD * TH == 4, "4 waves x one input row each");
 };
 
@@ -66,9 +66,14 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
                                                           const uint4* __restrict__ skip_wsplit, float* __restrict__ out,
                                                           int Cin, int D, int H, int W, int Cout, int Cs, int tiles_w,
                                                           int tiles_h, int relu) {
-    using C = DB<TD, TH>;
+    // NTERMS = 19 (F16X3): the main loop on two fp16 terms with block-floating operands (split_f16.h; the scheme of
+    // conv3d_bf16s.hip); the skip projection, whose operand never passes through LDS, stays on three bf16 terms
+    constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [3 terms][2 channel halves][CS]
+    constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed main weights
+    using C = DB<TD, TH, NC>;
+    constexpr int MSLOT = NC * 2 * C::CS;                      // LDS slot of the waves' maxima
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [NC terms][2 channel halves][CS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     int t = blockIdx.x;
@@ -108,7 +113,9 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     const int nchunks = (Cin + 15) / 16;
     const int G = nchunks * KST;
     const int wlane = (half * Cout + min(co0 + l31, Cout - 1)) * 16;
-    const int wstep = 3 * 2 * Cout * 16;                       // bytes per K-step
+    const int wstep = NCW * 2 * Cout * 16;                     // bytes per K-step of the main weights
+    const int swstep = 3 * 2 * Cout * 16;                      // ... of the skip projection's (always three bf16 terms)
+    const float* wunscale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wsplit) + (size_t)G * wstep);
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(wsplit), 0, (int)min((long long)G * wstep, 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     // start together otherwise alternates between a phase where every CU multiplies and one where every CU waits for
     // HBM (measured on the last layer of hourglass2: 173 us of main loop + 61 us of skip reads + 29 us of stores = the
     // 263 us of the whole kernel, nothing overlapped).  Same sums, deterministic per workgroup.
+    constexpr int SNT = F16 ? 6 : NTERMS, SNC = (SNT == 6) ? 3 : 2;      // cross products / terms of the skip projection
     auto skip_phase = [&]() {
         // ---- 1x1x1 projection of the skip tensor at the 8 output positions of every lane: per 16 skip channels one K-step
         // per parity class; the operand (8 channels x this lane's 2x2x2 cube) comes straight from global memory ----
@@ -144,15 +152,15 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             const_cast<float*>(skip + (size_t)b * Cs * schan), 0, (int)min((long long)Cs * (long long)schan * 4, 0x7fffffffLL), 0x00020000);
         const int nks = (Cs + 15) / 16;
         const __amdgpu_buffer_rsrc_t swres = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint4*>(skip_wsplit), 0, nks * wstep, 0x00020000);
+            const_cast<uint4*>(skip_wsplit), 0, nks * swstep, 0x00020000);
         const unsigned lane_s = (unsigned)(((size_t)(2 * jd_) * out_plane + (size_t)(2 * jh_) * Wo + 2 * jw_) * 4);
         const unsigned schan_b = (unsigned)(schan * 4);
 #pragma unroll 1
         for (int ks = 0; ks < nks; ++ks) {
-            bf16x8 a[NC];
+            bf16x8 a[SNC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * wstep + c * 2 * Cout * 16, 0));
+            for (int c = 0; c < SNC; ++c)
+                a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * swstep + c * 2 * Cout * 16, 0));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                  // (pd, ph); the float2 holds pw = 0, 1
                 const unsigned qo = (unsigned)(((size_t)(q >> 1) * out_plane + (size_t)(q & 1) * Wo) * 4);
@@ -173,11 +181,11 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
                     const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
                     const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
                     const int cls = q * 2 + pw;
-                    if (NTERMS == 6) {
+                    if (SNT == 6) {
                         const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
                         acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], m8, acc[cls], 0, 0, 0);
                         acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], l8, acc[cls], 0, 0, 0);
-                        acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NC - 1], h8, acc[cls], 0, 0, 0);
+                        acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SNC - 1], h8, acc[cls], 0, 0, 0);
                     }
                     acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], m8, acc[cls], 0, 0, 0);
                     acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], h8, acc[cls], 0, 0, 0);
@@ -190,8 +198,38 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
 
     const bool skip_first = HAS_SKIP && ((blockIdx.x ^ blockIdx.y) & 1);
 #ifndef SS_ABL_D_SKIP
-    if (HAS_SKIP && skip_first) skip_phase();
+    if (HAS_SKIP && skip_first) {
+        skip_phase();
+        if (F16) {      // the main loop's accumulators carry the channel's weight scale (a power of two: exact)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ws = __uint_as_float((254u << 23) - __float_as_uint(wunscale[min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1)]));
+#pragma unroll
+                for (int p = 0; p < 8; ++p) acc[p][r] *= ws;
+            }
+        }
+    }
 #endif
+    // fp16 form: block-floating scale of the staged chunk (see conv3d_bf16s.hip)
+    int e_cur = E_ONE, e_run = E_MIN;
+    auto publish_max = [&](float m) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) m = fmaxf(m, fabsf(rin[q]));
+        const unsigned wm = wave_max_bits(__float_as_uint(m));
+        if (lane == 0) reinterpret_cast<unsigned*>(&lds[MSLOT])[wave] = wm;
+    };
+    if (F16) {
+        float m0 = 0.f;
+        if (HAS_SKIP && skip_first) {                          // see E_INIT_SHIFT (split_f16.h)
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, fabsf(acc[p][r]));
+            m0 *= __uint_as_float((unsigned)(127 - E_INIT_SHIFT) << 23);
+        }
+        publish_max(m0);
+        __syncthreads();
+    }
 #ifdef SS_ABL_D_MAIN
     const int nchunks_run = 0;
 #else
@@ -200,6 +238,21 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     for (int ck = 0, g0 = 0; ck < nchunks_run; ++ck, g0 += KST) {
         const int ci0 = ck * 16;
         // ---- split + transpose: registers -> [term][half][position] ----
+        float in_scale = 1.f;
+        if (F16) {
+            const uint4 wm = lds[MSLOT];
+            const int e_new = max(e_run, (int)(max(max(wm.x, wm.y), max(wm.z, wm.w)) >> 23));
+            e_run = e_new;
+            if (e_new != e_cur) {                              // wave-uniform; exact power-of-two rescale
+                const float ratio = __uint_as_float((unsigned)max(127 + e_cur - e_new, 0) << 23);
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][r] *= ratio;
+                e_cur = e_new;
+            }
+            in_scale = __uint_as_float((unsigned)(127 + E_ONE - e_cur) << 23);
+        }
 #pragma unroll
         for (int i = 0; i < C::NPOS; ++i) {
             const int p = tid + 256 * i;
@@ -210,8 +263,10 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int c0 = hf * 8 + 2 * c;
-                    split3_pk((ci0 + c0 < Cin) ? rin[c0 * C::NPOS + i] : 0.f, (ci0 + c0 + 1 < Cin) ? rin[(c0 + 1) * C::NPOS + i] : 0.f,
-                              hh[c], mm[c], ll[c]);
+                    const float x0 = (ci0 + c0 < Cin) ? rin[c0 * C::NPOS + i] : 0.f;
+                    const float x1 = (ci0 + c0 + 1 < Cin) ? rin[(c0 + 1) * C::NPOS + i] : 0.f;
+                    if (F16) split2_pk_f16(x0 * in_scale, x1 * in_scale, hh[c], mm[c]);
+                    else split3_pk(x0, x1, hh[c], mm[c], ll[c]);
                 }
                 lds[(0 * 2 + hf) * C::CS + p] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
                 lds[(1 * 2 + hf) * C::CS + p] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
@@ -240,21 +295,33 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             }
             // first tap of an offset group: fetch the next group's activation fragment
             if ((s == 0 || off_of(s) != off_of(s - 1)) && off_of(s) < 7) read_b(bnxt, off_of(s) + 1);
-            bf16x8 a[NC], bq[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                a[c] = __builtin_bit_cast(bf16x8, aq[s % 3][c]);
-                bq[c] = __builtin_bit_cast(bf16x8, bcur[c]);
-            }
             const int cls = cls_of(s);
-            if (NTERMS == 6) {
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[NC - 1], acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NC - 1], bq[0], acc[cls], 0, 0, 0);
+            if (F16) {
+                f16x8 a[NC], bq[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    a[c] = __builtin_bit_cast(f16x8, aq[s % 3][c]);
+                    bq[c] = __builtin_bit_cast(f16x8, bcur[c]);
+                }
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[1], acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bq[0], acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[0], acc[cls], 0, 0, 0);
+            } else {
+                bf16x8 a[NC], bq[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    a[c] = __builtin_bit_cast(bf16x8, aq[s % 3][c]);
+                    bq[c] = __builtin_bit_cast(bf16x8, bcur[c]);
+                }
+                if (NTERMS == 6) {
+                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], acc[cls], 0, 0, 0);
+                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[NC - 1], acc[cls], 0, 0, 0);
+                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NC - 1], bq[0], acc[cls], 0, 0, 0);
+                }
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[cls], 0, 0, 0);
             }
-            acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], acc[cls], 0, 0, 0);
-            acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], acc[cls], 0, 0, 0);
-            acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[cls], 0, 0, 0);
             // last tap of an offset group: the prefetched fragment becomes current
             if (s + 1 < KST && off_of(s + 1) != off_of(s)) {
 #pragma unroll
@@ -263,7 +330,17 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             __builtin_amdgcn_sched_barrier(0);
         }
         // steps 27, 28 of this chunk are steps 0, 1 of the next: re-base the fragment ring (27 % 3 == 0: already in place)
+        if (F16 && more) publish_max(0.f);                        // of the chunk staged next
         __syncthreads();
+    }
+    if (F16) {          // back to plain values: 2^-(activation scale) x the channel's 2^-(weight scale), exact
+        const float au = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float un = au * wunscale[min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1)];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[p][r] *= un;
+        }
     }
 
 #ifndef SS_ABL_D_SKIP
@@ -314,10 +391,43 @@ __global__ void pack_deconv_weights_kernel(const float* __restrict__ wpack, unsi
     wsplit[i] = (unsigned short)((term == 0 ? h : (term == 1 ? m : l)) & 0xffffu);
 }
 
+// fp16 form, pass 1: per output channel the power of two bringing max |w| into [2^14, 2^15); its inverse goes behind the terms
+__global__ __launch_bounds__(256) void deconv_weight_unscale_f16s_kernel(const float* __restrict__ wpack, float* __restrict__ wunscale,
+                                                                          int Cout, int rows) {
+    __shared__ unsigned wmax[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) m = fmaxf(m, fabsf(wpack[(size_t)i * Cout + blockIdx.x]));
+    const unsigned wm = wave_max_bits(__float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int e = max((int)(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])) >> 23), E_MIN);
+        wunscale[blockIdx.x] = __uint_as_float((unsigned)(127 - E_ONE + e) << 23);
+    }
+}
+// pass 2: -> [ceil(Cin/16)][27 K-steps][2 terms][2 channel halves][Cout][8] fp16 of w / wunscale[co]
+__global__ void pack_deconv_weights_f16s_kernel(const float* __restrict__ wpack, unsigned short* __restrict__ wsplit,
+                                                const float* __restrict__ wunscale, int Cin, int Cout, long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % 8);
+    long long r = i / 8;
+    const int co = (int)(r % Cout); r /= Cout;
+    const int hf = (int)(r % 2); r /= 2;
+    const int term = (int)(r % 2); r /= 2;
+    const int s = (int)(r % 27);
+    const int chunk = (int)(r / 27);
+    const int ci = chunk * 16 + hf * 8 + j;
+    const float x = (ci < Cin) ? wpack[((size_t)ci * 27 + tap_of(s)) * Cout + co] / wunscale[co] : 0.f;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
+}
+
 template <int TD, int TH, int NTERMS, bool HAS_SKIP>
 int launch_db(const float* in, const void* wsplit, const float* shift, const float* skip, const void* skip_wsplit, float* out,
               int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu, hipStream_t st) {
-    using C = DB<TD, TH>;
+    using C = DB<TD, TH, (NTERMS == 6) ? 3 : 2>;
     const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, TH), tiles_d = ss::ceil_div(D, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
@@ -335,11 +445,10 @@ int launch_db(const float* in, const void* wsplit, const float* shift, const flo
 template <int TD, int TH>
 int launch_db_all(const float* in, const void* wsplit, const float* shift, const float* skip, const void* skip_wsplit,
                   float* out, int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu, int nterms, hipStream_t st) {
-    if (skip != nullptr)
-        return nterms == 6 ? launch_db<TD, TH, 6, true>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st)
-                           : launch_db<TD, TH, 3, true>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st);
-    return nterms == 6 ? launch_db<TD, TH, 6, false>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st)
-                       : launch_db<TD, TH, 3, false>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st);
+#define SS_DB(NTERMS, HAS_SKIP) launch_db<TD, TH, NTERMS, HAS_SKIP>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st)
+    if (skip != nullptr) return nterms == 6 ? SS_DB(6, true) : (nterms == 3 ? SS_DB(3, true) : SS_DB(F16X3, true));
+    return nterms == 6 ? SS_DB(6, false) : (nterms == 3 ? SS_DB(3, false) : SS_DB(F16X3, false));
+#undef SS_DB
 }
 
 }  // namespace
@@ -352,11 +461,22 @@ extern "C" int ss_pack_deconv3d_weights_bf16s(const float* wpack, void* wsplit, 
     return ss::check_launch();
 }
 
+// the two-term fp16 form of the main weights (nterms = 19 of ss_deconv3d_bf16s_fwd; the skip projection keeps the bf16 form)
+extern "C" int ss_pack_deconv3d_weights_f16s(const float* wpack, void* wsplit, int Cin, int Cout, ss_stream_t stream) {
+    SS_REQUIRE(wpack && wsplit && Cin > 0 && Cout > 0);
+    const long long total = (long long)((Cin + 15) / 16) * 27 * 2 * 2 * Cout * 8;
+    float* wunscale = reinterpret_cast<float*>(reinterpret_cast<char*>(wsplit) + total * 2);
+    hipLaunchKernelGGL(deconv_weight_unscale_f16s_kernel, dim3(Cout), dim3(256), 0, ss::as_stream(stream), wpack, wunscale, Cout, Cin * 27);
+    hipLaunchKernelGGL(pack_deconv_weights_f16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0, ss::as_stream(stream),
+                       wpack, reinterpret_cast<unsigned short*>(wsplit), wunscale, Cin, Cout, total);
+    return ss::check_launch();
+}
+
 extern "C" int ss_deconv3d_bf16s_fwd(const float* in, const void* wsplit, const float* shift, const float* skip,
                                      const void* skip_wsplit, float* out, int B, int Cin, int D, int H, int W, int Cout,
                                      int Cs, int relu, int nterms, ss_stream_t stream) {
     SS_REQUIRE(in && wsplit && out);
-    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && (nterms == 3 || nterms == 6 || nterms == F16X3));
     SS_REQUIRE((skip == nullptr) || (skip_wsplit != nullptr && Cs > 0));
     SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0 && (reinterpret_cast<uintptr_t>(skip_wsplit) & 15) == 0);
     if ((reinterpret_cast<uintptr_t>(out) & 7) != 0) return SS_ERR_INVALID;

@@ -127,16 +127,22 @@ def deconv3d_hip(x, wpack, shift, relu, skip=None, skip_wpack=None):
     return out
 
 
-def pack_deconv_weight_bf16s(wpack):
+def pack_deconv_weight_bf16s(wpack, nterms=6):
     """fp32 pack [Cin][ntaps][Cout] (ntaps 27: transposed conv, BN scale folded; or [Cs][Cout]: the skip projection)
-    -> split-bf16 fragments for ss_deconv3d_bf16s_fwd."""
+    -> split fragments for ss_deconv3d_bf16s_fwd: three bf16 terms, or (nterms 19, main weights only) two scaled fp16
+    terms + the per-channel inverse scales."""
     wpack = wpack.detach().float().contiguous()
     _lib.require_device(wpack)
     Cin, Cout = wpack.shape[0], wpack.shape[-1]
     ntaps = 1 if wpack.dim() == 2 else wpack.shape[1]
-    out = torch.empty(((Cin + 15) // 16) * ntaps * 3 * 2 * Cout * 8, dtype=torch.int16, device=wpack.device)
     with torch.cuda.device(wpack.device):
-        call("ss_pack_deconv3d_weights_bf16s", ptr(wpack), ptr(out), Cin, Cout, ntaps)
+        if nterms == 19:
+            assert ntaps == 27
+            out = torch.empty(((Cin + 15) // 16) * 27 * 2 * 2 * Cout * 8 + 2 * Cout, dtype=torch.int16, device=wpack.device)
+            call("ss_pack_deconv3d_weights_f16s", ptr(wpack), ptr(out), Cin, Cout)
+        else:
+            out = torch.empty(((Cin + 15) // 16) * ntaps * 3 * 2 * Cout * 8, dtype=torch.int16, device=wpack.device)
+            call("ss_pack_deconv3d_weights_bf16s", ptr(wpack), ptr(out), Cin, Cout, ntaps)
     return out
 
 
@@ -163,19 +169,43 @@ def deconv3d_bf16s_hip(x, wsplit, Cout, shift, relu, nterms, skip=None, skip_wsp
 #: projections of the attention blocks.
 #: Default bf16x6: its measured error against fp64 is BELOW the exact-fp32 MFMA's (1.1e-7 vs 1.8e-7 of
 #: sum|a*b|, tools/exp_split_bf16.hip) at ~1.5x its speed; SS_CONV_ENGINE=f32 selects the exact engine.
-CONV_ENGINE = os.environ.get("SS_CONV_ENGINE", "bf16x6")
+#: "f16x3": the tiled 3x3x3 convs (stride 1 and 2) on TWO fp16 terms and three products with block-floating operands
+#: (same accuracy class as bf16x6, half its matrix-core time: conv3d_bf16s.hip); the other kernels stay on bf16x6.
+CONV_ENGINE = os.environ.get("SS_CONV_ENGINE", "f16x3")
+_NTERMS_TILED = {"bf16x6": 6, "bf16x3": 3, "f16x3": 19}          # `nterms` codes of ss_conv3d_bf16s_fwd
+_NTERMS_AUX = {"bf16x6": 6, "bf16x3": 3, "f16x3": 6, "f32": 6}   # kernels without an fp16 form (f32: unused)
+
+
+def _tiled_nterms():
+    return _NTERMS_TILED[CONV_ENGINE]
+
+
+def _aux_nterms():
+    return _NTERMS_AUX[CONV_ENGINE]
+
+
+DECONV_F16 = os.environ.get("SS_DECONV_F16", "1") != "0"        # f16x3 engine: the transposed convs' main loop on fp16 terms too
+
+
+def _deconv_nterms():
+    return _NTERMS_TILED[CONV_ENGINE] if DECONV_F16 else _NTERMS_AUX[CONV_ENGINE]
 DECONV_BF16S = os.environ.get("SS_DECONV_BF16S", "1") != "0"     # transposed convs on the split engine too (else exact fp32 MFMA)
 
 
-def pack_conv_weight_bf16s(w):
-    """[Cout,Cin,3,3,3] fp32 -> split-bf16 fragments for ss_conv3d_bf16s_fwd (int16 tensor, 16-B aligned)."""
+def pack_conv_weight_bf16s(w, nterms=6):
+    """[Cout,Cin,3,3,3] fp32 -> split fragments for ss_conv3d_bf16s_fwd (int16 tensor, 16-B aligned): three bf16 terms
+    (nterms 6 / 3) or two scaled fp16 terms + the per-channel inverse scales (nterms 19)."""
     w = w.detach().float().contiguous()
     _lib.require_device(w)
     Cout, Cin = w.shape[0], w.shape[1]
     assert tuple(w.shape[2:]) == (3, 3, 3)
-    out = torch.empty(((Cin + 7) // 8) * 14 * 3 * 2 * Cout * 8, dtype=torch.int16, device=w.device)
     with torch.cuda.device(w.device):
-        call("ss_pack_conv3d_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
+        if nterms == 19:
+            out = torch.empty(((Cin + 7) // 8) * 14 * 2 * 2 * Cout * 8 + 2 * Cout, dtype=torch.int16, device=w.device)
+            call("ss_pack_conv3d_weights_f16s", ptr(w), ptr(out), Cout, Cin)
+        else:
+            out = torch.empty(((Cin + 7) // 8) * 14 * 3 * 2 * Cout * 8, dtype=torch.int16, device=w.device)
+            call("ss_pack_conv3d_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
     return out
 
 
@@ -240,7 +270,7 @@ def run_conv2d(owner, key, conv, bn, x, relu):
     """Conv2d(3x3, s1, p1, no bias) [+ BN(eval)] [+ ReLU] of a 2-D map on the split-bf16 engine; None when it does not apply."""
     if not (CONV2D_HIP and CONV_ENGINE != "f32" and _is_plain_3x3(conv) and x.is_cuda):
         return None
-    nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+    nterms = _aux_nterms()
     srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
     def build():
@@ -322,17 +352,17 @@ def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
     """Fused Conv3d -> BN(eval) [-> +residual] [-> ReLU] [-> * sigmoid(gate)] on the selected engine."""
     k, s = _conv_geometry(conv)
     if CONV_ENGINE != "f32" and k == 3 and s in (1, 2) and conv.out_channels > 1:
-        nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+        nterms = _tiled_nterms()
         srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
         def build():
             sc, sh = fold_bn(bn) if bn is not None else (None, None)
-            return pack_conv_weight_bf16s(conv.weight), sc, sh
-        ws, scale, shift = _cache(owner).get(key + "/bf16s", srcs, build)
+            return pack_conv_weight_bf16s(conv.weight, nterms), sc, sh
+        ws, scale, shift = _cache(owner).get(key + ("/f16s" if nterms == 19 else "/bf16s"), srcs, build)
         return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual, gate, stride=s)
     if (CONV_ENGINE != "f32" and k == 3 and s == 1 and conv.out_channels == 1 and conv.in_channels in (16, 32, 64)
             and residual is None and gate is None):
-        nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+        nterms = _aux_nterms()
         srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
         def build_head():
@@ -437,8 +467,8 @@ def _stem_halves_params(stem, C):
         wf = torch.zeros(Cout // 2, 64, C, dtype=w.dtype, device=w.device)
         wf[:, :54] = wl.reshape(Cout // 2, 2, C, 27).permute(0, 3, 1, 2).reshape(Cout // 2, 54, C)
         return (pack_pointwise_weight_bf16s(wq), pack_pointwise_weight_bf16s(wf.reshape(Cout // 2 * 64, C)),
-                pack_conv_weight_bf16s(w[:, C:].contiguous()), sc, sh)
-    return _cache(stem).get("bc/halves", srcs, build)
+                pack_conv_weight_bf16s(w[:, C:].contiguous(), _tiled_nterms()), sc, sh)
+    return _cache(stem).get("bc/halves/" + CONV_ENGINE, srcs, build)
 
 
 def stem_broadcast_half(stem, left, att):
@@ -447,7 +477,7 @@ def stem_broadcast_half(stem, left, att):
     (3.6 instead of 87 GFLOP on the bench shape).  -> [B,Cout,nd,H,W], no BatchNorm / ReLU applied."""
     assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, left, att)
     C, Cout = left.shape[1], stem.conv.out_channels
-    nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+    nterms = _aux_nterms()
     wq, wf, _, _, _ = _stem_halves_params(stem, C)
     PATH_COUNTS["hip"] += 1
     if C == 32 and Cout % 2 == 0 and STEM_LEFT_FUSED:
@@ -460,7 +490,7 @@ def stem_volume_half(stem, right_vol, partial, gate_logits=None):
     """`stem` over its last C input channels (`right_vol` [B,C,nd,H,W]) continuing `partial`, then BatchNorm, ReLU
     and the optional channelAtt gate on the total."""
     assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, right_vol, partial, gate_logits)
-    nterms = {"bf16x6": 6, "bf16x3": 3}[CONV_ENGINE]
+    nterms = _tiled_nterms()
     _, _, wr, scale, shift = _stem_halves_params(stem, right_vol.shape[1])
     g = None if gate_logits is None else torch.sigmoid(gate_logits).contiguous()
     return conv3d_bf16s_hip(right_vol, wr, stem.conv.out_channels, scale, shift, bool(stem.relu), nterms, None, g, partial=partial)
@@ -534,7 +564,7 @@ class attention_block(nn.Module):
                 # projection -> per-(window, 4 heads) attention -> projection: three launches that each fill
                 # the chip at batch 1 (the fused kernel has one workgroup per window)
                 wq, bq, wo, bo, bf = self._params_split()
-                nterms = 3 if CONV_ENGINE == "bf16x3" else 6
+                nterms = _aux_nterms()
                 if bf:
                     qkv = conv3d_pointwise_bf16s_hip(x, wq, 3 * C, None, bq, False, nterms)
                 else:
@@ -621,8 +651,9 @@ class hourglass(nn.Module):
             wd = pack_conv_weight(dc.weight, transposed=True) * ds.reshape(1, 1, -1)
             wr = pack_conv_weight(rc.weight).reshape(rc.weight.shape[1], rc.weight.shape[0]) * rs.reshape(1, -1)
             wd, wr = wd.contiguous(), wr.contiguous()
-            return wd, wr, (db + rb).contiguous(), pack_deconv_weight_bf16s(wd), pack_deconv_weight_bf16s(wr)
-        return _cache(self).get(key, srcs, build)
+            return (wd, wr, (db + rb).contiguous(), pack_deconv_weight_bf16s(wd, _deconv_nterms()) if CONV_ENGINE != "f32" else None,
+                    pack_deconv_weight_bf16s(wr) if CONV_ENGINE != "f32" else None)
+        return _cache(self).get(key + "/" + CONV_ENGINE, srcs, build)
 
     def _up(self, key, deconv_seq, redir_seq, x, skip):
         wd, wr, shift, wds, wrs = self._up_params(key, deconv_seq, redir_seq)
@@ -631,7 +662,7 @@ class hourglass(nn.Module):
         # layers with fewer workgroups than CUs: the exact-fp32 kernel's even/odd-plane split doubles them (67 vs 88 us on
         # the bench's smallest layer); everything else: split-bf16
         if CONV_ENGINE != "f32" and DECONV_BF16S and workgroups >= 256:
-            return deconv3d_bf16s_hip(x, wds, wd.shape[2], shift, True, 3 if CONV_ENGINE == "bf16x3" else 6, skip, wrs)
+            return deconv3d_bf16s_hip(x, wds, wd.shape[2], shift, True, _deconv_nterms(), skip, wrs)
         return deconv3d_hip(x, wd, shift, relu=True, skip=skip, skip_wpack=wr)
 
     def forward(self, x):

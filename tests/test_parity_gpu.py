@@ -357,7 +357,7 @@ def test_conv3d_kernel(sa, case):
     check(f"conv3d/{case}", y, ref, 2e-4)
 
 
-@pytest.mark.parametrize("engine", ["f32", "bf16x6"])
+@pytest.mark.parametrize("engine", ["f32", "bf16x6", "f16x3"])
 def test_conv3d_fused_channel_gate(sa, engine):
     """concat_stem + concat_feature_att_4 (models/SemStereo.py:319-320) as ONE kernel:
     sigmoid(gate)[:, :, None] * relu(bn(conv(x)))."""
@@ -374,8 +374,9 @@ def test_conv3d_fused_channel_gate(sa, engine):
         y = sa.modules.conv3d_hip(dev(x), sa.modules.pack_conv_weight(dev(w)), dev(scale), dev(shift), 3, 1, True,
                                   None, dev(torch.sigmoid(gate)))
     else:
-        y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w)), Cout, dev(scale), dev(shift),
-                                        True, 6, None, dev(torch.sigmoid(gate)))
+        nt = 19 if engine == "f16x3" else 6
+        y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w), nt), Cout, dev(scale), dev(shift),
+                                        True, nt, None, dev(torch.sigmoid(gate)))
     check(f"conv3d_gate/{engine}", y, ref, 2e-5)
 
 
@@ -509,8 +510,9 @@ def test_conv3d_head_split_bf16(sa, case, nterms):
     assert float((yn.double().cpu() - refn).abs().max()) <= (4e-6 if nterms == 6 else 4e-5)
 
 
+@pytest.mark.parametrize("nterms", [6, 19])
 @pytest.mark.parametrize("case", [(64, 128, 4, 7, 40), (32, 64, 6, 10, 34), (20, 40, 3, 5, 9), (64, 128, 16, 64, 64)])
-def test_conv3d_split_bf16_stride2(sa, case):
+def test_conv3d_split_bf16_stride2(sa, case, nterms):
     """the stride-2 instantiation of the split-bf16 conv (odd sizes, ragged channels) against float64 and the exact-fp32 kernel"""
     import torch.nn.functional as F
     from oracle import detdata as dd
@@ -519,11 +521,11 @@ def test_conv3d_split_bf16_stride2(sa, case):
     w = dd.t_uniform((Cout, Cin, 3, 3, 3), 482, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
     scale, shift = dd.t_uniform((Cout,), 483, 0.5, 1.5), dd.t_uniform((Cout,), 484, -0.2, 0.2)
     ref = F.relu(F.conv3d(x.double(), w.double(), None, 2, 1) * scale.double().reshape(1, -1, 1, 1, 1) + shift.double().reshape(1, -1, 1, 1, 1))
-    y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w)), Cout, dev(scale), dev(shift), True, 6, stride=2)
+    y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w), nterms), Cout, dev(scale), dev(shift), True, nterms, stride=2)
     y32 = sa.modules.conv3d_hip(dev(x), sa.modules.pack_conv_weight(dev(w)), dev(scale), dev(shift), 3, 2, True)
     assert y.shape == ref.shape
     e_split, e_f32 = float((y.double().cpu() - ref).abs().max()), float((y32.double().cpu() - ref).abs().max())
-    REPORT[f"conv3d_s2_bf16x6/{case}"] = e_split
+    REPORT[f"conv3d_s2_{_eng(nterms)}/{case}"] = e_split
     assert e_split <= 1.5 * e_f32 + 1e-6, (e_split, e_f32)
 
 
@@ -561,11 +563,16 @@ BF16S_CASES = [
 ]
 
 
-@pytest.mark.parametrize("nterms", [6, 3])
+def _eng(nterms):
+    return {6: "bf16x6", 3: "bf16x3", 19: "f16x3"}[nterms]
+
+
+@pytest.mark.parametrize("nterms", [6, 3, 19])
 @pytest.mark.parametrize("case", BF16S_CASES)
 def test_conv3d_split_bf16_engine(sa, case, nterms):
-    """fp32 conv emulated with 3-term bf16 operands on the bf16 matrix core: the 6-product form must
-    be as close to the fp32 reference as the exact-fp32 MFMA kernel is, the 3-product form within 4x."""
+    """fp32 conv emulated with 3-term bf16 operands (or two block-floating fp16 terms: nterms 19) on the 16-bit matrix
+    core: the 6-product bf16 form and the fp16 form must be as close to the float64 result as the exact-fp32 MFMA kernel
+    is, the 3-product bf16 form within 4e-5."""
     import torch.nn.functional as F
     from oracle import detdata as dd
     Cin, Cout, D, H, W, relu, use_res = case
@@ -578,21 +585,21 @@ def test_conv3d_split_bf16_engine(sa, case, nterms):
         ref = ref + res.double()
     if relu:
         ref = F.relu(ref)
-    ws = sa.modules.pack_conv_weight_bf16s(dev(w))
+    ws = sa.modules.pack_conv_weight_bf16s(dev(w), nterms)
     y = sa.modules.conv3d_bf16s_hip(dev(x), ws, Cout, dev(scale), dev(shift), relu, nterms, None if res is None else dev(res))
     wp = sa.modules.pack_conv_weight(dev(w))
     y32 = sa.modules.conv3d_hip(dev(x), wp, dev(scale), dev(shift), 3, 1, relu, None if res is None else dev(res))
     e_split = float((y.double().cpu() - ref).abs().max())
     e_f32 = float((y32.double().cpu() - ref).abs().max())
-    REPORT[f"conv3d_bf16x{nterms}/{case}"] = e_split
+    REPORT[f"conv3d_{_eng(nterms)}/{case}"] = e_split
     REPORT[f"conv3d_f32mfma_vs_f64/{case}"] = e_f32
-    if nterms == 6:
+    if nterms != 3:
         assert e_split <= 1.5 * e_f32 + 1e-7, (e_split, e_f32)
     else:       # 3 products drop terms of 2^-16 relative size: ~1e-5 absolute on O(1) outputs at small K
         assert e_split <= 4e-5, (e_split, e_f32)
 
 
-@pytest.mark.parametrize("engine", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("engine", ["f32", "bf16x6", "bf16x3", "f16x3"])
 def test_hot_segment_on_each_conv_engine(sa, golden, engine):
     name = "s128"
     old = sa.modules.CONV_ENGINE
@@ -663,7 +670,7 @@ def test_deconv3d_kernel(sa, case, split, monkeypatch):
     check(f"deconv3d/{case}/split{split}", y, ref, 2e-4)
 
 
-@pytest.mark.parametrize("nterms", [6, 3])
+@pytest.mark.parametrize("nterms", [6, 3, 19])
 @pytest.mark.parametrize("case", [(128, 64, 2, 3, 5, 64), (64, 32, 3, 9, 33, 32), (32, 32, 2, 4, 40, 0), (8, 24, 2, 3, 6, 6), (20, 40, 1, 5, 34, 10)])
 def test_deconv3d_split_bf16_engine(sa, case, nterms):
     """ConvTranspose3d + 1x1x1 skip projection + shift + ReLU on the split-bf16 engine (ragged channel chunks, Cout not a
@@ -684,13 +691,86 @@ def test_deconv3d_split_bf16_engine(sa, case, nterms):
     wp = sa.modules.pack_conv_weight(dev(w), transposed=True)
     wsp = None if ws is None else sa.modules.pack_conv_weight(dev(ws)).reshape(Cs, Cout).contiguous()
     y32 = sa.modules.deconv3d_hip(dev(x), wp, dev(shift), True, None if skip is None else dev(skip), wsp)
-    y = sa.modules.deconv3d_bf16s_hip(dev(x), sa.modules.pack_deconv_weight_bf16s(wp), Cout, dev(shift), True, nterms,
+    y = sa.modules.deconv3d_bf16s_hip(dev(x), sa.modules.pack_deconv_weight_bf16s(wp, nterms), Cout, dev(shift), True, nterms,
                                       None if skip is None else dev(skip),
                                       None if wsp is None else sa.modules.pack_deconv_weight_bf16s(wsp))
     e_split, e_f32 = float((y.double().cpu() - ref).abs().max()), float((y32.double().cpu() - ref).abs().max())
-    REPORT[f"deconv3d_bf16x{nterms}/{case}"] = e_split
+    REPORT[f"deconv3d_{_eng(nterms)}/{case}"] = e_split
     REPORT[f"deconv3d_f32_vs_f64/{case}"] = e_f32
-    assert e_split <= (1.5 * e_f32 + 1e-6 if nterms == 6 else 4e-5), (e_split, e_f32)
+    assert e_split <= (1.5 * e_f32 + 1e-6 if nterms != 3 else 4e-5), (e_split, e_f32)
+
+
+F16_RANGE_CASES = {
+    # name: (multiplier per input channel (32 of them), weight multiplier per output channel (32))
+    "tensor_1e-6": (lambda c: 1e-6, lambda c: 1.0),
+    "tensor_1e+6": (lambda c: 1e6, lambda c: 1.0),
+    "tensor_1e-20_weights_1e+12": (lambda c: 1e-20, lambda c: 1e12),
+    "channels_1e-6_to_1e+6": (lambda c: 10.0 ** (-6 + 12 * c / 31), lambda c: 1.0),
+    "channels_1e+6_to_1e-6": (lambda c: 10.0 ** (6 - 12 * c / 31), lambda c: 1.0),
+    "out_channels_1e-8_to_1e+8": (lambda c: 1.0, lambda c: 10.0 ** (-8 + 16 * c / 31)),
+    "one_huge_channel": (lambda c: 3e4 if c == 17 else 1e-3, lambda c: 1.0),
+    "tensor_1e-30": (lambda c: 1e-30, lambda c: 1.0),
+}
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("name", sorted(F16_RANGE_CASES))
+def test_conv3d_f16_form_block_floating_ranges(sa, name, stride):
+    """The fp16 form must not depend on the operands' magnitude: fp16 has 5 exponent bits, so weights are scaled per output
+    channel and activations per staged chunk of the tile (conv3d_bf16s.hip).  Inputs far outside fp16's range, channels
+    12 decades apart in either order (the accumulators are rescaled when the running maximum grows), a partial sum as the
+    initial accumulator: the error against float64, relative to each output channel's rms, stays at the exact-fp32 kernel's."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    in_mul, w_mul = F16_RANGE_CASES[name]
+    Cin = Cout = 32
+    D, H, W = 5, 12, 70
+    x = F.relu(dd.t_normalish((1, Cin, D, H, W), 701)) * torch.tensor([in_mul(c) for c in range(Cin)]).reshape(1, -1, 1, 1, 1)
+    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 702, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    w = w * torch.tensor([w_mul(c) for c in range(Cout)]).reshape(-1, 1, 1, 1, 1)
+    x, w = x.float(), w.float()
+    ref = F.conv3d(x.double(), w.double(), None, stride, 1)
+    one, zero = dev(torch.ones(Cout)), dev(torch.zeros(Cout))
+    y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w), 19), Cout, one, zero, False, 19, stride=stride)
+    y32 = sa.modules.conv3d_hip(dev(x), sa.modules.pack_conv_weight(dev(w)), one, zero, 3, stride, False)
+    assert bool(torch.isfinite(y).all())
+    rms = ref.pow(2).mean(dim=(0, 2, 3, 4), keepdim=True).sqrt().clamp_min(1e-300)
+    e = float(((y.double().cpu() - ref) / rms).abs().max())
+    e32 = float(((y32.double().cpu() - ref) / rms).abs().max())
+    REPORT[f"conv3d_f16x3_range/{name}/s{stride}"] = e
+    assert e <= 1.5 * e32 + 1e-6, (e, e32)
+    if stride == 1:      # continuing a partial sum of very different magnitude than this half's contribution
+        part = (dd.t_normalish(tuple(ref.shape), 703).double() * rms * 100.0).float()
+        yp = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w), 19), Cout, one, zero, False, 19, partial=dev(part))
+        refp = ref + part.double()
+        y6 = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w), 6), Cout, one, zero, False, 6, partial=dev(part))
+        ep = float(((yp.double().cpu() - refp) / (100.0 * rms)).abs().max())
+        ep6 = float(((y6.double().cpu() - refp) / (100.0 * rms)).abs().max())
+        # the accumulator holds the (100x larger) partial sum through ~160 fp32 accumulations: their rounding, in either form
+        assert ep <= 2.0 * ep6 + 1e-6 and ep <= 2e-5, (ep, ep6)
+
+
+@pytest.mark.parametrize("in_mul", [1e-6, 1.0, 1e6])
+def test_deconv3d_f16_form_block_floating_ranges(sa, in_mul):
+    """the transposed conv's fp16 main loop beside its bf16 skip projection of O(1) values, the two 12 decades apart"""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin, Cout, D, H, W, Cs = 48, 40, 3, 9, 35, 16
+    x = (F.relu(dd.t_normalish((1, Cin, D, H, W), 711)) * in_mul).float()
+    w = dd.t_uniform((Cin, Cout, 3, 3, 3), 712, -1, 1) * (3.0 / (Cin * 27 / 8)) ** 0.5
+    skip = dd.t_normalish((1, Cs, 2 * D, 2 * H, 2 * W), 713)
+    ws = dd.t_uniform((Cout, Cs, 1, 1, 1), 714, -1, 1) * (3.0 / Cs) ** 0.5
+    ref = F.conv_transpose3d(x.double(), w.double(), None, stride=2, padding=1, output_padding=1) + F.conv3d(skip.double(), ws.double())
+    wp = sa.modules.pack_conv_weight(dev(w), transposed=True)
+    wsp = sa.modules.pack_conv_weight(dev(ws)).reshape(Cs, Cout).contiguous()
+    zero = dev(torch.zeros(Cout))
+    y = sa.modules.deconv3d_bf16s_hip(dev(x), sa.modules.pack_deconv_weight_bf16s(wp, 19), Cout, zero, False, 19, dev(skip),
+                                      sa.modules.pack_deconv_weight_bf16s(wsp))
+    y32 = sa.modules.deconv3d_hip(dev(x), wp, zero, False, dev(skip), wsp)
+    rms = float(ref.pow(2).mean().sqrt())
+    e, e32 = float((y.double().cpu() - ref).abs().max()) / rms, float((y32.double().cpu() - ref).abs().max()) / rms
+    REPORT[f"deconv3d_f16x3_range/{in_mul}"] = e
+    assert e <= 1.5 * e32 + 1e-6, (e, e32)
 
 
 def test_patch_and_gate_fusion(sa):
