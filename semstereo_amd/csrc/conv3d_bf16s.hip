@@ -25,6 +25,16 @@
 #include "common.h"
 #include "split_f16.h"
 
+#ifdef SS_TIMING     // phase timestamps of every workgroup (tools/wg_phases.py); not part of the product build
+__device__ unsigned long long ss_dbg_t[8 * 16384];
+extern "C" int ss_debug_read(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ss_dbg_t), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#define SS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384 && blockIdx.y == 0 && blockIdx.z == 0) ss_dbg_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SS_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -82,7 +92,8 @@ struct BCfg {
     static_assert(KD == 3 || (KD == 1 && TD == 1), "2-D form: depth-1 tiles");
     static constexpr int CS = ID * IH * IW;                    // positions in the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
-    static constexpr int SLOTS = LT * CS + 2;                  // + one all-zero slot (the 28th half-step) + the waves' maxima (f16 form)
+    // + one all-zero slot (the 28th half-step) + the waves' maxima (f16 form) + the affine of the workgroup's (<= 64) channels
+    static constexpr int SLOTS = LT * CS + 2 + 32;
     static constexpr size_t LDS_BYTES = (size_t)SLOTS * 16;
     static_assert(TD * TH == 4 * NT && TH % NT == 0, "4 waves x NT rows tile TD x TH");
 };
@@ -92,12 +103,16 @@ struct BCfg {
 // MT: 32-channel output tiles per wave (the activation fragments of a row then feed MT x 6 MFMAs: used by the stride-2
 // layers, whose staging is 8x dearer per MFMA and whose 2-4 output tiles would otherwise each stage the same input)
 template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
-__global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
+#ifndef SS_F16_WGS
+#define SS_F16_WGS 2              // workgroups per CU the fp16 form is compiled for
+#endif
+__global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
                                                         float* __restrict__ out,
                                                         int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
-                                                        int tiles_w, int tiles_h, int relu) {
+                                                        int tiles_w, int tiles_h, int relu, int stagger_first,
+                                                        int stagger_shift, int stagger_groups, int stagger_cycles) {
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
     constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed weights
@@ -107,6 +122,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [NC][CS] slots + zero slot + maxima
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // De-phasing (see launch_bgm): the workgroups of the first round start stagger_cycles * g / groups late
+    if (stagger_cycles > 0) {
+        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (bid < stagger_first) {
+            const long long wait = (long long)stagger_cycles * ((bid >> stagger_shift) % stagger_groups) / stagger_groups;
+            const long long t0 = __builtin_readcyclecounter();
+            while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    SS_STAMP(0);
     const int l31 = lane & 31, half = lane >> 5;
     int t = blockIdx.x;
     const int tw = t % tiles_w; t /= tiles_w;
@@ -121,24 +146,51 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     // relu bit 0: ReLU; bit 1: `residual` is added BEFORE the affine, i.e. it is the initial value of the accumulator
     // (a partial sum of the same convolution computed elsewhere, stem_left.hip).  It is then read here, under the
     // first chunk's staging, instead of in the epilogue where nothing hides its latency.
+#ifdef SS_ABL_RES
+    const bool res_pre = false;
+#else
     const bool res_pre = (relu & 2) != 0 && residual != nullptr;
+#endif
     // f16 form: float[Cout] of 2^-(weight scale of the channel), stored behind the packed terms
     const float* wunscale = reinterpret_cast<const float*>(
         reinterpret_cast<const char*>(wsplit) + (size_t)((Cin + 7) / 8) * C::KSTEPS * ((NTERMS == F16X3 ? 2 : 3) * 2 * Cout * 16));
+    // Output-side addressing (partial sum in, result out, gate, residual): buffer descriptors per batch element with a
+    // 32-bit per-lane offset per row and a scalar offset per channel, positions outside the volume parked beyond the
+    // buffer (loads give 0, stores are dropped): no 64-bit per-lane arithmetic and no branches around the 64 stores of a
+    // lane (they were ~35 instructions and 3.5 branches per store).
+    const size_t out_plane = (size_t)Ho * Wo;
+    const unsigned ochan_b = (unsigned)((size_t)Do * out_plane * 4), gchan_b = (unsigned)(out_plane * 4);
+    const int obytes = (int)min((long long)Cout * (long long)ochan_b, 0x7fffffffLL);
+    unsigned vout[NT], vgate[NT];
+    {
+        const int ow_ = ow0 + l31, od_ = od0 + dzw;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int oh_ = oh0 + hy0 + i;
+            const bool ok = ow_ < Wo && od_ < Do && oh_ < Ho;
+            vout[i] = ok ? (unsigned)((((size_t)od_ * Ho + oh_) * Wo + ow_) * 4) + 4u * half * ochan_b : 0x80000000u;
+            vgate[i] = ok ? (unsigned)(((size_t)oh_ * Wo + ow_) * 4) + 4u * half * gchan_b : 0x80000000u;
+        }
+    }
+    // this lane's channel of fragment register r of output tile mt: cbase(mt, r) + 4 * half
+    auto cbase = [&](int mt, int r) { return co0 + mt * 32 + (r & 3) + 8 * (r >> 2); };
     f32x16 acc[MT * NT];                  // index mt * NT + row
     if (res_pre) {
-        const int ow_ = min(ow0 + l31, Wo - 1), od_ = min(od0 + dzw, Do - 1);
+        const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(residual) + (size_t)b * Cout * Do * out_plane, 0, obytes, 0x00020000);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int oh_ = min(oh0 + hy0 + i, Ho - 1);
+            for (int r = 0; r < 16; ++r) {
+                const int cb = cbase(mt, r);
+                const bool cok = cb + 4 * half < Cout;
+                // f16 form: the accumulator carries the channel's weight scale (a power of two: exact)
+                const float ws = F16 ? __uint_as_float((254u << 23) - __float_as_uint(wunscale[min(cb + 4 * half, Cout - 1)])) : 1.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = min(co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
-                    acc[mt * NT + i][r] = residual[(((size_t)b * Cout + co) * Do + od_) * ((size_t)Ho * Wo) + (size_t)oh_ * Wo + ow_];
-                    // f16 form: the accumulator carries the channel's weight scale (a power of two: exact)
-                    if (F16) acc[mt * NT + i][r] *= __uint_as_float((254u << 23) - __float_as_uint(wunscale[co]));
+                for (int i = 0; i < NT; ++i) {
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                  pres, (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, 0));
+                    acc[mt * NT + i][r] = F16 ? v * ws : v;
                 }
             }
     } else {
@@ -176,6 +228,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
     float rin[NQ];
     int nlive = min(8, Cin), nlive_next = 8;                 // channels that exist in the staged / prefetched chunk
     if (tid == 0) lds[ZSLOT] = make_uint4(0u, 0u, 0u, 0u);
+    // per-channel epilogue constants, fetched now and parked in LDS: read after the K loop they cost two exposed round
+    // trips to L2/HBM per workgroup (tools/wg_phases.py).  aff[0][c] = scale (x 2^-(weight scale) in the f16 form), aff[1][c] = shift
+    float* aff = reinterpret_cast<float*>(&lds[ZSLOT + 2]);
+    if (tid < 32 * MT) {
+        const int co = min(co0 + tid, Cout - 1);
+        float sc0 = scale ? scale[co] : 1.0f;
+        if (F16) sc0 *= wunscale[co];                          // a power of two: exact
+        aff[tid] = sc0;
+        aff[64 + tid] = shift ? shift[co] : 0.0f;
+    }
 
     // weight fragments: [global K-step g = blk*14 + s][term][half][Cout][8 bf16] as uint4 slots; lanes of
     // output channels beyond Cout read a clamped (valid) column and are dropped in the epilogue
@@ -233,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
         publish_max(m0);
         __syncthreads();
     }
+    SS_STAMP(1);
 
     for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
         // ---- split + transpose: registers -> [term][position][8 ch] ----
@@ -335,6 +398,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int r = 0; r < RP; ++r) {
+#ifdef SS_ABL_MFMA      // one cheap VALU op per MFMA that keeps both operands live
+                            acc[mt * NT + i0 + r][p] += __uint_as_float(a[mt][pa[p]].x ^ bcur[r][pb[p]].y);
+                            continue;
+#endif
                             if (F16)
                                 acc[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                     __builtin_bit_cast(f16x8, a[mt][pa[p]]), __builtin_bit_cast(f16x8, bcur[r][pb[p]]),
@@ -375,58 +442,80 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16s(const float* __restrict__
                     for (int c = 0; c < NC; ++c) aq[k][mt][c] = tq[k][mt][c];
         }
         nlive = nlive_next;
-        if (F16 && more) publish_max(0.f);                        // of the chunk staged next (its loads were issued >= 4 K-steps ago)
+#ifndef SS_ABL_MAX
+        if (F16 && more) publish_max(0.f);
+#endif                        // of the chunk staged next (its loads were issued >= 4 K-steps ago)
 #ifndef SS_ABL_BAR2
         __syncthreads();
 #endif
     }
 
-    // ---- epilogue (identical to conv3d_mfma: the 32x32 D layout does not depend on the input type) ----
-    const int ow = ow0 + l31;
-    const int od = od0 + dzw;
-    if (ow >= Wo || od >= Do) return;
-    const size_t out_plane = (size_t)Ho * Wo;
-    // f16 form: 2^-(activation scale) and the per-channel 2^-(weight scale) stored behind the packed weights
+    SS_STAMP(2);
+    // ---- epilogue: 32x32 D layout (col = lane & 31 = output column, row = channel, see cbase) ----
+    // f16 form: 2^-(activation scale); the per-channel 2^-(weight scale) is stored behind the packed weights
     const float acc_unscale = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
-    // the side inputs (affine, gate, residual) of a group of 4 fragment rows are fetched first, with
-    // clamped (always valid) addresses and no branches, so their latencies overlap instead of chaining
+    const float* obase = out + (size_t)b * Cout * Do * out_plane;
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(obase), 0, obytes, 0x00020000);
+    // a residual added after the affine (none when it was the initial accumulator): an empty buffer reads as zeros
+    const bool res_epi = residual != nullptr && !res_pre;
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(res_epi ? residual + (size_t)b * Cout * Do * out_plane : obase), 0, res_epi ? obytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(GATED ? gate + (size_t)b * Cout * out_plane : obase), 0,
+        GATED ? (int)min((long long)Cout * (long long)gchan_b, 0x7fffffffLL) : 0, 0x00020000);
+    const float floor_v = (relu & 1) ? 0.f : -__builtin_inff();
+    // the side inputs (affine, gate, residual) of a group of EG fragment rows are fetched first so that their latencies
+    // overlap instead of chaining; every group costs one exposed round trip (load -> store -> the next group's loads)
+#ifndef SS_EPI_GROUP
+#define SS_EPI_GROUP 8
+#endif
+    constexpr int EG = SS_EPI_GROUP;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 4) {
-        float sc[4], sh[4], un[4], gv[4][NT], rv[4][NT];
+    for (int r0 = 0; r0 < 16; r0 += EG) {
+        float sc[EG], sh[EG], gv[EG][NT], rv[EG][NT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = r0 + q;
-            const int co = min(co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
-            sc[q] = scale ? scale[co] : 1.0f;
-            sh[q] = shift ? shift[co] : 0.0f;
-            if (F16) un[q] = wunscale[co] * acc_unscale;       // powers of two: the products below are exact
+        for (int q = 0; q < EG; ++q) {
+            const int cb = cbase(mt, r0 + q);
+            const bool cok = cb + 4 * half < Cout;
+            sc[q] = aff[cb - co0 + 4 * half];
+            sh[q] = aff[64 + cb - co0 + 4 * half];
+            if (F16) sc[q] *= acc_unscale;                     // powers of two: exact, so is (acc * un) * sc == acc * (un * sc)
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const int oh = min(oh0 + hy0 + i, Ho - 1);
-                gv[q][i] = GATED ? gate[(((size_t)b * Cout + co) * Ho + oh) * Wo + ow] : 1.0f;
-                rv[q][i] = (residual && !res_pre) ? residual[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] : 0.0f;
+                if (GATED) gv[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                      gres, (int)(cok ? vgate[i] : 0x80000000u), cb * (int)gchan_b, 0));
+                rv[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                         rres, (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, 0));
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < EG; ++q) {
             const int r = r0 + q;
-            const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co >= Cout) continue;
+            const int cb = cbase(mt, r);
+            const bool cok = cb + 4 * half < Cout;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const int oh = oh0 + hy0 + i;
-                if (oh >= Ho) continue;
-                const float a0 = F16 ? acc[mt * NT + i][r] * un[q] : acc[mt * NT + i][r];
-                float v = ss::add_rn(ss::mul_rn(a0, sc[q]), sh[q]);
-                if (residual && !res_pre) v = ss::add_rn(v, rv[q][i]);
-                if (relu & 1) v = fmaxf(v, 0.f);
+                float v = ss::add_rn(ss::mul_rn(acc[mt * NT + i][r], sc[q]), sh[q]);
+                v = fmaxf(ss::add_rn(v, rv[q][i]), floor_v);
                 if (GATED) v = ss::mul_rn(gv[q][i], v);     // channelAtt gate, broadcast over D
-                out[(((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + ow] = v;
+#ifdef SS_ABL_STORE
+                if (v == 123456.f)
+#endif
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)(cok ? vout[i] : 0x80000000u),
+                                                      cb * (int)ochan_b, 0);
             }
         }
     }
+    SS_STAMP(3);
+#ifdef SS_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 16384 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        ss_dbg_t[blockIdx.x * 8 + 4] = hw;
+    }
+#endif
 }
 
 // [Cout,Cin,3,3,3] fp32 -> [ceil(Cin/8)][14 steps][3 terms][2 halves][Cout][8] bf16 (zero padded)
@@ -503,8 +592,28 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
         if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
     }
     dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32 * MT), B);
+    // Workgroups of equal duration that all start together stay in lock-step: every CU stages at the same time, multiplies
+    // at the same time and stores at the same time, so the prologue and the epilogue run at the chip's HBM bandwidth (512
+    // workgroups x 64 KB of stores at once: 9.6 us of a 53 us lifetime on concat_stem, tools/wg_phases.py) while HBM idles
+    // during the K loops.  The workgroups of the first round therefore start spread over one estimated lifetime; the later
+    // rounds inherit the spread, each slot being refilled when its workgroup ends.
+    static const int resident = [&] {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, C::LDS_BYTES) != hipSuccess || per_cu <= 0) per_cu = 2;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        return per_cu * cus;
+    }();
+    static const int st_pct = getenv("SS_CONV_STAGGER") ? atoi(getenv("SS_CONV_STAGGER")) : 0;       // % of the estimated lifetime
+    static const int st_groups = getenv("SS_CONV_STAGGER_GROUPS") ? atoi(getenv("SS_CONV_STAGGER_GROUPS")) : 4;
+    static const int st_shift = getenv("SS_CONV_STAGGER_SHIFT") ? atoi(getenv("SS_CONV_STAGGER_SHIFT")) : 0;
+    const long long total_wgs = nt * grid.y * grid.z;
+    // lifetime estimate: the matrix-core cycles of two waves per SIMD (x 32 cycles per MFMA) + as much again for the rest
+    const long long life = 2LL * ((Cin + 7) / 8) * C::KSTEPS * NT * MT * ((NTERMS == 6) ? 6 : 3) * 32 * 2;
+    const int stagger = (total_wgs > 2LL * resident && st_pct > 0) ? (int)std::min<long long>(life * st_pct / 100, 1 << 22) : 0;
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
-                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
+                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu, resident, st_shift,
+                       std::max(st_groups, 1), stagger);
     return ss::check_launch();
 }
 
@@ -561,6 +670,7 @@ static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* s
     if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     hipStream_t st = ss::as_stream(stream);
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    if ((long long)Cout * Do * Ho * Wo * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;      // ... and so must its output
     auto blocks = [&](int td, int th) {
         return (long long)ss::ceil_div(Wo, 32) * ss::ceil_div(Ho, th) * ss::ceil_div(Do, td) * ss::ceil_div(Cout, 32) * B;
     };
