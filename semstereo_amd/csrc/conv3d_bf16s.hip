@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     }
     SS_STAMP(1);
 
+#ifdef SS_TIMING
+    long long t_steps = 0;
+#endif
     for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
         // ---- split + transpose: registers -> [term][position][8 ch] ----
         // (SS_ABL_*: timing ablations built by tools/ablate_conv.sh only -- results are wrong with them)
@@ -338,6 +341,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #endif
         const bool more = ci0 + 8 < Cin;
         nlive_next = min(8, Cin - ci0 - 8);
+#ifdef SS_TIMING
+        const long long tk0 = __builtin_readcyclecounter();
+#endif
 
         // B fragments are read one row GROUP ahead of their MFMAs.  With RP = 2 the MFMAs of two rows
         // alternate so that no two consecutive ones share an accumulator (SS_ROW_PAIR; no gain measured).
@@ -442,6 +448,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                     for (int c = 0; c < NC; ++c) aq[k][mt][c] = tq[k][mt][c];
         }
         nlive = nlive_next;
+#ifdef SS_TIMING
+        t_steps += (long long)__builtin_readcyclecounter() - tk0;
+#endif
 #ifndef SS_ABL_MAX
         if (F16 && more) publish_max(0.f);
 #endif                        // of the chunk staged next (its loads were issued >= 4 K-steps ago)
@@ -486,9 +495,23 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             for (int i = 0; i < NT; ++i) {
                 if (GATED) gv[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                                       gres, (int)(cok ? vgate[i] : 0x80000000u), cb * (int)gchan_b, 0));
-                rv[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                         rres, (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, 0));
             }
+        }
+        if (res_epi) {                                         // one uniform branch per group, none per element
+#pragma unroll
+            for (int q = 0; q < EG; ++q) {
+                const int cb = cbase(mt, r0 + q);
+                const bool cok = cb + 4 * half < Cout;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    rv[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             rres, (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, 0));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EG; ++q)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) rv[q][i] = 0.f;
         }
 #pragma unroll
         for (int q = 0; q < EG; ++q) {
@@ -514,6 +537,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         ss_dbg_t[blockIdx.x * 8 + 4] = hw;
+        ss_dbg_t[blockIdx.x * 8 + 5] = (unsigned long long)t_steps;
     }
 #endif
 }

@@ -37,6 +37,7 @@ t = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
 t0 = t[:, 0].min()
 pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
 print(f"{engine} [{mode}] {n} workgroups: shader clock cycles")
-for name, v in (("prologue", pro), ("K loop", loop), ("epilogue", epi), ("lifetime", t[:, 3] - t[:, 0])):
-    print(f"  {name:9s} mean {v.mean():8.1f}  p10 {np.percentile(v, 10):8.1f}  p50 {np.percentile(v, 50):8.1f}  p90 {np.percentile(v, 90):8.1f}")
+steps = t[:, 5]
+for name, v in (("prologue", pro), ("K loop", loop), (" K-steps", steps), (" chunk boundaries", loop - steps), ("epilogue", epi), ("lifetime", t[:, 3] - t[:, 0])):
+    print(f"  {name:18s} mean {v.mean():8.1f}  p10 {np.percentile(v, 10):8.1f}  p50 {np.percentile(v, 50):8.1f}  p90 {np.percentile(v, 90):8.1f}")
 print(f"  kernel span {t[:, 3].max() - t0} ticks; sum of lifetimes / span / 256 CUs = {(t[:, 3] - t[:, 0]).sum() / (t[:, 3].max() - t0) / 256:.2f} resident workgroups per CU")
