@@ -208,6 +208,9 @@ int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const float* scale,
                         const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int relu,
                         int nterms, ss_stream_t stream);
 int ss_pack_conv2d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
+/* two-term fp16 form of the 2-D weights (nterms = 19 of ss_conv2d_bf16s_fwd; see ss_pack_conv3d_weights_f16s):
+ * ceil(Cin/8)*5*2*2*Cout*16 + 4*Cout bytes. */
+int ss_pack_conv2d_weights_f16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
 /* The single-output-channel classifier heads, nn.Conv3d(C, 1, 3, padding=1, bias=False)
  * (models/SemStereo.py:228-234, classif.2 / classif_att_.2), on the split-bf16 engine with the 27 taps as
  * the matrix rows:  out [B,1,D,H,W] = relu?(scale[0] * conv(in [B,Cin,D,H,W]) + shift[0]);

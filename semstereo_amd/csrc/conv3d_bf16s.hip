@@ -744,11 +744,21 @@ extern "C" int ss_pack_conv2d_weights_bf16s(const float* w, void* wsplit, int Co
     return ss::check_launch();
 }
 
+extern "C" int ss_pack_conv2d_weights_f16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream) {
+    SS_REQUIRE(w && wsplit && Cout > 0 && Cin > 0);
+    const long long total = (long long)ss::ceil_div(Cin, 8) * 5 * 2 * 2 * Cout * 8;
+    float* wunscale = reinterpret_cast<float*>(reinterpret_cast<char*>(wsplit) + total * 2);
+    hipLaunchKernelGGL(weight_unscale_f16s_kernel, dim3(Cout), dim3(256), 0, ss::as_stream(stream), w, wunscale, Cin * 9);
+    hipLaunchKernelGGL(pack_weights_f16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
+                       ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), wunscale, Cout, Cin, 9, total);
+    return ss::check_launch();
+}
+
 extern "C" int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                                    const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int relu,
                                    int nterms, ss_stream_t stream) {
     SS_REQUIRE(in && wsplit && out);
-    SS_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && (nterms == 3 || nterms == 6 || nterms == F16X3));
     SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
     if ((long long)Cin * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     hipStream_t st = ss::as_stream(stream);
@@ -756,7 +766,8 @@ extern "C" int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const fl
     const int r = relu ? 1 : 0;
 #define SS_B2(NT, TH)                                                                                                      \
     return (nterms == 6) ? launch_bgm<1, NT, 1, TH, 6, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st) \
-                         : launch_bgm<1, NT, 1, TH, 3, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st)
+         : (nterms == 3) ? launch_bgm<1, NT, 1, TH, 3, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st) \
+                         : launch_bgm<1, NT, 1, TH, F16X3, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st)
     if (blocks(16) >= 512) { SS_B2(4, 16); }
     if (blocks(8) >= 512) { SS_B2(2, 8); }
     SS_B2(1, 4);

@@ -22,6 +22,7 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using ss_u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {       // lo16 = bf16(x0), hi16 = bf16(x1), RNE
     const f32x2_t v = {x0, x1};
@@ -56,7 +57,8 @@ struct DB {
     static constexpr int ID = TD + 1, IH = TH + 1, IW = 33;
     static constexpr int CS = ID * IH * IW;                    // positions of the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
-    static constexpr size_t LDS_BYTES = (size_t)(LT * 2 * CS + 1) * 16;     // + the four waves' maxima (fp16 form)
+    // + the four waves' maxima (fp16 form) + the per-channel epilogue constants of the workgroup's 32 channels
+    static constexpr size_t LDS_BYTES = (size_t)(LT * 2 * CS + 1 + 16) * 16;
     static_assert(TD * TH == 4, "4 waves x one input row each");
 };
 
@@ -138,6 +140,14 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
 
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const size_t out_plane = (size_t)Ho * Wo;
+    // per-channel epilogue constants, fetched now and parked in LDS (read after the K loop they are an exposed round trip
+    // to L2/HBM per workgroup): aff[c] = shift, aff[32 + c] = 2^-(weight scale) (fp16 form)
+    float* aff = reinterpret_cast<float*>(&lds[MSLOT + 1]);
+    if (tid < 32) {
+        const int co = min(co0 + tid, Cout - 1);
+        aff[tid] = shift ? shift[co] : 0.0f;
+        aff[32 + tid] = F16 ? wunscale[co] : 1.0f;
+    }
     // Half of the workgroups project the skip tensor BEFORE the main loop, half after it: a grid whose workgroups all
     // start together otherwise alternates between a phase where every CU multiplies and one where every CU waits for
     // HBM (measured on the last layer of hourglass2: 173 us of main loop + 61 us of skip reads + 29 us of stores = the
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         if (F16) {      // the main loop's accumulators carry the channel's weight scale (a power of two: exact)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                // (from global memory: `aff` is not visible before the first barrier)
                 const float ws = __uint_as_float((254u << 23) - __float_as_uint(wunscale[min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1)]));
 #pragma unroll
                 for (int p = 0; p < 8; ++p) acc[p][r] *= ws;
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         const float au = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float un = au * wunscale[min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1)];
+            const float un = au * aff[32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
             for (int p = 0; p < 8; ++p) acc[p][r] *= un;
         }
@@ -347,25 +358,34 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     if (HAS_SKIP && !skip_first) skip_phase();
 #endif
 
-    // ---- epilogue: each lane owns the 2x2x2 output cube of its input position ----
+    // ---- epilogue: each lane owns the 2x2x2 output cube of its input position.  Buffer stores: a 32-bit per-lane offset
+    // per (plane, row) pair of the cube (positions outside the volume parked beyond the buffer: the store is dropped) and
+    // a scalar offset per channel -- no 64-bit per-lane arithmetic, no branches ----
     const int jw = iw0 + l31, jd = id0 + dzw, jh = ih0 + hyw;
-    if (jw >= W || jd >= D || jh >= H) return;
+    const unsigned ochan_b = (unsigned)((size_t)Do * out_plane * 4);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
+        out + (size_t)b * Cout * Do * out_plane, 0, (int)min((long long)Cout * (long long)ochan_b, 0x7fffffffLL), 0x00020000);
+    const bool ok = jw < W && jd < D && jh < H;
+    unsigned vo[4];
+#pragma unroll
+    for (int pdh = 0; pdh < 4; ++pdh)
+        vo[pdh] = ok ? (unsigned)((((size_t)(2 * jd + (pdh >> 1)) * Ho + 2 * jh + (pdh & 1)) * Wo + 2 * jw) * 4) + 4u * half * ochan_b
+                     : 0x80000000u;
+    const float floor_v = relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= Cout) continue;
-        const float sh = shift ? shift[co] : 0.0f;
+        const int cb = co0 + (r & 3) + 8 * (r >> 2);
+        const bool cok = cb + 4 * half < Cout;
+        const float sh = aff[(r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
         for (int pdh = 0; pdh < 4; ++pdh) {
-            const int od = 2 * jd + (pdh >> 1), oh = 2 * jh + (pdh & 1);
-            float v0 = ss::add_rn(acc[pdh * 2 + 0][r], sh);
-            float v1 = ss::add_rn(acc[pdh * 2 + 1][r], sh);
-            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            float* op = out + (((size_t)b * Cout + co) * Do + od) * out_plane + (size_t)oh * Wo + 2 * jw;
+            const float v0 = fmaxf(ss::add_rn(acc[pdh * 2 + 0][r], sh), floor_v);
+            const float v1 = fmaxf(ss::add_rn(acc[pdh * 2 + 1][r], sh), floor_v);
 #ifdef SS_ABL_D_STORE
             if (v0 == 123456.f)
 #endif
-            *reinterpret_cast<float2*>(op) = make_float2(v0, v1);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ss_u32x2, make_float2(v0, v1)), ores,
+                                                  (int)(cok ? vo[pdh] : 0x80000000u), cb * (int)ochan_b, 0);
         }
     }
 }
@@ -482,6 +502,7 @@ extern "C" int ss_deconv3d_bf16s_fwd(const float* in, const void* wsplit, const 
     if ((reinterpret_cast<uintptr_t>(out) & 7) != 0) return SS_ERR_INVALID;
     if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     if (skip != nullptr && (long long)Cs * 8 * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    if ((long long)Cout * 8 * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;       // 32-bit output offsets per batch element
     hipStream_t st = ss::as_stream(stream);
     if (D >= 2 && H < 4)
         return launch_db_all<2, 2>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, nterms, st);

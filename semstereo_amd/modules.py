@@ -230,15 +230,19 @@ def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None,
     return out
 
 
-def pack_conv2d_weight_bf16s(w):
-    """[Cout,Cin,3,3] fp32 -> split-bf16 fragments for ss_conv2d_bf16s_fwd."""
+def pack_conv2d_weight_bf16s(w, nterms=6):
+    """[Cout,Cin,3,3] fp32 -> split fragments for ss_conv2d_bf16s_fwd (three bf16 terms, or two scaled fp16 terms: nterms 19)."""
     w = w.detach().float().contiguous()
     _lib.require_device(w)
     Cout, Cin = w.shape[0], w.shape[1]
     assert tuple(w.shape[2:]) == (3, 3)
-    out = torch.empty(((Cin + 7) // 8) * 5 * 3 * 2 * Cout * 8, dtype=torch.int16, device=w.device)
     with torch.cuda.device(w.device):
-        call("ss_pack_conv2d_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
+        if nterms == 19:
+            out = torch.empty(((Cin + 7) // 8) * 5 * 2 * 2 * Cout * 8 + 2 * Cout, dtype=torch.int16, device=w.device)
+            call("ss_pack_conv2d_weights_f16s", ptr(w), ptr(out), Cout, Cin)
+        else:
+            out = torch.empty(((Cin + 7) // 8) * 5 * 3 * 2 * Cout * 8, dtype=torch.int16, device=w.device)
+            call("ss_pack_conv2d_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
     return out
 
 
@@ -259,24 +263,30 @@ def _is_plain_3x3(conv):
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros")
 
 
-#: concat_feature's 3x3 2-D convs on the split engine instead of MIOpen.  The kernels are faster (110 + 38 us against
-#: 170 + 58 us of Winograd + BatchNorm + clamp) but run on the second stream UNDER the attention branch, where they now
-#: compete for the same matrix pipe: the step is 1 % slower at batch 1 and 1 % faster at batch 4, so it is opt-in
-#: (it also takes MIOpen's per-box algorithm choice out of the matching branch).
-CONV2D_HIP = os.environ.get("SS_CONV2D_HIP", "0") != "0"
+#: concat_feature's 3x3 2-D convs on the split engine instead of MIOpen (which also takes MIOpen's per-box algorithm choice
+#: out of the matching branch).  They run on the second stream UNDER the attention branch and compete with it for the
+#: matrix pipe: with three-term bf16 operands (110 + 38 us against 170 + 58 us of Winograd + BatchNorm + clamp) the step
+#: was 1 % slower at batch 1, with the fp16 form (half the matrix-core time again) it is 2.2 % faster at batch 1 and 4.
+#: "auto": on for the f16x3 engine; SS_CONV2D_HIP=0 / 1 forces it.
+_c2d = os.environ.get("SS_CONV2D_HIP", "auto")
+CONV2D_HIP = "auto" if _c2d == "auto" else (_c2d != "0")
+
+
+def _conv2d_hip_on():
+    return CONV_ENGINE == "f16x3" if CONV2D_HIP == "auto" else bool(CONV2D_HIP)
 
 
 def run_conv2d(owner, key, conv, bn, x, relu):
     """Conv2d(3x3, s1, p1, no bias) [+ BN(eval)] [+ ReLU] of a 2-D map on the split-bf16 engine; None when it does not apply."""
-    if not (CONV2D_HIP and CONV_ENGINE != "f32" and _is_plain_3x3(conv) and x.is_cuda):
+    if not (_conv2d_hip_on() and CONV_ENGINE != "f32" and _is_plain_3x3(conv) and x.is_cuda):
         return None
-    nterms = _aux_nterms()
+    nterms = _tiled_nterms()
     srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
     def build():
         sc, sh = fold_bn(bn) if bn is not None else (None, None)
-        return pack_conv2d_weight_bf16s(conv.weight), sc, sh
-    ws, scale, shift = _cache(owner).get(key + "/2d_bf16s", srcs, build)
+        return pack_conv2d_weight_bf16s(conv.weight, nterms), sc, sh
+    ws, scale, shift = _cache(owner).get(key + "/2d_" + CONV_ENGINE, srcs, build)
     return conv2d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms)
 
 
