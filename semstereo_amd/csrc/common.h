@@ -47,6 +47,13 @@ __device__ __forceinline__ float exp_fast(float x) {
 int ss_softmax_regress_split_launch(const float* logits, float* prob, float* disp, float* var, int B, int maxdisp, int H,
                                     int W, hipStream_t st);
 
+// conv3d_f16p.hip: the pipelined one-workgroup-per-CU instantiation of the fp16-form 3x3x3 stride-1 conv (relu bit 1:
+// `residual` is the initial accumulator), for layers whose grid fills the chip with 2 x 8 x 32 tiles
+bool ss_conv3d_f16p_applicable(int B, int D, int H, int W, int Cout);
+int ss_conv3d_f16p_launch(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
+                          const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu,
+                          hipStream_t st);
+
 #define SS_REQUIRE(cond)              \
     do {                                \
         if (!(cond)) return SS_ERR_INVALID; \

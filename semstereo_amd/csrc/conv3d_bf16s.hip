@@ -709,6 +709,13 @@ static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* s
     // CU, slower than the exact-fp32 kernel (283 vs 229 us on the largest layer).  A 2 x 2 tile is 78 KB: two
     // workgroups per CU, faster on every stride-2 layer of the model (190 / 95 / 68 / 41 us vs 229 / 122 / 81 / 62).
     if (stride == 2) { SS_B(2, 1, 2, 2); }     // 5 x 5 x 65 halo positions: 78 KB of split operands, two workgroups per CU
+    // the pipelined one-workgroup-per-CU form (conv3d_f16p.hip) is opt-in: 9-15 % faster on a plain 32 -> 32 layer launched
+    // alone, no faster inside the step (its input then comes from the infinity cache and the tiled kernel is not as
+    // far behind), and its gated instantiation spills
+    const char* pipe_env = getenv("SS_CONV_PIPE");
+    const bool pipelined = pipe_env != nullptr && atoi(pipe_env) != 0;
+    if (tile == 0 && stride == 1 && nterms == F16X3 && pipelined && !forced && ss_conv3d_f16p_applicable(B, D, H, W, Cout))
+        return ss_conv3d_f16p_launch(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
     if (tile == 0) { SS_B(1, 4, 2, 8); }
     if (tile == 1) { SS_B(1, 2, 1, 8); }
     SS_B(1, 1, 1, 4);

@@ -751,6 +751,43 @@ def test_conv3d_f16_form_block_floating_ranges(sa, name, stride):
         assert ep <= 2.0 * ep6 + 1e-6 and ep <= 2e-5, (ep, ep6)
 
 
+@pytest.mark.parametrize("variant", ["plain", "residual", "partial", "partial+gate"])
+def test_conv3d_f16_pipelined_kernel_matches_the_tiled_one(sa, variant, monkeypatch):
+    """conv3d_f16p.hip (SS_CONV_PIPE=1: one 8-wave workgroup per CU walking the depth tiles of its column, double-buffered
+    LDS image) on a layer large enough for it (>= 3 depth tiles per workgroup), ragged in every dimension, against float64
+    and against the tiled kernel, for each epilogue form."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin, Cout, D, H, W = 20, 40, 45, 130, 250          # 2 x 17 x 8 columns x 2 channel tiles = 544 >= 256 CUs: 12 depth tiles each
+    x = F.relu(dd.t_normalish((1, Cin, D, H, W), 801))
+    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 802, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    scale, shift = dd.t_uniform((Cout,), 803, 0.5, 1.5), dd.t_uniform((Cout,), 804, -0.2, 0.2)
+    conv = F.conv3d(x.double().cuda(), w.double().cuda(), None, 1, 1).cpu()
+    extra = dd.t_normalish(tuple(conv.shape), 805) if variant != "plain" else None
+    gate = torch.sigmoid(dd.t_normalish((1, Cout, H, W), 806)) if variant == "partial+gate" else None
+    aff = lambda t: t * scale.double().reshape(1, -1, 1, 1, 1) + shift.double().reshape(1, -1, 1, 1, 1)
+    if variant == "plain":
+        ref = F.relu(aff(conv))
+    elif variant == "residual":
+        ref = F.relu(aff(conv) + extra.double())
+    else:
+        ref = F.relu(aff(conv + extra.double()))
+        if gate is not None:
+            ref = gate.double().unsqueeze(2) * ref
+    ws = sa.modules.pack_conv_weight_bf16s(dev(w), 19)
+    kw = dict(residual=dev(extra)) if variant == "residual" else (dict(partial=dev(extra)) if extra is not None else {})
+    if gate is not None:
+        kw["gate"] = dev(gate)
+    outs = {}
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("SS_CONV_PIPE", pipe)
+        outs[pipe] = sa.modules.conv3d_bf16s_hip(dev(x), ws, Cout, dev(scale), dev(shift), True, 19, **kw).cpu()
+    e_p, e_t = float((outs["1"].double() - ref).abs().max()), float((outs["0"].double() - ref).abs().max())
+    REPORT[f"conv3d_f16p/{variant}"] = e_p
+    assert e_p <= 1.5 * e_t + 1e-6, (e_p, e_t)
+    assert float((outs["1"] - outs["0"]).abs().max()) <= 2e-5
+
+
 @pytest.mark.parametrize("in_mul", [1e-6, 1.0, 1e6])
 def test_deconv3d_f16_form_block_floating_ranges(sa, in_mul):
     """the transposed conv's fp16 main loop beside its bf16 skip projection of O(1) values, the two 12 decades apart"""
