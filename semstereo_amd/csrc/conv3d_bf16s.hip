@@ -258,6 +258,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     auto load_in = [&](int ch, int i) {                                       // channel ch (absolute), position slot i
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, SS_IN_AUX));
     };
+    auto load_in_masked = [&](int ch, int i, unsigned mask) {                 // mask 0x80000000: beyond the buffer, reads 0
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(poff[i] | mask), ch * chan_b, SS_IN_AUX));
+    };
     const int G = ((Cin + 7) / 8) * KSTEPS;
     // Ring of weight fragments, AP steps ahead: vmcnt retires in order, so a wait for a fragment also
     // waits for every input (HBM) load issued before it -- the distance must cover HBM latency, not L2's.
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #endif
         const bool more = ci0 + 8 < Cin;
         nlive_next = min(8, Cin - ci0 - 8);
+        const unsigned nomore = more ? 0u : 0x80000000u;
 #ifdef SS_TIMING
         const long long tk0 = __builtin_readcyclecounter();
 #endif
@@ -363,20 +367,20 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             // weight fragments two steps ahead, then this step's slice of the next chunk's input
+            // No vector-memory instruction of the K loop sits under a branch: where control flow merges, the compiler's
+            // wait-count pass cannot tell how many loads are younger than the one it waits for and falls back to
+            // vmcnt(0/1) -- every K-step then waited for the input loads it had just issued (seen in the ISA).  Past the
+            // end, the last fragment is requested again and the input loads get an offset beyond the buffer (no access).
 #ifndef SS_ABL_A
-            if (g0 + s + AP < G) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) aq[(s + AP) % AR][mt][c] = load_a(g0 + s + AP, c, mt);
-            }
+                for (int c = 0; c < NC; ++c) aq[(s + AP) % AR][mt][c] = load_a(min(g0 + s + AP, G - 1), c, mt);
 #endif
 #ifndef SS_ABL_IN
-            if (more) {
 #pragma unroll
-                for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q)
-                    rin[q] = load_in(ci0 + 8 + min(q / C::NPOS, nlive_next - 1), q % C::NPOS);
-            }
+            for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q)
+                rin[q] = load_in_masked(min(ci0 + 8, Cin - 1) + min(q / C::NPOS, max(nlive_next, 1) - 1), q % C::NPOS, nomore);
 #endif
             uint4 a[MT][NC];
 #pragma unroll

@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     auto load_in = [&](int ch, int i) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], min(ch, Cin - 1) * chan_b, 0));
     };
+    auto load_in_masked = [&](int ch, int i, unsigned mask) {          // mask 0x80000000: beyond the buffer, reads 0
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(poff[i] | mask), min(ch, Cin - 1) * chan_b, 0));
+    };
     uint4 aq[3][NC];                      // aq[g % 3]
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         }
         __syncthreads();
         const bool more = ck + 1 < nchunks;
+        const unsigned nomore = more ? 0u : 0x80000000u;
 
         uint4 bcur[NC], bnxt[NC];
         auto read_b = [&](uint4 (&dst)[NC], int o) {
@@ -296,14 +300,12 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         read_b(bcur, 0);
 #pragma unroll
         for (int s = 0; s < KST; ++s) {
-            if (g0 + s + 2 < G) {
+            // no vector-memory instruction under a branch (see conv3d_bf16s.hip: the wait-count pass falls back to vmcnt(0)
+            // at control-flow merges): past the end the last fragment is requested again, the input loads go beyond the buffer
 #pragma unroll
-                for (int c = 0; c < NC; ++c) aq[(s + 2) % 3][c] = load_a(g0 + s + 2, c);
-            }
-            if (more) {
+            for (int c = 0; c < NC; ++c) aq[(s + 2) % 3][c] = load_a(min(g0 + s + 2, G - 1), c);
 #pragma unroll
-                for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q) rin[q] = load_in(ci0 + 16 + q / C::NPOS, q % C::NPOS);
-            }
+            for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q) rin[q] = load_in_masked(ci0 + 16 + q / C::NPOS, q % C::NPOS, nomore);
             // first tap of an offset group: fetch the next group's activation fragment
             if ((s == 0 || off_of(s) != off_of(s - 1)) && off_of(s) < 7) read_b(bnxt, off_of(s) + 1);
             const int cls = cls_of(s);
