@@ -100,15 +100,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restr
             const int i = gi * GR + k;
             if (i >= NRW) continue;
             const int r = wave + 4 * i;
-            if (!row_valid(r)) continue;                 // wave-uniform
+            // rows outside the volume are requested beyond the buffer (no access, zeros) instead of skipped: a load under a
+            // branch makes the compiler's wait-count pass fall back to vmcnt(0) at the merge, i.e. drain the whole prefetch
             const int gd = d0 - 1 + r / IH, gh = h0 - 1 + r % IH;
-            const unsigned ro = (unsigned)(((size_t)gd * H + gh) * W * 4);
+            const unsigned off = (row_valid(r) && col_ok) ? lane_off + (unsigned)(((size_t)gd * H + gh) * W * 4) : 0x80000000u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    xg[k][ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        ires, (int)(lane_off + ro), (ks * 16 + j) * chan_b, 0));
+                    xg[k][ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)off, (ks * 16 + j) * chan_b, 0));
         }
     };
     auto process_group = [&](float (&xg)[GR][KS][8], int gi) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restr
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-            if (row_valid(r)) {                          // rows outside the volume contribute zeros
+            {                                            // (rows outside the volume were read as zeros)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     unsigned bh[4], bm[4], bl[4];
@@ -281,7 +281,17 @@ __global__ __launch_bounds__(256, 2) void pointwise_bf16s(const float* __restric
     const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(in + (size_t)b * Cin * npos), 0, (int)min((long long)Cin * npos * 4, 0x7fffffffLL), 0x00020000);
     const int chan_b = (int)(npos * 4);
-    float* ob = out + (size_t)b * Cout * npos;
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
+        out + (size_t)b * Cout * npos, 0, (int)min((long long)Cout * npos * 4, 0x7fffffffLL), 0x00020000);
+    // this wave's 32 (scale, shift) pairs, parked in LDS now (written and read by the same wave: no barrier): fetched
+    // after the MFMAs of every tile they were an exposed round trip to L2 per tile
+    __shared__ float aff[4][64];
+    if (lane < 32) {
+        const int co = min(mt * 32 + lane, Cout - 1);
+        aff[wave][lane] = scale ? scale[co] : 1.0f;
+        aff[wave][32 + lane] = shift ? shift[co] : 0.0f;
+    }
+    const float floor_v = relu ? 0.f : -__builtin_inff();
     const long long t0 = (long long)blockIdx.x * tiles_per_wave;
     float x[KS][8];
     auto lane_offset = [&](long long tile) {
@@ -303,8 +313,9 @@ __global__ __launch_bounds__(256, 2) void pointwise_bf16s(const float* __restric
     for (int it = 0; it < tiles_per_wave; ++it) {
         const long long tile = t0 + it;
         if (tile * 32 >= npos) break;
-        const bool more = it + 1 < tiles_per_wave;
-        const unsigned offn = lane_offset(tile + 1);          // beyond npos: every lane reads zeros
+        // the next tile's loads are issued unconditionally (a load under a branch costs a vmcnt(0) at the merge): beyond
+        // npos, or after the last tile, every lane reads zeros from beyond the buffer
+        const unsigned offn = (it + 1 < tiles_per_wave) ? lane_offset(tile + 1) : 0x80000000u;
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_bf16s(const float* __restric
             unsigned bh[4], bm[4], bl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) split3_pk(x[ks][2 * j], x[ks][2 * j + 1], bh[j], bm[j], bl[j]);
-            if (more) load_step(offn, ks);
+            load_step(offn, ks);
             const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
             const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
             if (NTERMS == 6) {
@@ -328,15 +339,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_bf16s(const float* __restric
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], h8, acc, 0, 0, 0);
         }
         const long long p = tile * 32 + l31;
-        if (p < npos) {
+        const unsigned vo = (p < npos) ? (unsigned)((4LL * half * npos + p) * 4) : 0x80000000u;     // beyond the buffer: dropped
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co >= Cout) continue;
-                float v = ss::add_rn(ss::mul_rn(acc[r], scale ? scale[co] : 1.0f), shift ? shift[co] : 0.0f);
-                if (relu) v = fmaxf(v, 0.f);
-                ob[(size_t)co * npos + p] = v;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int cl = (r & 3) + 8 * (r >> 2);
+            const float v = fmaxf(ss::add_rn(ss::mul_rn(acc[r], aff[wave][cl + 4 * half]), aff[wave][32 + cl + 4 * half]), floor_v);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores,
+                                                  (int)((mt * 32 + cl + 4 * half < Cout) ? vo : 0x80000000u), (mt * 32 + cl) * chan_b, 0);
         }
     }
 }
@@ -394,6 +403,7 @@ extern "C" int ss_conv3d_pointwise_bf16s_fwd(const float* in, const void* wsplit
     SS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && npos > 0 && (nterms == 3 || nterms == 6));
     SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
     if ((long long)Cin * npos * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;     // 32-bit buffer offsets per pair
+    if ((long long)Cout * npos * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     hipStream_t st = ss::as_stream(stream);
 #define SS_PW(KSV)                                                                                                    \
     if (Cin == 16 * KSV)                                                                                              \
