@@ -93,7 +93,7 @@ struct BCfg {
     static constexpr int CS = ID * IH * IW;                    // positions in the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
     // + one all-zero slot (the 28th half-step) + the waves' maxima (f16 form) + the affine of the workgroup's (<= 64) channels
-    static constexpr int SLOTS = LT * CS + 2 + 32;
+    static constexpr int SLOTS = LT * CS + 2 + 48;
     static constexpr size_t LDS_BYTES = (size_t)SLOTS * 16;
     static_assert(TD * TH == 4 * NT && TH % NT == 0, "4 waves x NT rows tile TD x TH");
 };
@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const int dzw = (wave * NT) / TH, hy0 = (wave * NT) % TH;
     const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + l31 * S;     // slot of this lane's first row, tap (0,0,0)
 
-    // relu bit 0: ReLU; bit 1: `residual` is added BEFORE the affine, i.e. it is the initial value of the accumulator
-    // (a partial sum of the same convolution computed elsewhere, stem_left.hip).  It is then read here, under the
-    // first chunk's staging, instead of in the epilogue where nothing hides its latency.
+    // relu bit 0: ReLU; bit 1: `residual` is added BEFORE the affine: a partial sum of the same convolution computed
+    // elsewhere (stem_left.hip).  It joins the accumulator in the epilogue, fetched together with the gate (as initial
+    // accumulators its 64 loads per lane were 14 k cycles of every workgroup's prologue: tools/wg_phases.py).
 #ifdef SS_ABL_RES
     const bool res_pre = false;
 #else
@@ -175,30 +175,10 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // this lane's channel of fragment register r of output tile mt: cbase(mt, r) + 4 * half
     auto cbase = [&](int mt, int r) { return co0 + mt * 32 + (r & 3) + 8 * (r >> 2); };
     f32x16 acc[MT * NT];                  // index mt * NT + row
-    if (res_pre) {
-        const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(residual) + (size_t)b * Cout * Do * out_plane, 0, obytes, 0x00020000);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int i = 0; i < MT * NT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cb = cbase(mt, r);
-                const bool cok = cb + 4 * half < Cout;
-                // f16 form: the accumulator carries the channel's weight scale (a power of two: exact)
-                const float ws = F16 ? __uint_as_float((254u << 23) - __float_as_uint(wunscale[min(cb + 4 * half, Cout - 1)])) : 1.0f;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                  pres, (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, 0));
-                    acc[mt * NT + i][r] = F16 ? v * ws : v;
-                }
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < MT * NT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    }
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const size_t in_plane = (size_t)H * W, chan = (size_t)D * in_plane;
     const float* inb = in + (size_t)b * Cin * chan;
@@ -229,14 +209,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     int nlive = min(8, Cin), nlive_next = 8;                 // channels that exist in the staged / prefetched chunk
     if (tid == 0) lds[ZSLOT] = make_uint4(0u, 0u, 0u, 0u);
     // per-channel epilogue constants, fetched now and parked in LDS: read after the K loop they cost two exposed round
-    // trips to L2/HBM per workgroup (tools/wg_phases.py).  aff[0][c] = scale (x 2^-(weight scale) in the f16 form), aff[1][c] = shift
+    // trips to L2/HBM per workgroup (tools/wg_phases.py).  aff[c] = scale, aff[64 + c] = shift, aff[128 + c] = 2^-(weight scale)
     float* aff = reinterpret_cast<float*>(&lds[ZSLOT + 2]);
     if (tid < 32 * MT) {
         const int co = min(co0 + tid, Cout - 1);
-        float sc0 = scale ? scale[co] : 1.0f;
-        if (F16) sc0 *= wunscale[co];                          // a power of two: exact
-        aff[tid] = sc0;
+        aff[tid] = scale ? scale[co] : 1.0f;
         aff[64 + tid] = shift ? shift[co] : 0.0f;
+        aff[128 + tid] = F16 ? wunscale[co] : 1.0f;            // 2^-(weight scale of the channel)
     }
 
     // weight fragments: [global K-step g = blk*14 + s][term][half][Cout][8 bf16] as uint4 slots; lanes of
@@ -287,15 +266,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         if (lane == 0) reinterpret_cast<unsigned*>(&lds[ZSLOT + 1])[wave] = wm;
     };
     if (F16) {
-        float m0 = 0.f;
-        if (res_pre) {                                                        // see E_INIT_SHIFT
-#pragma unroll
-            for (int i = 0; i < MT * NT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, fabsf(acc[i][r]));
-            m0 *= __uint_as_float((unsigned)(127 - E_INIT_SHIFT) << 23);
-        }
-        publish_max(m0);
+        publish_max(0.f);
         __syncthreads();
     }
     SS_STAMP(1);
@@ -469,10 +440,10 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const float acc_unscale = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
     const float* obase = out + (size_t)b * Cout * Do * out_plane;
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(obase), 0, obytes, 0x00020000);
-    // a residual added after the affine (none when it was the initial accumulator): an empty buffer reads as zeros
+    // the residual: added after the affine, or (res_pre) a partial sum added before it
     const bool res_epi = residual != nullptr && !res_pre;
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(res_epi ? residual + (size_t)b * Cout * Do * out_plane : obase), 0, res_epi ? obytes : 0, 0x00020000);
+        const_cast<float*>(residual ? residual + (size_t)b * Cout * Do * out_plane : obase), 0, residual ? obytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(GATED ? gate + (size_t)b * Cout * out_plane : obase), 0,
         GATED ? (int)min((long long)Cout * (long long)gchan_b, 0x7fffffffLL) : 0, 0x00020000);
@@ -487,21 +458,21 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += EG) {
-        float sc[EG], sh[EG], gv[EG][NT], rv[EG][NT];
+        float sc[EG], sh[EG], un[EG], gv[EG][NT], rv[EG][NT];
 #pragma unroll
         for (int q = 0; q < EG; ++q) {
             const int cb = cbase(mt, r0 + q);
             const bool cok = cb + 4 * half < Cout;
             sc[q] = aff[cb - co0 + 4 * half];
             sh[q] = aff[64 + cb - co0 + 4 * half];
-            if (F16) sc[q] *= acc_unscale;                     // powers of two: exact, so is (acc * un) * sc == acc * (un * sc)
+            un[q] = F16 ? aff[128 + cb - co0 + 4 * half] * acc_unscale : 1.0f;      // powers of two: acc * un is exact
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 if (GATED) gv[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                                       gres, (int)(cok ? vgate[i] : 0x80000000u), cb * (int)gchan_b, 0));
             }
         }
-        if (res_epi) {                                         // one uniform branch per group, none per element
+        if (residual != nullptr) {                             // one uniform branch per group, none per element
 #pragma unroll
             for (int q = 0; q < EG; ++q) {
                 const int cb = cbase(mt, r0 + q);
@@ -524,8 +495,11 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             const bool cok = cb + 4 * half < Cout;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                float v = ss::add_rn(ss::mul_rn(acc[mt * NT + i][r], sc[q]), sh[q]);
-                v = fmaxf(ss::add_rn(v, rv[q][i]), floor_v);
+                float a0 = F16 ? acc[mt * NT + i][r] * un[q] : acc[mt * NT + i][r];
+                if (res_pre) a0 = ss::add_rn(a0, rv[q][i]);                 // the partial sum of the same convolution
+                float v = ss::add_rn(ss::mul_rn(a0, sc[q]), sh[q]);
+                if (res_epi) v = ss::add_rn(v, rv[q][i]);
+                v = fmaxf(v, floor_v);
                 if (GATED) v = ss::mul_rn(gv[q][i], v);     // channelAtt gate, broadcast over D
 #ifdef SS_ABL_STORE
                 if (v == 123456.f)
