@@ -181,6 +181,63 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
     }
 }
 
+// The live form of the concat volume (MODE_CONCAT without the left half, one column per lane) with no branch and no
+// 64-bit per-lane arithmetic in the channel loop: both taps of a row come from ONE unconditional 8-byte buffer load at a
+// clamped column (rows or whole pairs outside the image: an offset beyond the buffer, which reads zeros), the two values
+// are then picked by selects; stores go through a buffer descriptor with a scalar channel offset.  (The generic kernel
+// takes a divergent branch per row and channel around its loads: the compiler then waits with vmcnt(0) after each.)
+template <bool NT>
+__global__ __launch_bounds__(256) void warp_right_gated(const float* __restrict__ y, const float* __restrict__ disp,
+                                                         const float* __restrict__ gate, float* __restrict__ out,
+                                                         int C, int H, int W, int nd, float half_w, float half_h) {
+    const int w = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int h = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int j = blockIdx.z % nd, b = blockIdx.z / nd;
+    if (h >= H) return;                                        // wave-uniform
+    const bool inside = w < W;
+    const long long plane = (long long)H * W;
+    const int pix = h * W + min(w, W - 1);
+    const float dv = disp[((long long)b * nd + j) * plane + pix];
+    const float g = gate ? gate[((long long)b * nd + j) * plane + pix] : 1.0f;
+    // the reference's coordinate round trip (see make_taps)
+    const float gx = ((float)w - dv) / half_w - 1.0f, gy = (float)h / half_h - 1.0f;
+    const float ix = ss::mul_rn(gx + 1.0f, half_w), iy = ss::mul_rn(gy + 1.0f, half_h);
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float fw = ix - xw, fe = 1.0f - fw, fn = iy - yn, fs = 1.0f - fn;
+    const float w_nw = ss::mul_rn(fs, fe), w_ne = ss::mul_rn(fs, fw), w_sw = ss::mul_rn(fn, fe), w_se = ss::mul_rn(fn, fw);
+    // columns: west tap xi, east tap xi + 1; the pair is fetched at xc = clamp(xi, 0, W - 2)
+    const bool xfin = (xw >= -1.0f) && (xw <= (float)(W - 1));      // at least one tap of the pair inside
+    const int xi = xfin ? (int)xw : -2;
+    const int xc = min(max(xi, 0), W - 2);
+    const bool west_is_y = (xi == xc + 1);                     // xi = W - 1: the west tap is the pair's second element
+    const bool east_is_x = (xi == xc - 1);                     // xi = -1: the east tap is the pair's first element
+    const bool west_ok = xfin && xi >= 0, east_ok = xfin && xi <= W - 2;
+    const int yi = (int)yn;
+    const bool n_ok = (yn > -1.0f) && (yn < (float)H), s_ok = (yn + 1.0f > -1.0f) && (yn + 1.0f < (float)H);
+    const unsigned off_n = (inside && xfin && n_ok) ? (unsigned)((yi * W + xc) * 4) : 0x80000000u;
+    const unsigned off_s = (inside && xfin && s_ok) ? (unsigned)(((yi + 1) * W + xc) * 4) : 0x80000000u;
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(y + (long long)b * C * plane), 0, (int)min((long long)C * plane * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
+        out + (long long)b * C * nd * plane, 0, (int)min((long long)C * nd * plane * 4, 0x7fffffffLL), 0x00020000);
+    const unsigned off_o = inside ? (unsigned)(((long long)j * plane + pix) * 4) : 0x80000000u;
+    const int ystep = (int)(plane * 4), ostep = (int)((long long)nd * plane * 4);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const f2 pn = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(yres, (int)off_n, c * ystep, 0));
+        const f2 ps = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(yres, (int)off_s, c * ystep, 0));
+        const float a = west_ok ? (west_is_y ? pn.y : pn.x) : 0.f, bq = east_ok ? (east_is_x ? pn.x : pn.y) : 0.f;
+        const float cq = west_ok ? (west_is_y ? ps.y : ps.x) : 0.f, d = east_ok ? (east_is_x ? ps.x : ps.y) : 0.f;
+        float r = ss::mul_rn(a, w_nw);
+        r = ss::add_rn(r, ss::mul_rn(bq, w_ne));
+        r = ss::add_rn(r, ss::mul_rn(cq, w_sw));
+        r = ss::add_rn(r, ss::mul_rn(d, w_se));
+        if (gate) r = ss::mul_rn(g, r);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), ores, (int)off_o, c * ostep, NT ? 2 : 0);
+    }
+}
+
 template <int MODE>
 int launch(const float* x, const float* y, const float* disp, const float* gate, float* out0, float* out1, int B,
            int C, int H, int W, int nd, hipStream_t st) {
@@ -199,6 +256,14 @@ int launch(const float* x, const float* y, const float* disp, const float* gate,
     const int planes = (MODE == MODE_CORR) ? 1 : ((MODE == MODE_CONCAT && x != nullptr) || out1 != nullptr) ? 2 * C : C;
     int nt = (size_t)B * planes * nd * H * W * sizeof(float) > ((size_t)192 << 20);
     if (const char* f = getenv("SS_WARP_STREAM")) nt = f[0] == '1';      // tuning aid
+    static const bool fast_ok = getenv("SS_WARP_GENERIC") == nullptr;
+    if (MODE == MODE_CONCAT && x == nullptr && !v4 && fast_ok && W >= 2 && (long long)C * nd * H * W * 4 < 0x7fffffffLL &&
+        (long long)B * nd <= 65535) {
+        const dim3 grid(ss::ceil_div(W, 64), ss::ceil_div(H, 4), B * nd);
+        if (nt) hipLaunchKernelGGL(warp_right_gated<true>, grid, dim3(256), 0, st, y, disp, gate, out0, C, H, W, nd, half_w, half_h);
+        else hipLaunchKernelGGL(warp_right_gated<false>, grid, dim3(256), 0, st, y, disp, gate, out0, C, H, W, nd, half_w, half_h);
+        return ss::check_launch();
+    }
     if (v4)
         hipLaunchKernelGGL((warp_kernel<MODE, 4>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, disp, gate, out0,
                            out1, C, H, W, nd, half_w, half_h, total, nt);

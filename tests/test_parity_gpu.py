@@ -167,6 +167,32 @@ def test_warp_streaming_stores_identical(sa, monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 7, 64, 5), (1, 5, 9, 37, 3), (1, 4, 3, 2, 2), (1, 32, 4, 130, 24)])
+@pytest.mark.parametrize("gated", [True, False])
+def test_warp_right_half_fast_path(sa, shape, gated):
+    """The live form of the concat volume (left half omitted, warp.hip: warp_right_gated -- one unconditional 8-byte load
+    per tap row at a clamped column, selects instead of branches) against the oracle and, bit for bit, against the generic
+    kernel: fractional disparities, disparities that push one or both taps of a row out of the image on either side,
+    odd and minimal widths, W not a multiple of the 64-column workgroup."""
+    from oracle import detdata as dd
+    B, C, H, W, nd = shape
+    y = dd.t_normalish((B, C, H, W), 151)
+    disp = dd.t_uniform((B, nd, H, W), 152, -1.5 * W, 1.5 * W)
+    disp[:, 0] = torch.round(disp[:, 0])                                    # integers too (the live case)
+    disp[:, -1, :, 0] = 1.0                                                 # w - d = -1: only the east tap inside
+    disp[:, -1, :, -1] = 0.0                                                # w - d = W - 1: only the west tap inside
+    att = dd.t_uniform((B, 1, nd, H, W), 153, 0.0, 1.0) if gated else None
+    yw, _ = oops.SpatialTransformer_grid(y, y, disp)
+    ref = yw if att is None else att * yw
+    out = sa.ops.concat_volume_sampled(None, dev(y), dev(disp), None if att is None else dev(att))
+    # the same launch through the generic kernel: feed a left half and drop it
+    both = sa.ops.concat_volume_sampled(dev(torch.zeros_like(y)), dev(y), dev(disp), None if att is None else dev(att))
+    assert torch.equal(out, both[:, C:])
+    # vs the oracle: the fp32 coordinate round trip (w - d)/((W-1)/2) - 1 -> * (W-1)/2 leaves |d| * 2^-24 in the bilinear
+    # weights of fractional disparities (here |d| up to 1.5 W; ATen's CPU kernel orders the same sums differently)
+    check(f"concat_sampled_right/{shape}/{gated}", out, ref, 5e-5)
+
+
 def test_warp_float4_form_identical(sa, monkeypatch):
     """SS_WARP_VEC=4 (4 columns per lane) against the default one-column-per-lane form, fractional disparities."""
     from oracle import detdata as dd
