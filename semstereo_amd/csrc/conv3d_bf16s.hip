@@ -111,8 +111,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
                                                         float* __restrict__ out,
                                                         int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
-                                                        int tiles_w, int tiles_h, int relu, int stagger_first,
-                                                        int stagger_shift, int stagger_groups, int stagger_cycles) {
+                                                        int tiles_w, int tiles_h, int relu) {
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
     constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed weights
@@ -122,15 +121,6 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [NC][CS] slots + zero slot + maxima
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // De-phasing (see launch_bgm): the workgroups of the first round start stagger_cycles * g / groups late
-    if (stagger_cycles > 0) {
-        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if (bid < stagger_first) {
-            const long long wait = (long long)stagger_cycles * ((bid >> stagger_shift) % stagger_groups) / stagger_groups;
-            const long long t0 = __builtin_readcyclecounter();
-            while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     SS_STAMP(0);
     const int l31 = lane & 31, half = lane >> 5;
     int t = blockIdx.x;
@@ -594,28 +584,11 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
         if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
     }
     dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32 * MT), B);
-    // Workgroups of equal duration that all start together stay in lock-step: every CU stages at the same time, multiplies
-    // at the same time and stores at the same time, so the prologue and the epilogue run at the chip's HBM bandwidth (512
-    // workgroups x 64 KB of stores at once: 9.6 us of a 53 us lifetime on concat_stem, tools/wg_phases.py) while HBM idles
-    // during the K loops.  The workgroups of the first round therefore start spread over one estimated lifetime; the later
-    // rounds inherit the spread, each slot being refilled when its workgroup ends.
-    static const int resident = [&] {
-        int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, C::LDS_BYTES) != hipSuccess || per_cu <= 0) per_cu = 2;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        return per_cu * cus;
-    }();
-    static const int st_pct = getenv("SS_CONV_STAGGER") ? atoi(getenv("SS_CONV_STAGGER")) : 0;       // % of the estimated lifetime
-    static const int st_groups = getenv("SS_CONV_STAGGER_GROUPS") ? atoi(getenv("SS_CONV_STAGGER_GROUPS")) : 4;
-    static const int st_shift = getenv("SS_CONV_STAGGER_SHIFT") ? atoi(getenv("SS_CONV_STAGGER_SHIFT")) : 0;
-    const long long total_wgs = nt * grid.y * grid.z;
-    // lifetime estimate: the matrix-core cycles of two waves per SIMD (x 32 cycles per MFMA) + as much again for the rest
-    const long long life = 2LL * ((Cin + 7) / 8) * C::KSTEPS * NT * MT * ((NTERMS == 6) ? 6 : 3) * 32 * 2;
-    const int stagger = (total_wgs > 2LL * resident && st_pct > 0) ? (int)std::min<long long>(life * st_pct / 100, 1 << 22) : 0;
+    // (Workgroups of equal duration that all start together stay in lock-step -- every CU stages, multiplies and stores at
+    // the same time.  Starting the first round's workgroups spread over 0.5-1.5 estimated lifetimes, in 2-16 groups, was
+    // measured: no gain, -0 .. -8 %.)
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
-                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu, resident, st_shift,
-                       std::max(st_groups, 1), stagger);
+                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
     return ss::check_launch();
 }
 
