@@ -189,6 +189,9 @@ DECONV_F16 = os.environ.get("SS_DECONV_F16", "1") != "0"        # f16x3 engine: 
 
 def _deconv_nterms():
     return _NTERMS_TILED[CONV_ENGINE] if DECONV_F16 else _NTERMS_AUX[CONV_ENGINE]
+#: transposed convs with fewer workgroups than this run on the exact-fp32 kernel, whose even/odd-plane split doubles them
+#: (bf16x6 at 128 workgroups: 88 vs 67 us; the fp16 form: 66 vs 72 us, hence 128 and not 256)
+DECONV_MIN_WORKGROUPS = int(os.environ.get("SS_DECONV_MIN_WGS", "128" if os.environ.get("SS_CONV_ENGINE", "f16x3") == "f16x3" else "256"))
 DECONV_BF16S = os.environ.get("SS_DECONV_BF16S", "1") != "0"     # transposed convs on the split engine too (else exact fp32 MFMA)
 
 
@@ -669,9 +672,8 @@ class hourglass(nn.Module):
         wd, wr, shift, wds, wrs = self._up_params(key, deconv_seq, redir_seq)
         B, _, D, H, W = x.shape
         workgroups = B * D * ((H + 3) // 4) * ((W + 31) // 32) * ((wd.shape[2] + 31) // 32)
-        # layers with fewer workgroups than CUs: the exact-fp32 kernel's even/odd-plane split doubles them (67 vs 88 us on
-        # the bench's smallest layer); everything else: split-bf16
-        if CONV_ENGINE != "f32" and DECONV_BF16S and workgroups >= 256:
+        # layers with few workgroups: the exact-fp32 kernel's even/odd-plane split doubles them (see DECONV_MIN_WORKGROUPS)
+        if CONV_ENGINE != "f32" and DECONV_BF16S and workgroups >= DECONV_MIN_WORKGROUPS:
             return deconv3d_bf16s_hip(x, wds, wd.shape[2], shift, True, _deconv_nterms(), skip, wrs)
         return deconv3d_hip(x, wd, shift, relu=True, skip=skip, skip_wpack=wr)
 
