@@ -17,6 +17,16 @@
 #include "common.h"
 #include "split_f16.h"
 
+#ifdef SS_TIMING     // phase timestamps of every workgroup (development builds only)
+__device__ unsigned long long ss_dbgd_t[8 * 8192];
+extern "C" int ss_debug_read_d(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ss_dbgd_t), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#define SS_DSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0 && blockIdx.z == 0) ss_dbgd_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SS_DSTAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -52,13 +62,14 @@ __host__ __device__ constexpr int off_of(int s) {
 
 constexpr int KST = 27;           // K-steps per 16-channel chunk
 
-template <int TD, int TH, int LT = 3>      // LT: operand terms kept in LDS
+template <int TD, int TH, int LT = 3, bool WLDS = false>      // LT: operand terms kept in LDS; WLDS: + a chunk's weights
 struct DB {
     static constexpr int ID = TD + 1, IH = TH + 1, IW = 33;
     static constexpr int CS = ID * IH * IW;                    // positions of the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
     // + the four waves' maxima (fp16 form) + the per-channel epilogue constants of the workgroup's 32 channels
-    static constexpr size_t LDS_BYTES = (size_t)(LT * 2 * CS + 1 + 16) * 16;
+    static constexpr int WSLOTS = WLDS ? 27 * 2 * 64 : 0;      // [27 K-steps][2 terms][2 halves x 32 channels] 16-byte slots
+    static constexpr size_t LDS_BYTES = (size_t)(LT * 2 * CS + 1 + 16 + WSLOTS) * 16;
     static_assert(TD * TH == 4, "4 waves x one input row each");
 };
 
@@ -73,8 +84,13 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;
     constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed main weights
-    using C = DB<TD, TH, NC>;
+    using C = DB<TD, TH, NC, F16>;
     constexpr int MSLOT = NC * 2 * C::CS;                      // LDS slot of the waves' maxima
+    // fp16 form: the chunk's weight fragments (27 K-steps x 2 terms, 55 KB) are brought into LDS once per workgroup by
+    // LDS-DMA loads (buffer_load_dwordx4 ... lds: no registers) instead of being fetched by each of the four waves: a K-step
+    // has only three MFMAs per wave here, and eight waves per CU re-reading 2 KB of weights every 96 cycles is 85 B/clk
+    // against the 64 B/clk of the vector L1 -- the main loop ran at the L1's pace (tools: phases of this kernel)
+    constexpr int WL = MSLOT + 1 + 16;
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [NC terms][2 channel halves][CS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -134,10 +150,12 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(poff[i] | mask), min(ch, Cin - 1) * chan_b, 0));
     };
     uint4 aq[3][NC];                      // aq[g % 3]
+    if (!F16) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) aq[k][c] = load_a(min(k, G - 1), c);
+            for (int c = 0; c < NC; ++c) aq[k][c] = load_a(min(k, G - 1), c);
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) rin[q] = load_in(q / C::NPOS, q % C::NPOS);
 
@@ -210,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
 
 
     const bool skip_first = HAS_SKIP && ((blockIdx.x ^ blockIdx.y) & 1);
+    SS_DSTAMP(0);
 #ifndef SS_ABL_D_SKIP
     if (HAS_SKIP && skip_first) {
         skip_phase();
@@ -249,9 +268,19 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
 #else
     const int nchunks_run = nchunks;
 #endif
+    SS_DSTAMP(1);
     for (int ck = 0, g0 = 0; ck < nchunks_run; ++ck, g0 += KST) {
         const int ci0 = ck * 16;
         // ---- split + transpose: registers -> [term][half][position] ----
+        if (F16) {          // this chunk's weights: wave w issues the (K-step, term) pairs i = w, w + 4, ...; lane -> (half, channel)
+#pragma unroll
+            for (int k = 0; k < (KST * 2 + 3) / 4; ++k) {
+                const int i = wave + 4 * k;                    // wave-uniform
+                if (i < KST * 2)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (__attribute__((address_space(3))) void*)&lds[WL + i * 64], 16, wlane,
+                                                             (g0 + i / 2) * wstep + (i & 1) * 2 * Cout * 16, 0, 0);
+            }
+        }
         float in_scale = 1.f;
         if (F16) {
             const uint4 wm = lds[MSLOT];
@@ -287,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
                 if (NC == 3) lds[(2 * 2 + hf) * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
             }
         }
+        if (F16) __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the LDS-DMA weight loads have landed
         __syncthreads();
         const bool more = ck + 1 < nchunks;
         const unsigned nomore = more ? 0u : 0x80000000u;
@@ -298,12 +328,21 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             for (int c = 0; c < NC; ++c) dst[c] = lds[(c * 2 + half) * C::CS + slot];
         };
         read_b(bcur, 0);
+        if (F16) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) aq[0][c] = lds[WL + c * 64 + lane];
+        }
 #pragma unroll
         for (int s = 0; s < KST; ++s) {
             // no vector-memory instruction under a branch (see conv3d_bf16s.hip: the wait-count pass falls back to vmcnt(0)
             // at control-flow merges): past the end the last fragment is requested again, the input loads go beyond the buffer
+            if (!F16) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) aq[(s + 2) % 3][c] = load_a(min(g0 + s + 2, G - 1), c);
+                for (int c = 0; c < NC; ++c) aq[(s + 2) % 3][c] = load_a(min(g0 + s + 2, G - 1), c);
+            } else if (s + 1 < KST) {                          // next step's fragments from the LDS copy
+#pragma unroll
+                for (int c = 0; c < NC; ++c) aq[(s + 1) % 3][c] = lds[WL + ((s + 1) * 2 + c) * 64 + lane];
+            }
 #pragma unroll
             for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q) rin[q] = load_in_masked(ci0 + 16 + q / C::NPOS, q % C::NPOS, nomore);
             // first tap of an offset group: fetch the next group's activation fragment
@@ -346,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         if (F16 && more) publish_max(0.f);                        // of the chunk staged next
         __syncthreads();
     }
+    SS_DSTAMP(2);
     if (F16) {          // back to plain values: 2^-(activation scale) x the channel's 2^-(weight scale), exact
         const float au = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
 #pragma unroll
@@ -360,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     if (HAS_SKIP && !skip_first) skip_phase();
 #endif
 
+    SS_DSTAMP(3);
     // ---- epilogue: each lane owns the 2x2x2 output cube of its input position.  Buffer stores: a 32-bit per-lane offset
     // per (plane, row) pair of the cube (positions outside the volume parked beyond the buffer: the store is dropped) and
     // a scalar offset per channel -- no 64-bit per-lane arithmetic, no branches ----
@@ -390,6 +431,10 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
                                                   (int)(cok ? vo[pdh] : 0x80000000u), cb * (int)ochan_b, 0);
         }
     }
+    SS_DSTAMP(4);
+#ifdef SS_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0 && blockIdx.z == 0) ss_dbgd_t[blockIdx.x * 8 + 5] = skip_first;
+#endif
 }
 
 // wpack [Cin][27][Cout] fp32 (ss_pack_conv3d_weights, transposed form, BN scale folded by the caller) ->
@@ -449,7 +494,7 @@ __global__ void pack_deconv_weights_f16s_kernel(const float* __restrict__ wpack,
 template <int TD, int TH, int NTERMS, bool HAS_SKIP>
 int launch_db(const float* in, const void* wsplit, const float* shift, const float* skip, const void* skip_wsplit, float* out,
               int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu, hipStream_t st) {
-    using C = DB<TD, TH, (NTERMS == 6) ? 3 : 2>;
+    using C = DB<TD, TH, (NTERMS == 6) ? 3 : 2, NTERMS == F16X3>;
     const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, TH), tiles_d = ss::ceil_div(D, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
