@@ -85,7 +85,8 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsig
 }
 
 // KD: kernel depth, 3 (3x3x3) or 1 (3x3 over [B,C,H,W] maps seen as depth-1 volumes: 9 taps, 5 K-steps)
-template <int S, int NT, int TD, int TH, int KD = 3, int LT = 3>      // LT: operand terms kept in LDS
+// WSL: 16-byte LDS slots of a chunk's weight fragments (0: every wave fetches its own)
+template <int S, int NT, int TD, int TH, int KD = 3, int LT = 3, int WSL = 0>      // LT: operand terms kept in LDS
 struct BCfg {
     static constexpr int KT = KD * 9, KSTEPS = (KT + 1) / 2;
     static constexpr int ID = (TD - 1) * S + KD, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
@@ -93,10 +94,18 @@ struct BCfg {
     static constexpr int CS = ID * IH * IW;                    // positions in the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
     // + one all-zero slot (the 28th half-step) + the waves' maxima (f16 form) + the affine of the workgroup's (<= 64) channels
-    static constexpr int SLOTS = LT * CS + 2 + 48;
+    static constexpr int SLOTS = LT * CS + 2 + 48 + WSL;
     static constexpr size_t LDS_BYTES = (size_t)SLOTS * 16;
     static_assert(TD * TH == 4 * NT && TH % NT == 0, "4 waves x NT rows tile TD x TH");
 };
+
+constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
+#ifdef SS_NO_WLDS      // A/B builds (tools)
+    return false;
+#else
+    return NTERMS == 19 && S == 1 && NT == 1 && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
+#endif
+}
 
 // GATED: the channelAtt gate is fused into the epilogue (only concat_stem has one, so its launches also carry
 // their own kernel symbol in a profile: conv3d_bf16s<..., true>)
@@ -115,7 +124,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
     constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed weights
-    using C = BCfg<S, NT, TD, TH, KD, NC>;
+    // Small tiles in the fp16 form: a K-step has only 3 MFMAs per row and wave, and eight waves per CU each re-reading the
+    // step's 2 KB of weight fragments every 96-192 cycles ask the vector L1 for 43-85 B/clk of its 64.  The chunk's fragments
+    // (14 steps x 2 terms, 28 KB) are then brought into LDS once per workgroup by LDS-DMA loads (no registers) and read
+    // from there by the four waves (deconv3d_bf16s.hip has the measurement: -11 %).
+    constexpr bool WLDS = wlds_form(S, NT, NTERMS, MT, KD);
+    using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? BCfg<S, NT, TD, TH, KD>::KSTEPS * 2 * 64 : 0>;
+    constexpr int WL = NC * C::CS + 2 + 48;                    // first slot of the weight fragments
     constexpr int KSTEPS = C::KSTEPS;                          // shadows the 3-D constant
     constexpr int ZSLOT = NC * C::CS;                          // the all-zero slot; ZSLOT + 1: the four waves' maxima
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [NC][CS] slots + zero slot + maxima
@@ -235,12 +250,14 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // waits for every input (HBM) load issued before it -- the distance must cover HBM latency, not L2's.
     constexpr int AP = SS_A_AHEAD, AR = AP + 1;
     uint4 aq[AR][MT][NC];                                      // aq[s % AR] = fragments of step s of the chunk
+    if (!WLDS) {
 #pragma unroll
-    for (int k = 0; k < AP; ++k)
+        for (int k = 0; k < AP; ++k)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) aq[k][mt][c] = load_a(min(k, G - 1), c, mt);
+                for (int c = 0; c < NC; ++c) aq[k][mt][c] = load_a(min(k, G - 1), c, mt);
+    }
     {   // first chunk: plain load of every slice
 #pragma unroll
         for (int q = 0; q < NQ; ++q) rin[q] = load_in(min(q / C::NPOS, nlive - 1), q % C::NPOS);
@@ -267,6 +284,14 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
         // ---- split + transpose: registers -> [term][position][8 ch] ----
         // (SS_ABL_*: timing ablations built by tools/ablate_conv.sh only -- results are wrong with them)
+        if constexpr (WLDS) {         // this chunk's weights: wave w issues the (K-step, term) pairs i = w, w + 4, ...; lane -> (half, channel)
+#pragma unroll
+            for (int k = 0; k < (KSTEPS * 2 + 3) / 4; ++k) {
+                const int i = wave + 4 * k;                    // wave-uniform
+                if (i < KSTEPS * 2)
+                    lds_dma16(wres, &lds[WL + i * 64], wlane[0], (g0 + i / 2) * wstep + (i & 1) * 2 * Cout * 16);
+            }
+        }
 #ifndef SS_ABL_SPLIT
         float in_scale = 1.f;
         if (F16) {
@@ -300,6 +325,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
         }
 #endif
+        if (WLDS) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the LDS-DMA weight loads have landed
 #ifndef SS_ABL_BAR1
         __syncthreads();
 #endif
@@ -325,6 +351,10 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         };
 #pragma unroll
         for (int r = 0; r < RP; ++r) read_b(bcur[r], 0, r);
+        if (WLDS) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) aq[0][0][c] = lds[WL + c * 64 + lane];
+        }
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             // weight fragments two steps ahead, then this step's slice of the next chunk's input
@@ -333,10 +363,15 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             // vmcnt(0/1) -- every K-step then waited for the input loads it had just issued (seen in the ISA).  Past the
             // end, the last fragment is requested again and the input loads get an offset beyond the buffer (no access).
 #ifndef SS_ABL_A
+            if (!WLDS) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) aq[(s + AP) % AR][mt][c] = load_a(min(g0 + s + AP, G - 1), c, mt);
+                    for (int c = 0; c < NC; ++c) aq[(s + AP) % AR][mt][c] = load_a(min(g0 + s + AP, G - 1), c, mt);
+            } else if (s + 1 < KSTEPS) {                       // next step's fragments from the LDS copy
+#pragma unroll
+                for (int c = 0; c < NC; ++c) aq[(s + 1) % AR][0][c] = lds[WL + ((s + 1) * 2 + c) * 64 + lane];
+            }
 #endif
 #ifndef SS_ABL_IN
 #pragma unroll
@@ -397,7 +432,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             __builtin_amdgcn_sched_barrier(0);     // keep each step's loads inside the step
         }
         // steps 14 .. 14+AP-1 of this chunk are steps 0 .. AP-1 of the next: re-base the fragment ring
-        {
+        if (!WLDS) {
             uint4 tq[AP][MT][NC];
 #pragma unroll
             for (int k = 0; k < AP; ++k)
@@ -572,7 +607,8 @@ __global__ void pack_weights_f16s_kernel(const float* __restrict__ w, unsigned s
 template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
-    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2>;
+    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2,
+                   wlds_form(S, NT, NTERMS, MT, KD) ? BCfg<S, NT, TD, TH, KD>::KSTEPS * 2 * 64 : 0>;
     const int Do = (D + 2 * (KD / 2) - KD) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;

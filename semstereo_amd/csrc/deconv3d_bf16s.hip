@@ -277,8 +277,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             for (int k = 0; k < (KST * 2 + 3) / 4; ++k) {
                 const int i = wave + 4 * k;                    // wave-uniform
                 if (i < KST * 2)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (__attribute__((address_space(3))) void*)&lds[WL + i * 64], 16, wlane,
-                                                             (g0 + i / 2) * wstep + (i & 1) * 2 * Cout * 16, 0, 0);
+                    lds_dma16(wres, &lds[WL + i * 64], wlane, (g0 + i / 2) * wstep + (i & 1) * 2 * Cout * 16);
             }
         }
         float in_scale = 1.f;

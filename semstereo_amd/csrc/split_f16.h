@@ -32,6 +32,12 @@ __device__ __forceinline__ unsigned wave_max_bits(unsigned x) {
     return max(max((unsigned)__builtin_amdgcn_readlane((int)x, 15), (unsigned)__builtin_amdgcn_readlane((int)x, 31)),
                max((unsigned)__builtin_amdgcn_readlane((int)x, 47), (unsigned)__builtin_amdgcn_readlane((int)x, 63)));
 }
+// One wave-wide LDS-DMA load (buffer_load_dwordx4 ... lds): 64 lanes x 16 bytes from (voffset per lane, soffset) to 1 KB of
+// LDS at `dst`, no registers.  (Kept in a helper: called directly inside some __global__ templates the builtin makes
+// hipcc 7.2 drop the kernel's host stub without a diagnostic.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t res, uint4* dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(res, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
+}
 constexpr int F16X3 = 19;                                       // the ABI's `nterms` code of this form
 // biased fp32 exponents.  A maximum with exponent e is scaled by 2^(E_ONE - e) into [2^14, 2^15); E_MIN floors e so that
 // every scale and its inverse stay normal fp32 numbers (values below 2^-111 are flushed).  Both operands being normalised,
