@@ -190,8 +190,8 @@ DECONV_F16 = os.environ.get("SS_DECONV_F16", "1") != "0"        # f16x3 engine: 
 def _deconv_nterms():
     return _NTERMS_TILED[CONV_ENGINE] if DECONV_F16 else _NTERMS_AUX[CONV_ENGINE]
 #: transposed convs with fewer workgroups than this run on the exact-fp32 kernel, whose even/odd-plane split doubles them
-#: (bf16x6 at 128 workgroups: 88 vs 67 us; the fp16 form: 66 vs 72 us, hence 128 and not 256)
-DECONV_MIN_WORKGROUPS = int(os.environ.get("SS_DECONV_MIN_WGS", "128" if os.environ.get("SS_CONV_ENGINE", "f16x3") == "f16x3" else "256"))
+#: (bf16x6 at 128 workgroups: 88 vs 67 us; the fp16 form: 66 vs 72 us -- 6 us, not worth trading an exact layer for)
+DECONV_MIN_WORKGROUPS = int(os.environ.get("SS_DECONV_MIN_WGS", "256"))
 DECONV_BF16S = os.environ.get("SS_DECONV_BF16S", "1") != "0"     # transposed convs on the split engine too (else exact fp32 MFMA)
 
 
