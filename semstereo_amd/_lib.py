@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

@@ -15,7 +15,7 @@ void note_hip_error(hipError_t e) {
 }
 }  // namespace ss
 
-extern "C" int ss_abi_version(void) { return 3; }   // 3: + head / pointwise / partial-sum convs, attention core, stem_left
+extern "C" int ss_abi_version(void) { return 4; }   // 4: + two-term fp16 forms (nterms = 19, ss_pack_*_f16s), 2-D conv
 
 extern "C" const char* ss_status_string(int status) {
     switch (status) {
