@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (3): bumped on any signature change or new entry point the Python binding requires. */
+/* ABI version (4): bumped on any signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* Static, human-readable text for an ss_status. */
 const char* ss_status_string(int status);
