@@ -139,3 +139,37 @@ def test_shard_bounds_cover_the_batch_exactly_once():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_term_fp16_block_floating_scheme_in_numpy():
+    """The arithmetic behind the f16x3 engine (semstereo_amd/csrc/split_f16.h), restated in numpy: a power-of-two scale taken
+    from the biased exponent of the block maximum puts that maximum into [2^14, 2^15); hi = fp16(x s), lo = fp16(x s - hi)
+    then reconstruct every element within 2^-17 of the maximum to one fp32 ulp (2^-23 relative), and anything smaller to
+    2^-39 of the maximum; the three products kept (hh, hl, lh) miss the exact product by at most the dropped lo*lo."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    E_ONE = 141
+    for mag in (1e-30, 1e-6, 1.0, 3e4, 1e20):
+        x = (rng.standard_normal(4096) * mag).astype(np.float32)
+        x[::7] *= np.float32(2.0 ** -20)                                   # elements far below the block maximum
+        m = np.abs(x).max()
+        e = int(np.float32(m).view(np.uint32) >> 23)                       # biased exponent of the maximum
+        s = np.float32(2.0) ** np.float32(E_ONE - e)
+        assert 2.0 ** 14 <= float(m) * float(s) < 2.0 ** 15
+        xs = x * s                                                          # exact: a power of two
+        hi = xs.astype(np.float16)
+        lo = (xs - hi.astype(np.float32)).astype(np.float16)
+        assert np.isfinite(hi).all() and np.isfinite(lo).all()
+        err = np.abs(xs.astype(np.float64) - hi.astype(np.float64) - lo.astype(np.float64))
+        big = np.abs(xs) >= 2.0 ** -3                                       # lo still a normal fp16 number
+        assert (err[big] <= np.abs(xs[big]).astype(np.float64) * 2.0 ** -23).all()
+        assert (err[~big] <= 2.0 ** -25).all() and 2.0 ** -25 <= float(m) * float(s) * 2.0 ** -39
+        # products: (hi + lo)(hi' + lo') - (hh + hl + lh) = lo * lo'
+        w = (rng.standard_normal(4096)).astype(np.float32)
+        ew = int(np.float32(np.abs(w).max()).view(np.uint32) >> 23)
+        ws = w * np.float32(2.0) ** np.float32(E_ONE - ew)
+        wh = ws.astype(np.float16); wl = (ws - wh.astype(np.float32)).astype(np.float16)
+        h64, l64, wh64, wl64 = (a.astype(np.float64) for a in (hi, lo, wh, wl))
+        kept = h64 * wh64 + h64 * wl64 + l64 * wh64
+        exact = (h64 + l64) * (wh64 + wl64)
+        assert (np.abs(exact - kept) <= np.abs(h64 * wh64) * 2.0 ** -21 + 2.0 ** -46).all()
