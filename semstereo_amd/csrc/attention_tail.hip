@@ -231,14 +231,24 @@ __global__ __launch_bounds__(256) void topk_candidates_split(const float* __rest
     const float* lb = logits + (b * D + q * DQ) * plane;
     float aw[DQ], p[DQ];
     float mx = -INFINITY;
+    // the 5 * DQ loads are issued in batches of 40 BEFORE their sums: left to the compiler each load was followed by its
+    // own s_waitcnt vmcnt(0) (74 of them for D = 64), i.e. one exposed L2 round trip per value
+    constexpr int KB = (DQ % 8 == 0) ? 8 : DQ;
 #pragma unroll
-    for (int k = 0; k < DQ; ++k) {
-        const float* lp = lb + k * plane;
-        float a = 0.f;
+    for (int k0 = 0; k0 < DQ; k0 += KB) {
+        float lv[KB][5];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) a = ss::add_rn(a, ss::mul_rn(lp[nb[t]], st[t]));
-        aw[k] = a;
-        mx = fmaxf(mx, a);
+        for (int k = 0; k < KB; ++k)
+#pragma unroll
+            for (int t = 0; t < 5; ++t) lv[k][t] = lb[(k0 + k) * plane + nb[t]];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) a = ss::add_rn(a, ss::mul_rn(lv[k][t], st[t]));
+            aw[k0 + k] = a;
+            mx = fmaxf(mx, a);
+        }
     }
     redf[q][lane] = mx;
     __syncthreads();
