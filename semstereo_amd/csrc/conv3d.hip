@@ -376,21 +376,29 @@ __global__ __launch_bounds__(256) void depthwise_patch_v4(const float* __restric
     const long long bcd = t;
     const long long bc = bcd / D;
     const int c = (int)(bc % C);
-    const float* ip = in + bcd * H * W;
     float wv[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = w[c * 9 + k];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // all nine input loads unconditional, through a buffer descriptor over this (b, c, d) plane: rows and neighbours
+    // outside it get an offset beyond the buffer and read 0 (under a branch every load is followed by its own
+    // s_waitcnt vmcnt(0): three exposed round trips per thread instead of one)
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + bcd * H * W), 0, H * W * 4, 0x00020000);
+    float4 m[3];
+    float xl[3], xr[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int yy = y + ky - 1;
-        if ((unsigned)yy >= (unsigned)H) continue;
-        const float* rp = ip + (long long)yy * W + x0;
-        const float4 m = *reinterpret_cast<const float4*>(rp);
-        float x[6];
-        x[0] = (x0 > 0) ? rp[-1] : 0.f;
-        x[1] = m.x; x[2] = m.y; x[3] = m.z; x[4] = m.w;
-        x[5] = (x0 + 4 < W) ? rp[4] : 0.f;
+        const bool rok = (unsigned)yy < (unsigned)H;
+        const unsigned ro = (unsigned)((yy * W + x0) * 4);
+        m[ky] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ires, (int)(rok ? ro : 0x80000000u), 0, 0));
+        xl[ky] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)((rok && x0 > 0) ? ro - 4 : 0x80000000u), 0, 0));
+        xr[ky] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)((rok && x0 + 4 < W) ? ro + 16 : 0x80000000u), 0, 0));
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        if ((unsigned)(y + ky - 1) >= (unsigned)H) continue;      // (the reference skips the row: no fma with zeros, -0.0 stays -0.0)
+        const float x[6] = {xl[ky], m[ky].x, m[ky].y, m[ky].z, m[ky].w, xr[ky]};
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
