@@ -150,13 +150,30 @@ __global__ __launch_bounds__(256, 2) void stem_left_fused(const float* __restric
     const int w0 = blockIdx.x * FTW, h0 = blockIdx.y * FTH, b = blockIdx.z;
     const size_t plane = (size_t)H * W;
 
-    const float* ab = att + (size_t)b * ND * plane;
-    for (int e = tid; e < ND * NPOSH; e += 256) {
-        const int x = e % HW;
-        int r = e / HW;
-        const int y = r % HH, j = r / HH;
-        const int gh = h0 + y - 1, gw = w0 + x - 1;
-        atile[j][y][x] = ((unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) ? ab[(size_t)j * plane + (size_t)gh * W + gw] : 0.f;
+    // the att halo tile: every thread's loads are issued together, unconditionally, through a buffer descriptor (positions
+    // outside the map: an offset beyond the buffer, which reads 0).  As a rolled loop of conditional loads this was 19
+    // exposed round trips per workgroup.
+    {
+        const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(att + (size_t)b * ND * plane), 0, (int)min((long long)ND * (long long)plane * 4, 0x7fffffffLL), 0x00020000);
+        constexpr int NE = (ND * NPOSH + 255) / 256;
+        float av[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + 256 * k;
+            const int x = e % HW;
+            int r = e / HW;
+            const int y = r % HH, j = r / HH;
+            const int gh = h0 + y - 1, gw = w0 + x - 1;
+            const bool ok = e < ND * NPOSH && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            av[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  ares, (int)(ok ? (unsigned)(((size_t)j * plane + (size_t)gh * W + gw) * 4) : 0x80000000u), 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + 256 * k;
+            if (e < ND * NPOSH) (&atile[0][0][0])[e] = av[k];
+        }
     }
 
     // this wave's N-tiles of the halo tile (wave, wave + 4): the left map there, split once
@@ -287,7 +304,7 @@ extern "C" int ss_stem_left_fused_fwd(const float* left, const void* wsplit, con
     SS_REQUIRE(B > 0 && C > 0 && Cout > 0 && nd > 0 && H > 0 && W > 0 && (nterms == 3 || nterms == 6));
     SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
     if (C != 32 || Cout % 2 != 0 || B > 65535) return SS_ERR_UNSUPPORTED;
-    if ((long long)C * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    if ((long long)C * H * W * 4 >= 0x7fffffffLL || (long long)nd * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     hipStream_t st = ss::as_stream(stream);
     if (nd == 24) return launch_fused<24>(left, wsplit, att, out, B, Cout, H, W, nterms, st);
     if (nd == 32) return launch_fused<32>(left, wsplit, att, out, B, Cout, H, W, nterms, st);
