@@ -3,14 +3,23 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch PAIRS_PER_GPU]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus 8 --batch 4                      # BASELINE.json configs[3]: 32 pairs over 8 GPUs
+    python bench.py --gpus 8 --height 2048 --width 2048 --maxdisp 192     # configs[4]: 8 pairs over 8 GPUs
 
 A step = one pass of the hot path (1/4- and 1/8-scale features -> 1/4-scale disparity,
 reference models/SemStereo.py:273-323) over this rank's batch of synthetic 1024x1024, maxdisp=128
 pairs, inputs resident in HBM.  Pairs are sharded over ranks (weak scaling, no collective inside
 the forward); the timed region is bracketed by barrier + synchronize and the MAX over ranks is
-reported.  Rank 0 prints ONE JSON line with pairs/s, the roofline of the dominant kernel (fp32-MFMA
-conv of concat_stem) and of the cost-volume build kernel (HBM), EPE against the CPU oracle, and
-the oracle's own pairs/s on the host cores.
+reported.  Rank 0 prints ONE JSON line with pairs/s, the roofline of the dominant kernel (the
+matrix-core conv of concat_stem: two-term fp16 operands, fp32 accumulate) and of the cost-volume
+build kernel (HBM), EPE against the CPU oracle, and the oracle's own pairs/s on the host cores.
+
+Without a launcher (`WORLD_SIZE` unset) and `--gpus N > 1` this file launches its own N ranks: the
+parent makes NO GPU/HIP call, starts N fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits non-zero if any child
+fails -- the counterpart of the reference's `nn.DataParallel(model)` (test_us3d.py:58), one process
+per GPU instead of one thread per GPU.  `--dry-launch` rehearses exactly that control flow
+(launcher, rendezvous, barriers, metric reduction, teardown) on CPU over gloo with a stand-in step.
 """
 import argparse
 import json
@@ -102,6 +111,63 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this file and relay
+    rank 0's stdout (the JSON line).  The parent has made no GPU/HIP call (nothing before this point touches
+    torch.cuda) and never exec-replaces itself; children are ended by their exact PIDs if one of them fails."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        time.sleep(0.05)
+    if failed is None:
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        t.join(timeout=5)
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}; the other ranks were ended", file=sys.stderr)
+        return 1
+    t.join(timeout=30)
+    return 0
+
+
+def dry_step_factory(device):
+    """Stand-in step of `--dry-launch`: a few small CPU matmuls (the launcher rehearsal measures nothing)."""
+    a = torch.randn(64, 64, device=device)
+
+    def step():
+        return {"pred": (a @ a).sum().reshape(1, 1, 1, 1)}
+    return step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,34 +185,54 @@ def main():
                     "fp32 oracle's time) that tells kernel error from the reference algorithm's own conditioning")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the oracle run")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true", help="CPU rehearsal of the N-rank control flow over gloo "
+                    "(launcher, rendezvous, barriers, metric reduction, teardown) with a stand-in step; measures nothing")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become the parent of N ranks BEFORE anything touches the GPU (not even is_available())
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # one rank per GPU over RCCL; SS_DIST_BACKEND=gloo lets the N > 1 control flow be rehearsed with several
     # ranks on ONE GPU (RCCL refuses two ranks on a device) -- the numbers of such a run mean nothing
-    backend = os.environ.get("SS_DIST_BACKEND", "nccl")
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists)"
-    if backend != "nccl":
-        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    dry = args.dry_launch
+    backend = "gloo" if dry else os.environ.get("SS_DIST_BACKEND", "nccl")
+    if not dry:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists)"
+        if backend != "nccl":
+            os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     rank, world, local = sdist.init_from_env(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    semstereo_amd._lib.load()
+    if dry:
+        device = torch.device("cpu")
+        sync = lambda: None                                          # noqa: E731
+        if os.environ.get("SS_DRY_FAIL_RANK") == str(rank):          # test hook: a rank that dies after the rendezvous
+            sys.exit(7)
+    else:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        sync = torch.cuda.synchronize
+        semstereo_amd._lib.load()
     M = semstereo_amd.modules
     if args.engine:
         M.CONV_ENGINE = args.engine
     engine = M.CONV_ENGINE
 
     H, W, maxdisp, B = args.height, args.width, args.maxdisp, args.batch
-    seg = semstereo_amd.HotSegment(maxdisp).to(device).eval()
-    init_unit_gain(seg, 1234)                    # same random-init weights on every rank
+    if dry:
+        seg = torch.nn.Linear(8, 8).to(device).eval()               # something to broadcast
+        feats = ()
+    else:
+        seg = semstereo_amd.HotSegment(maxdisp).to(device).eval()
+        init_unit_gain(seg, 1234)                    # same random-init weights on every rank
     sdist.broadcast_module(seg, src=0)
-    fl8, fr8 = synth_features(B, 256, H // 8, W // 8, 6, 100 + rank, device)
-    fl4, fr4 = synth_features(B, 128, H // 4, W // 4, 12, 200 + rank, device)
-    feats = (fl4, fr4, fl8, fr8)
+    if not dry:
+        fl8, fr8 = synth_features(B, 256, H // 8, W // 8, 6, 100 + rank, device)
+        fl4, fr4 = synth_features(B, 128, H // 4, W // 4, 12, 200 + rank, device)
+        feats = (fl4, fr4, fl8, fr8)
 
     timer = KernelTimer()
-    if not args.no_kernel_timers:
+    if not args.no_kernel_timers and not dry:
         if M.CONV_ENGINE == "f32":
             seg.concat_stem.forward = timer.wrap("concat_stem", seg.concat_stem.forward)
         else:       # the gated launch of the split-bf16 conv is concat_stem's (the right half of the volume)
@@ -158,21 +244,23 @@ def main():
     def step():
         with torch.no_grad():
             return seg(*feats)
+    if dry:
+        step = dry_step_factory(device)
 
     def timed_run(nsteps, nwarm, kernel_timers=False):
         """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks.
         The per-kernel HIP events are recorded only inside the timed region."""
         for _ in range(nwarm):
             o = step()
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         timer.enabled = kernel_timers
         t0 = time.perf_counter()
         for _ in range(nsteps):
             o = step()
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -184,7 +272,9 @@ def main():
     assert M.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside the timed region"
 
     by_engine, outs = {engine: pairs / tmax}, {engine: out}
-    if not args.no_other_engines:
+    if dry:
+        unfused_rate = None
+    elif not args.no_other_engines:
         for e in ("f32", "bf16x6", "bf16x3", "f16x3"):
             if e != engine:
                 M.CONV_ENGINE = e
@@ -205,8 +295,20 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if dry:
+        print(json.dumps({"metric": "dry launch (CPU rehearsal of the N-rank control flow; measures nothing)", "dry_launch": True,
+                          "value": pairs / tmax, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * tmax / args.steps, "pairs_counted": pairs, "backend": backend,
+                          "data": "synthetic"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     D8, k = 2 * (maxdisp // 8), 24
     H8, W8, H4, W4 = H // 8, W // 8, H // 4, W // 4
+    cfg_name = {(1024, 1024, 128, 1, 1): "configs[1]", (1024, 1024, 128, 8, 1): "configs[2]", (1024, 1024, 128, 4, 8): "configs[3]",
+                (2048, 2048, 192, 1, 8): "configs[4]"}.get((H, W, maxdisp, B, world), "shape of configs[1] at another batch / rank count"
+                                                           if (H, W, maxdisp) == (1024, 1024, 128) else "custom shape")
     engine_note = {
         "f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for every 3-D layer",
         "bf16x6": "3x3x3 stride-1 convs: fp32 operands split into 3 bf16 terms, 6 cross products on v_mfma_f32_32x32x16_bf16, "
@@ -222,8 +324,10 @@ def main():
                   f"{H}x{W} maxdisp={maxdisp}",
         "value": pairs / tmax, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[1]: {H}x{W} tile, maxdisp={maxdisp}, batch={B} per GPU, "
+        "dtype": {"f32": "f32", "f16x3": "f32 (2xfp16 split operands, fp32 accumulate)",
+                  "bf16x6": "f32 (3xbf16 split operands, 6 products, fp32 accumulate)",
+                  "bf16x3": "f32 (3xbf16 split operands, 3 products, fp32 accumulate)"}[engine], "data": "synthetic",
+        "config": {"workload": f"BASELINE.json {cfg_name}: {H}x{W} tile, maxdisp={maxdisp}, batch={B} per GPU x {world} GPU(s), "
                                "features [B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity [B,1,H/4,W/4]",
                    "pairs_per_gpu_per_step": B, "parallelism": f"pairs sharded over {world} rank(s), no collective in the forward",
                    "weights": "random init at unit gain (see init_unit_gain), BatchNorm eval",

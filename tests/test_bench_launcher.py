@@ -1,0 +1,62 @@
+"""`python bench.py --gpus N` must be runnable as typed: with WORLD_SIZE unset the parent spawns
+its own N ranks without touching the GPU, relays rank 0's JSON line and fails if a rank fails.  Rehearsed here on
+CPU with `--dry-launch` (gloo, stand-in step): launcher, rendezvous on 127.0.0.1, barriers around the timed region,
+SUM / MAX metric reduction, rank != 0 teardown.  The counterpart of nn.DataParallel in test_us3d.py:58."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def _json_lines(text):
+    return [json.loads(line) for line in text.splitlines() if line.startswith("{")]
+
+
+def test_self_launch_two_ranks_prints_one_json_line():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "4", "--warmup", "1", "--batch", "4"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    res = lines[0]
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["warmup"] == 1 and res["dry_launch"] is True
+    assert res["pairs_counted"] == 2 * 4 * 4            # SUM over both ranks of batch x steps
+    assert res["ms_per_step"] > 0
+
+
+def test_self_launch_fails_when_a_rank_fails():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "0"],
+                       env=_env(SS_DRY_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not _json_lines(r.stdout)
+    assert "rank 1 exited with code 7" in r.stderr
+
+
+def test_external_launcher_form_still_works():
+    """The driver's form: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29613", BENCH, "--gpus", "2", "--dry-launch",
+                        "--steps", "3", "--warmup", "1"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["pairs_counted"] == 2 * 3
+
+
+def test_parent_makes_no_gpu_call_before_spawning():
+    """Static check of the launcher branch: nothing between argument parsing and launch_ranks() may touch torch.cuda."""
+    src = open(BENCH).read()
+    main = src[src.index("def main():"):]
+    upto = main[:main.index("launch_ranks(args.gpus")]
+    assert "torch.cuda" not in upto and "_lib.load" not in upto
+    launcher = src[src.index("def launch_ranks"):src.index("def dry_step_factory")]
+    launcher = launcher[launcher.index('"""', launcher.index('"""') + 3):]          # code only, not the docstring
+    assert "torch.cuda" not in launcher and "os.exec" not in launcher and "execv" not in launcher
