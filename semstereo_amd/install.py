@@ -19,8 +19,6 @@ overlap (260 pairs/s) -- need the inference call path itself:
     semstereo_amd.accelerate(net, fuse_forward=True)   # eval()/no_grad calls take the fused path; training,
                                                        # autograd and seg-only calls still run the reference forward()
 """
-import types
-
 import torch
 import torch.nn as nn
 
@@ -81,27 +79,45 @@ def accelerate(model, fuse_forward=False):
         assert list(new.state_dict().keys()) == before, f"state_dict keys of {name} changed"
         setattr(target, name, new)
         done.append(name)
-    if fuse_forward and "_ss_reference_forward" not in target.__dict__:
-        target.__dict__["_ss_reference_forward"] = target.forward           # the bound reference method
-        target.forward = types.MethodType(fused_inference_forward, target)
+    if fuse_forward and not getattr(type(target), "_ss_fused_forward", False):
+        target.__class__ = _fused_class(type(target))
     return done
+
+
+_FUSED_CLASSES = {}
+
+
+def _fused_class(base):
+    """A subclass of the model's own class whose forward() is `fused_inference_forward`; the reference's forward()
+    stays reachable as the base class's.  The routing lives on the CLASS, not in the instance __dict__:
+    nn.DataParallel builds its per-GPU replicas with `replica = cls.__new__(cls); replica.__dict__ =
+    module.__dict__.copy()` (torch/nn/modules/module.py: _replicate_for_data_parallel), so a bound method stored in
+    the instance would keep pointing every replica at the cuda:0 original (main_us3d.py:100, test_us3d.py:58)."""
+    cls = _FUSED_CLASSES.get(base)
+    if cls is None:
+        def forward(self, left, right):
+            return fused_inference_forward(self, left, right, reference_forward=super(cls, self).forward)
+        cls = type(base.__name__, (base,), {"forward": forward, "_ss_fused_forward": True, "_ss_reference_class": base,
+                                            "__module__": base.__module__, "__qualname__": base.__qualname__})
+        _FUSED_CLASSES[base] = cls
+    return cls
 
 
 def restore_forward(model):
     """Undo `accelerate(..., fuse_forward=True)`'s forward routing (the swapped sub-modules stay)."""
     target = model.module if isinstance(model, nn.DataParallel) else model
-    if "_ss_reference_forward" in target.__dict__:
-        del target.__dict__["forward"]
-        del target.__dict__["_ss_reference_forward"]
+    if getattr(type(target), "_ss_fused_forward", False):
+        target.__class__ = type(target)._ss_reference_class
 
 
-def fused_inference_forward(self, left, right):
+def fused_inference_forward(self, left, right, reference_forward=None):
     """The caller side of the hot path, models/SemStereo.py:246-346, for eval-mode / no-autograd calls: the
     same sub-module calls in the same order as the reference's forward() around `segment.run_segment`
     (:273-323 fused).  Returns exactly what the reference returns in eval mode: `[disp_full_res]` or
     `([disp_full_res], label_logits)`, disp = 4 * SSR_upsample(pred).  Everything else (training, autograd,
     segmentation-only models) is handed to the reference's own forward()."""
-    reference_forward = self.__dict__["_ss_reference_forward"]
+    if reference_forward is None:
+        reference_forward = super(type(self), self).forward
     if (self.training or not self.stereo_if or not left.is_cuda
             or (torch.is_grad_enabled() and (left.requires_grad or right.requires_grad
                                              or any(p.requires_grad for p in self.parameters())))):

@@ -38,6 +38,12 @@ def _inference(module, *tensors):
             return False
         if any(p.requires_grad for p in module.parameters()):
             return False
+        if module.__dict__.get("_is_replica", False):
+            # an nn.DataParallel replica holds its weights as plain attributes (parameters() is empty);
+            # torch/nn/parallel/replicate.py keeps them reachable in _former_parameters
+            for m in module.modules():
+                if any(p is not None and p.requires_grad for p in getattr(m, "_former_parameters", {}).values()):
+                    return False
     return True
 
 
@@ -58,6 +64,12 @@ class _ParamCache:
 
 
 def _cache(module):
+    """Per-module cache of derived tensors.  An nn.DataParallel replica gets a throw-away cache: its __dict__ is a
+    shallow copy of the original's (so `_ss_cache` would be the SAME object on every GPU), and its parameters are
+    fresh broadcast copies on each forward that the caching allocator tends to hand the same address with version 0
+    -- a (data_ptr, version) stamp cannot tell new weights from old ones there."""
+    if module.__dict__.get("_is_replica", False):
+        return _ParamCache()
     c = module.__dict__.get("_ss_cache")
     if c is None:
         c = module.__dict__["_ss_cache"] = _ParamCache()

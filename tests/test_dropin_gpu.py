@@ -89,3 +89,30 @@ def test_fused_forward_matches_the_cpu_composition(sa):
     assert float((labg.cpu() - labc.detach()).abs().max()) <= 1e-4
     err = (dg.cpu() - dc.detach()).abs()
     assert float(err.median()) <= 1e-4 and float((err <= 4e-3).float().mean()) >= 0.99, (float(err.median()), float(err.max()))
+
+
+def test_data_parallel_replicas_run_their_own_forward_in_two_threads(sa):
+    """nn.DataParallel (main_us3d.py:100, test_us3d.py:58): one Python thread per replica, replicas built by copying the
+    instance __dict__.  One GPU is enough to exercise the contract of SURVEY.md section 8(b) -- device_ids [0, 0] gives two
+    replicas with their own broadcast weight copies that run the fused forward CONCURRENTLY from two threads on two
+    streams' worth of launches: the routing must bind each replica (not the original), replicas must not share packed
+    weights, and the C ABI must be re-entrant.  The result must equal the plain single-thread call."""
+    import torch.nn as nn
+    net, module = _build(sa)
+    left, right = _images(B=2)
+    sa.accelerate(net, fuse_forward=True)
+    with torch.no_grad():
+        (want,), lab = net(left, right)
+    try:
+        dp = nn.DataParallel(net, device_ids=[0, 0])
+    except Exception as e:                                   # a torch build that refuses duplicate ids
+        pytest.skip(f"DataParallel(device_ids=[0, 0]) not accepted: {e}")
+    before = dict(sa.modules.PATH_COUNTS)
+    for _ in range(3):
+        with torch.no_grad():
+            (got,), lab2 = dp(left, right)
+        assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "a replica fell back to PyTorch layers"
+        assert got.shape == want.shape and torch.equal(lab2, lab)
+        err = (got - want).abs()
+        assert float(err.median()) <= 1e-4 and float((err <= 4e-3).float().mean()) >= 0.995, (float(err.median()), float(err.max()))
+    sa.restore_forward(net)

@@ -46,6 +46,36 @@ def ref_module():
             sys.modules[k] = v
 
 
+def _cpu_replicate(network, detach=True):
+    """What torch.nn.parallel.replicate(network, devices, detach=True) builds per device (torch/nn/parallel/replicate.py),
+    on CPU: every module through _replicate_for_data_parallel(), children re-linked, parameters as plain detached
+    tensors set as NON-parameter attributes (so replica.parameters() is empty), buffers copied."""
+    from collections import OrderedDict
+    modules = list(network.modules())
+    index = {m: i for i, m in enumerate(modules)}
+    copies = []
+    for m in modules:
+        r = m._replicate_for_data_parallel()
+        r._former_parameters = OrderedDict()
+        copies.append(r)
+    for i, m in enumerate(modules):
+        for key, child in m._modules.items():
+            if child is None:
+                copies[i]._modules[key] = None
+            else:
+                setattr(copies[i], key, copies[index[child]])
+        for key, p in m._parameters.items():
+            if p is None:
+                copies[i]._parameters[key] = None
+            else:
+                c = p.detach().clone().requires_grad_(p.requires_grad and not detach)
+                setattr(copies[i], key, c)
+                copies[i]._former_parameters[key] = c
+        for key, b in m._buffers.items():
+            copies[i]._buffers[key] = None if b is None else b.detach().clone()
+    return copies[0]
+
+
 def test_accelerate_on_the_real_reference_model(ref_module):
     import semstereo_amd as sa
     torch.manual_seed(0)
@@ -72,15 +102,33 @@ def test_accelerate_on_the_real_reference_model(ref_module):
     # handed to the reference's own forward() (CPU tensors, autograd on), the attribute names it needs exist,
     # and the routing can be undone
     sa.accelerate(net, fuse_forward=True)
-    assert net.forward.__func__ is sys.modules["semstereo_amd.install"].fused_inference_forward
+    assert type(net)._ss_fused_forward and isinstance(net, ref_module.SemStereo) and "forward" not in net.__dict__
     for name in ("feature", "feature_up", "head_l", "chal_0", "chal_4", "spx32_16", "spx16_8", "spx8_4", "spx4_2", "spx2",
                  "ssr_upsample", "stereo_if", "seg_if", "att_weights_only", "maxdisp", "gamma", "beta", "concat_feature"):
         assert hasattr(net, name), name
     (again,), _ = net(imgL, imgR)
     assert torch.allclose(again.detach(), want, atol=1e-4, rtol=1e-4)
     assert list(net.state_dict().keys()) == keys
+    # nn.DataParallel's replicas (main_us3d.py:100, test_us3d.py:58) must run THEIR OWN forward on THEIR OWN weights:
+    # replicas are built by copying the instance __dict__, so the routing has to live on the class
+    replica = _cpu_replicate(net)
+    assert replica.forward.__self__ is replica and type(replica) is type(net)
+    assert replica.hourglass is not net.hourglass and replica.hourglass.forward.__self__ is replica.hourglass
+    assert replica.hourglass.conv1[0][0].weight is not net.hourglass.conv1[0][0].weight and not list(replica.parameters())
+    from semstereo_amd.modules import _cache, _inference
+    assert _cache(net.hourglass) is _cache(net.hourglass)                 # the original keeps its packed weights ...
+    assert _cache(replica.hourglass) is not _cache(net.hourglass)         # ... a replica never sees or reuses them
+    assert _cache(replica.hourglass) is not _cache(replica.hourglass)
+    with torch.no_grad():
+        assert _inference(replica.hourglass, imgL)
+    replica.hourglass.conv1[0][0].weight.requires_grad_(True)            # non-detached replicas (autograd on) are not inference
+    assert not _inference(replica.hourglass, imgL)
+    replica.hourglass.conv1[0][0].weight.requires_grad_(False)
+    # with autograd on, DataParallel's replicas carry differentiable copies: the twins take their PyTorch path (CPU-runnable)
+    (rep_out,), _ = _cpu_replicate(net, detach=False)(imgL, imgR)
+    assert torch.allclose(rep_out.detach(), want, atol=1e-4, rtol=1e-4)
     sa.restore_forward(net)
-    assert "forward" not in net.__dict__ and net.forward.__func__ is ref_module.SemStereo.forward
+    assert type(net) is ref_module.SemStereo and "forward" not in net.__dict__
 
 
 def test_install_into_the_real_reference_module(ref_module):
