@@ -34,8 +34,12 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (4): bumped on any signature change or new entry point the Python binding requires. */
+/* ABI version (5): bumped on any signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
+/* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
+ * measurement aids) are read from the environment ONCE per process; call this after changing
+ * one of them.  No reference counterpart (the reference has no tuning surface). */
+int ss_reload_tuning(void);
 /* Static, human-readable text for an ss_status. */
 const char* ss_status_string(int status);
 /* hipGetErrorString of the last SS_ERR_LAUNCH on this thread ("" if none). */

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -58,7 +58,7 @@ _SIGNATURES = {
     "ss_window_attention_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
-EXPORTS = sorted(list(_SIGNATURES) + ["ss_abi_version", "ss_status_string", "ss_last_hip_error", "ss_ssr_param_count"])
+EXPORTS = sorted(list(_SIGNATURES) + ["ss_abi_version", "ss_status_string", "ss_last_hip_error", "ss_ssr_param_count", "ss_reload_tuning"])
 
 _lib = None
 
@@ -81,6 +81,8 @@ def load():
     lib.ss_status_string.restype = ctypes.c_char_p
     lib.ss_status_string.argtypes = [_I]
     lib.ss_last_hip_error.restype = ctypes.c_char_p
+    lib.ss_reload_tuning.restype = _I
+    lib.ss_reload_tuning.argtypes = []
     if lib.ss_abi_version() != ABI_VERSION:
         raise SemStereoHipError(f"ABI mismatch: library {lib.ss_abi_version()} != binding {ABI_VERSION}; rebuild")
     for name, argtypes in _SIGNATURES.items():

@@ -451,8 +451,7 @@ extern "C" int ss_topk_candidates_fwd(const float* logits, const float* strength
     const size_t lds = (size_t)2 * D * T * sizeof(float);
     auto kern = topk_candidates_kernel;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
     }
     const long long total = (long long)B * H * W;
     hipLaunchKernelGGL(kern, dim3((unsigned)ss::ceil_div_ll(total, T)), dim3(T), lds, ss::as_stream(stream), logits,

@@ -1,10 +1,39 @@
 // Status strings and the per-thread HIP error note of libsemstereo_hip.so.
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 namespace {
 thread_local char g_last_error[256] = "";
+
+int env_int(const char* name) {            // -1: unset; otherwise its integer value (a set but non-numeric variable: 1)
+    const char* v = getenv(name);
+    if (v == nullptr) return -1;
+    return (v[0] >= '0' && v[0] <= '9') ? atoi(v) : 1;
+}
+
+ss::Tuning read_tuning() {
+    ss::Tuning t;
+    t.conv_tile = env_int("SS_CONV_TILE");
+    t.conv_s2_mt1 = env_int("SS_CONV_S2_MT1");
+    t.gwc_stream = env_int("SS_GWC_STREAM");
+    t.warp_stream = env_int("SS_WARP_STREAM");
+    t.warp_vec4 = env_int("SS_WARP_VEC") == 4 ? 1 : 0;
+    t.warp_generic = env_int("SS_WARP_GENERIC");
+    t.deconv_split = env_int("SS_DECONV_SPLIT");
+    return t;
+}
+
+// two slots, published by index: a reload never writes the slot a concurrent launch may be reading
+ss::Tuning g_tuning[2];
+std::atomic<int> g_tuning_slot{-1};
+std::mutex g_mutex;
+std::unordered_map<unsigned long long, int> g_lds_set;      // (kernel address ^ device) -> bytes granted
 }
 
 namespace ss {
@@ -13,9 +42,48 @@ void note_hip_error(hipError_t e) {
     strncpy(g_last_error, s ? s : "unknown hip error", sizeof(g_last_error) - 1);
     g_last_error[sizeof(g_last_error) - 1] = 0;
 }
+
+const Tuning& tuning() {
+    int slot = g_tuning_slot.load(std::memory_order_acquire);
+    if (slot < 0) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        slot = g_tuning_slot.load(std::memory_order_relaxed);
+        if (slot < 0) {
+            g_tuning[0] = read_tuning();
+            g_tuning_slot.store(slot = 0, std::memory_order_release);
+        }
+    }
+    return g_tuning[slot];
+}
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    if (bytes <= 64 * 1024) return SS_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(kernel) * 64ull + (unsigned)dev;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_lds_set.find(key);
+    if (it != g_lds_set.end() && it->second >= bytes) return SS_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        note_hip_error(e);
+        return SS_ERR_LAUNCH;
+    }
+    g_lds_set[key] = bytes;
+    return SS_OK;
+}
 }  // namespace ss
 
-extern "C" int ss_abi_version(void) { return 4; }   // 4: + two-term fp16 forms (nterms = 19, ss_pack_*_f16s), 2-D conv
+extern "C" int ss_reload_tuning(void) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    const int cur = g_tuning_slot.load(std::memory_order_relaxed);
+    const int nxt = cur == 0 ? 1 : 0;
+    g_tuning[nxt] = read_tuning();
+    g_tuning_slot.store(nxt, std::memory_order_release);
+    return SS_OK;
+}
+
+extern "C" int ss_abi_version(void) { return 5; }   // 5: + ss_reload_tuning; tuning switches read once per process
 
 extern "C" const char* ss_status_string(int status) {
     switch (status) {

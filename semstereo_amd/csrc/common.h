@@ -23,6 +23,23 @@ inline int check_launch() {
 
 inline hipStream_t as_stream(ss_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Tuning switches (A/B measurements and the tests that cover both forms of a kernel): read from the environment ONCE
+// per process -- a launch costs no getenv() and an environment change mid-process cannot silently change which kernel
+// runs -- and again only when ss_reload_tuning() is called.  -1 = not set (the measured-best automatic choice).
+struct Tuning {
+    int conv_tile;        // SS_CONV_TILE   0..2: force a tile candidate of the conv kernels
+    int conv_s2_mt1;      // SS_CONV_S2_MT1 set: stride-2 convs with one output tile per wave
+    int gwc_stream;       // SS_GWC_STREAM  0/1: plain / nontemporal stores of the gwc volume
+    int warp_stream;      // SS_WARP_STREAM 0/1
+    int warp_vec4;        // SS_WARP_VEC=4
+    int warp_generic;     // SS_WARP_GENERIC set: the generic warp kernel for the live form too
+    int deconv_split;     // SS_DECONV_SPLIT 0/1: even/odd-plane split of the exact-fp32 transposed conv
+};
+const Tuning& tuning();
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch.
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 
@@ -46,13 +63,6 @@ __device__ __forceinline__ float exp_fast(float x) {
 // attention_tail.hip: wave-split softmax+regression+variance; returns non-zero if D is out of its range
 int ss_softmax_regress_split_launch(const float* logits, float* prob, float* disp, float* var, int B, int maxdisp, int H,
                                     int W, hipStream_t st);
-
-// conv3d_f16p.hip: the pipelined one-workgroup-per-CU instantiation of the fp16-form 3x3x3 stride-1 conv (relu bit 1:
-// `residual` is the initial accumulator), for layers whose grid fills the chip with 2 x 8 x 32 tiles
-bool ss_conv3d_f16p_applicable(int B, int D, int H, int W, int Cout);
-int ss_conv3d_f16p_launch(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
-                          const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu,
-                          hipStream_t st);
 
 #define SS_REQUIRE(cond)              \
     do {                                \

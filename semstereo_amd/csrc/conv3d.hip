@@ -436,9 +436,7 @@ int launch_conv(const float* in, const float* wpack, const float* scale, const f
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
     auto kern = conv3d_mfma<KS, S, MT, NT, TD, TH, CIT>;
     if (C::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)C::LDS_BYTES);
-        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
     dim3 grid((unsigned)nt, ss::ceil_div(Cout, C::CO_T), B);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, wpack, scale, shift, residual, gate, out, Cin, D, H, W,
@@ -479,8 +477,8 @@ extern "C" int ss_conv3d_fwd(const float* in, const float* wpack, const float* s
                ss::ceil_div(Cout, c.mt * 32) * B;
     };
     auto pick = [&](const Cand* cands, int n) {
-        const char* forced = getenv("SS_CONV_TILE");
-        if (forced && forced[0] >= '0' && forced[0] - '0' < n) return forced[0] - '0';
+        const int forced = ss::tuning().conv_tile;
+        if (forced >= 0 && forced < n) return forced;
         int best = 0;
         long long best_blocks = -1;
         for (int i = 0; i < n; ++i) {

@@ -615,9 +615,7 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
     auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD>;
     if (C::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)C::LDS_BYTES);
-        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
     dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32 * MT), B);
     // (Workgroups of equal duration that all start together stay in lock-step -- every CU stages, multiplies and stores at
@@ -635,7 +633,7 @@ int launch_bg(const float* in, const void* wsplit, const float* scale, const flo
     // unless that leaves fewer workgroups than CUs (57 vs 41 us on the smallest)
     const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const long long wg2 = (long long)ss::ceil_div(Wo, 32) * ss::ceil_div(Ho, TH) * ss::ceil_div(Do, TD) * ss::ceil_div(Cout, 64) * B;
-    if (S == 2 && Cout > 32 && wg2 >= 256 && getenv("SS_CONV_S2_MT1") == nullptr)
+    if (S == 2 && Cout > 32 && wg2 >= 256 && ss::tuning().conv_s2_mt1 < 0)
         return launch_bgm<S, NT, TD, TH, NTERMS, GATED, (S == 2) ? 2 : 1>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W,
                                                                           Cout, relu, st);
     return launch_bgm<S, NT, TD, TH, NTERMS, GATED, 1>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
@@ -685,9 +683,9 @@ static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* s
     auto blocks = [&](int td, int th) {
         return (long long)ss::ceil_div(Wo, 32) * ss::ceil_div(Ho, th) * ss::ceil_div(Do, td) * ss::ceil_div(Cout, 32) * B;
     };
-    const char* forced = getenv("SS_CONV_TILE");
+    const int forced = ss::tuning().conv_tile;
     int tile = (blocks(2, 8) >= 512) ? 0 : ((blocks(1, 8) >= 512) ? 1 : 2);
-    if (forced && forced[0] >= '0' && forced[0] <= '2') tile = forced[0] - '0';
+    if (forced >= 0 && forced <= 2) tile = forced;
 #define SS_B(S, NT, TD, TH)                                                                                              \
     return (nterms == 6) ? launch_b<S, NT, TD, TH, 6>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st) \
          : (nterms == 3) ? launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st) \
@@ -696,13 +694,6 @@ static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* s
     // CU, slower than the exact-fp32 kernel (283 vs 229 us on the largest layer).  A 2 x 2 tile is 78 KB: two
     // workgroups per CU, faster on every stride-2 layer of the model (190 / 95 / 68 / 41 us vs 229 / 122 / 81 / 62).
     if (stride == 2) { SS_B(2, 1, 2, 2); }     // 5 x 5 x 65 halo positions: 78 KB of split operands, two workgroups per CU
-    // the pipelined one-workgroup-per-CU form (conv3d_f16p.hip) is opt-in: 9-15 % faster on a plain 32 -> 32 layer launched
-    // alone, no faster inside the step (its input then comes from the infinity cache and the tiled kernel is not as
-    // far behind), and its gated instantiation spills
-    const char* pipe_env = getenv("SS_CONV_PIPE");
-    const bool pipelined = pipe_env != nullptr && atoi(pipe_env) != 0;
-    if (tile == 0 && stride == 1 && nterms == F16X3 && pipelined && !forced && ss_conv3d_f16p_applicable(B, D, H, W, Cout))
-        return ss_conv3d_f16p_launch(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
     if (tile == 0) { SS_B(1, 4, 2, 8); }
     if (tile == 1) { SS_B(1, 2, 1, 8); }
     SS_B(1, 1, 1, 4);

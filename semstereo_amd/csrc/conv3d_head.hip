@@ -202,8 +202,7 @@ int launch_head(const float* in, const void* wsplit, const float* scale, const f
     auto kern = conv3d_head_bf16s<TD, TH, KS, NTERMS>;
     const size_t lds = (size_t)9 * (TD + 2) * (TH + 2) * 32 * sizeof(float);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nt, B), dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
                        out, D, H, W, tiles_w, tiles_h, relu);

@@ -253,8 +253,7 @@ int launch_deconv_split(const float* in, const float* wpack, const float* scale,
     auto kern = deconv3d_mfma<TD, TH, CIT, HAS_SKIP, SPLIT>;
     const size_t lds = (size_t)C::LDS_FLOATS * 4;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
     }
     dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32) * (SPLIT ? 2 : 1), B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, wpack, scale, shift, skip, skip_w, out, Cin, D, H, W, Cout, Cs,
@@ -272,7 +271,7 @@ int launch_deconv_as(const float* in, const float* wpack, const float* scale, co
     // fewer workgroups than CUs: split every workgroup into its even- and odd-plane halves (measured on the
     // bench shapes: 128 workgroups 87 -> 67 us; at 384 workgroups the split form is already 7 % slower)
     bool split = nt * ss::ceil_div(Cout, 32) * B < 256;
-    if (const char* f = getenv("SS_DECONV_SPLIT")) split = f[0] == '1';      // tuning aid
+    if (ss::tuning().deconv_split >= 0) split = ss::tuning().deconv_split == 1;      // tuning aid
     if (split)
         return launch_deconv_split<TD, TH, CIT, HAS_SKIP, true>(in, wpack, scale, shift, skip, skip_w, out, B, Cin, D, H, W, Cout,
                                                                 Cs, relu, nt, tiles_w, tiles_h, st);

@@ -499,8 +499,7 @@ int launch_db(const float* in, const void* wsplit, const float* shift, const flo
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
     auto kern = deconv3d_bf16s<TD, TH, NTERMS, HAS_SKIP>;
     if (C::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
     dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32), B);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), shift, skip,

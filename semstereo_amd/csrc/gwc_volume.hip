@@ -327,7 +327,7 @@ extern "C" int ss_gwc_volume_fwd(const float* ref, const float* tgt, float* out,
         // volumes beyond the 256 MB infinity cache cannot stay resident for the consumer: stream them
         const size_t out_bytes = (size_t)B * groups * 2 * m * H * W * sizeof(float);
         bool stream_out = out_bytes > ((size_t)192 << 20);
-        if (const char* f = getenv("SS_GWC_STREAM")) stream_out = f[0] == '1';   // tuning aid
+        if (ss::tuning().gwc_stream >= 0) stream_out = ss::tuning().gwc_stream == 1;   // tuning aid
         if (Cg == 8) return launch_v4<8>(ref, tgt, out, B, C, H, W, m, groups, normalize, stream_out, st);
         if (Cg == 4) return launch_v4<4>(ref, tgt, out, B, C, H, W, m, groups, normalize, stream_out, st);
     }

@@ -281,15 +281,13 @@ int launch_fused(const float* left, const void* wsplit, const float* att, float*
     if (nterms == 6) {
         auto kern = stem_left_fused<ND, 6>;
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+            if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
         }
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, left, reinterpret_cast<const uint4*>(wsplit), att, out, Cout, H, W);
     } else {
         auto kern = stem_left_fused<ND, 3>;
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+            if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
         }
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, left, reinterpret_cast<const uint4*>(wsplit), att, out, Cout, H, W);
     }

@@ -249,14 +249,14 @@ int launch(const float* x, const float* y, const float* disp, const float* gate,
     // One column per lane by default: a wave's tap loads then touch 2 cache lines instead of 8, which
     // measures ~25 us faster on the live shape than the float4 form (SS_WARP_VEC=4) despite 4-byte stores.
     bool v4 = false;
-    if (const char* f = getenv("SS_WARP_VEC")) v4 = f[0] == '4' && (W % 4 == 0) && ((bits & 15) == 0);
+    if (ss::tuning().warp_vec4) v4 = (W % 4 == 0) && ((bits & 15) == 0);
     const long long total = (long long)B * nd * H * (v4 ? W / 4 : W);
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     const int planes = (MODE == MODE_CORR) ? 1 : ((MODE == MODE_CONCAT && x != nullptr) || out1 != nullptr) ? 2 * C : C;
     int nt = (size_t)B * planes * nd * H * W * sizeof(float) > ((size_t)192 << 20);
-    if (const char* f = getenv("SS_WARP_STREAM")) nt = f[0] == '1';      // tuning aid
-    static const bool fast_ok = getenv("SS_WARP_GENERIC") == nullptr;
+    if (ss::tuning().warp_stream >= 0) nt = ss::tuning().warp_stream == 1;      // tuning aid
+    const bool fast_ok = ss::tuning().warp_generic < 0;
     if (MODE == MODE_CONCAT && x == nullptr && !v4 && fast_ok && W >= 2 && (long long)C * nd * H * W * 4 < 0x7fffffffLL &&
         (long long)B * nd <= 65535) {
         const dim3 grid(ss::ceil_div(W, 64), ss::ceil_div(H, 4), B * nd);

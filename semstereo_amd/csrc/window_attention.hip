@@ -380,9 +380,7 @@ int launch_attn(const float* x, const float* wqkv_t, const float* bqkv, const fl
     const int use_mask = (H % bh != 0) && (W % bw != 0);
     auto kern = window_attention_kernel<T, 128>;
     if (A::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)A::LDS_BYTES);
-        if (e != hipSuccess) { ss::note_hip_error(e); return SS_ERR_LAUNCH; }
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)A::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
     const long long nwin = (long long)nwd * nwh * nww;
     if (nwin > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;

@@ -578,8 +578,16 @@ class attention_block(nn.Module):
                     self.final1x1.bias.detach().float().contiguous())
         return _cache(self).get("attn_split/" + ("bf16s" if bf else "f32"), srcs, build) + (bf,)
 
+    def hip_supported(self):
+        """What window_attention.hip is built for: the reference's own configuration (models/SemStereo.py:118,157:
+        128 channels, 16 heads, windows of 4x4x4 = 64 or 6x4x4 = 96 tokens)."""
+        bd, bh, bw = self.block
+        return self.dim_3d == 128 and self.num_heads == 16 and bd * bh * bw in (64, 96)
+
     def forward(self, x):
-        if _inference(self, x):
+        # another head count / width / window than the reference's: the same computation as PyTorch ops on the GPU
+        # (visible in PATH_COUNTS["torch"]) instead of an SS_ERR_UNSUPPORTED from deep inside forward()
+        if _inference(self, x) and self.hip_supported():
             PATH_COUNTS["hip"] += 1
             x = x if x.is_contiguous() else x.contiguous()
             dev = _lib.require_device(x)
@@ -879,7 +887,8 @@ class SSR_upsample(nn.Module):
         return _cache(self).get("ssr", srcs, build)
 
     def forward(self, depth_low, weights, pred_label):
-        if _inference(self, depth_low, weights, pred_label):
+        # ssr_upsample.hip is built for the reference's 6 classes (main_us3d.py:66); other counts: PyTorch ops on the GPU
+        if _inference(self, depth_low, weights, pred_label) and self.num_classes == 6:
             PATH_COUNTS["hip"] += 1
             depth_low, weights, pred_label = [t if t.is_contiguous() else t.contiguous() for t in (depth_low, weights, pred_label)]
             dev = _lib.require_device(depth_low, weights, pred_label)

@@ -397,6 +397,10 @@ def sample_strength(left, right, pred0, var, gamma, beta):
     return out
 
 
+#: the fused selection keeps a pixel's probabilities in registers: D = 2 * (maxdisp // 4) <= 128 (attention_tail.hip)
+TOPK_CANDIDATES_MAX_D = 128
+
+
 def topk_candidates(att_weights, strength, maxdisp, k):
     """Fused models/SemStereo.py:295-310: att_weights [B,1,2m,H,W] (up-sampled logits), strength [B,5,H,W]
     -> (att_topk [B,1,k,H,W], disparity_sample_topk [B,k,H,W], pred_att [B,H,W]).  Inference only."""

@@ -91,7 +91,7 @@ class HotSegment(nn.Module):
             prob0 = F.softmax(att_weights.squeeze(1), dim=1)
             pred0 = ops.disparity_regression(prob0, m4)
             var = ops.disparity_variance(prob0, m4, pred0.unsqueeze(1))
-        if fast:
+        if fast and 2 * m4 <= ops.TOPK_CANDIDATES_MAX_D:        # beyond (maxdisp >= 320): the line-by-line form below
             strength = ops.sample_strength(fl4, fr4, pred0, var, self.gamma, self.beta)        # :286-293 fused
             att_topk, samples, pred_att = ops.topk_candidates(att_weights, strength, m4, TOPK)  # :295-310 fused
             return att_topk, samples, pred_att, pred0

@@ -18,3 +18,18 @@ def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
     return {k: np.load(os.path.join(d, k + ".npz")) for k in ("ops", "stack", "segment")}
+
+
+@pytest.fixture
+def tuning_env(monkeypatch):
+    """Set a tuning switch of libsemstereo_hip.so for one test.  The library reads its switches from the environment once
+    per process (ss::tuning()), so a change needs ss_reload_tuning(); undone (and reloaded) at teardown."""
+    import semstereo_amd
+    lib = semstereo_amd._lib.load()
+
+    def setenv(name, value):
+        monkeypatch.setenv(name, value)
+        assert lib.ss_reload_tuning() == 0
+    yield setenv
+    monkeypatch.undo()
+    lib.ss_reload_tuning()

@@ -86,13 +86,13 @@ def test_gwc_vs_oracle_fast_path(sa, shape):
           oops.build_gwc_volume_norm(a, b, m, G), 2e-6)
 
 
-def test_gwc_streaming_stores_identical(sa, monkeypatch):
+def test_gwc_streaming_stores_identical(sa, tuning_env):
     """Volumes beyond the infinity cache are written with nontemporal stores: same bits either way."""
     from oracle import detdata as dd
     a, b = dd.t_normalish((1, 64, 9, 256, ), 13), dd.t_normalish((1, 64, 9, 256), 14)
     outs = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("SS_GWC_STREAM", flag)
+        tuning_env("SS_GWC_STREAM", flag)
         outs.append(sa.ops.build_gwc_volume_norm(dev(a), dev(b), 24, 8).cpu())
     assert torch.equal(outs[0], outs[1])
     check("gwc_stream", outs[1], oops.build_gwc_volume_norm(a, b, 24, 8), 2e-6)
@@ -154,7 +154,7 @@ def test_warp_fused_forms(sa):
     check("warp_correlation", sa.ops.warp_correlation(dev(x), dev(y), dev(disp)), (xw * yw).mean(dim=1), 1e-6, 2e-6)
 
 
-def test_warp_streaming_stores_identical(sa, monkeypatch):
+def test_warp_streaming_stores_identical(sa, tuning_env):
     from oracle import detdata as dd
     B, C, H, W, nd = 1, 8, 6, 64, 5
     x, y = dd.t_normalish((B, C, H, W), 45), dd.t_normalish((B, C, H, W), 46)
@@ -162,7 +162,7 @@ def test_warp_streaming_stores_identical(sa, monkeypatch):
     att = dd.t_uniform((B, 1, nd, H, W), 48, 0.0, 1.0)
     outs = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("SS_WARP_STREAM", flag)
+        tuning_env("SS_WARP_STREAM", flag)
         outs.append(sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp), dev(att)).cpu())
     assert torch.equal(outs[0], outs[1])
 
@@ -193,7 +193,7 @@ def test_warp_right_half_fast_path(sa, shape, gated):
     check(f"concat_sampled_right/{shape}/{gated}", out, ref, 5e-5)
 
 
-def test_warp_float4_form_identical(sa, monkeypatch):
+def test_warp_float4_form_identical(sa, tuning_env):
     """SS_WARP_VEC=4 (4 columns per lane) against the default one-column-per-lane form, fractional disparities."""
     from oracle import detdata as dd
     B, C, H, W, nd = 2, 8, 7, 64, 5
@@ -202,7 +202,7 @@ def test_warp_float4_form_identical(sa, monkeypatch):
     att = dd.t_uniform((B, 1, nd, H, W), 148, 0.0, 1.0)
     outs = []
     for flag in ("1", "4"):
-        monkeypatch.setenv("SS_WARP_VEC", flag)
+        tuning_env("SS_WARP_VEC", flag)
         outs.append(sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp), dev(att)).cpu())
     assert torch.equal(outs[0], outs[1])
     yw, xw = oops.SpatialTransformer_grid(x, y, disp)
@@ -678,10 +678,10 @@ def test_hot_segment_with_hip_2d_convs(sa, golden, hip2d):
 
 @pytest.mark.parametrize("split", ["0", "1"])     # one workgroup for all 8 output parity classes / even and odd planes apart
 @pytest.mark.parametrize("case", [(128, 64, 2, 3, 5, 64), (64, 32, 3, 9, 33, 32), (32, 32, 2, 4, 40, 0), (8, 24, 2, 3, 6, 6)])
-def test_deconv3d_kernel(sa, case, split, monkeypatch):
+def test_deconv3d_kernel(sa, case, split, tuning_env):
     import torch.nn.functional as F
     from oracle import detdata as dd
-    monkeypatch.setenv("SS_DECONV_SPLIT", split)
+    tuning_env("SS_DECONV_SPLIT", split)
     Cin, Cout, D, H, W, Cs = case
     x = dd.t_normalish((2, Cin, D, H, W), 91)
     w = dd.t_uniform((Cin, Cout, 3, 3, 3), 92, -1, 1) * (3.0 / (Cin * 27 / 8)) ** 0.5
@@ -777,43 +777,6 @@ def test_conv3d_f16_form_block_floating_ranges(sa, name, stride):
         ep6 = float(((y6.double().cpu() - refp) / (100.0 * rms)).abs().max())
         # the accumulator holds the (100x larger) partial sum through ~160 fp32 accumulations: their rounding, in either form
         assert ep <= 2.0 * ep6 + 1e-6 and ep <= 2e-5, (ep, ep6)
-
-
-@pytest.mark.parametrize("variant", ["plain", "residual", "partial", "partial+gate"])
-def test_conv3d_f16_pipelined_kernel_matches_the_tiled_one(sa, variant, monkeypatch):
-    """conv3d_f16p.hip (SS_CONV_PIPE=1: one 8-wave workgroup per CU walking the depth tiles of its column, double-buffered
-    LDS image) on a layer large enough for it (>= 3 depth tiles per workgroup), ragged in every dimension, against float64
-    and against the tiled kernel, for each epilogue form."""
-    import torch.nn.functional as F
-    from oracle import detdata as dd
-    Cin, Cout, D, H, W = 20, 40, 45, 130, 250          # 2 x 17 x 8 columns x 2 channel tiles = 544 >= 256 CUs: 12 depth tiles each
-    x = F.relu(dd.t_normalish((1, Cin, D, H, W), 801))
-    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 802, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
-    scale, shift = dd.t_uniform((Cout,), 803, 0.5, 1.5), dd.t_uniform((Cout,), 804, -0.2, 0.2)
-    conv = F.conv3d(x.double().cuda(), w.double().cuda(), None, 1, 1).cpu()
-    extra = dd.t_normalish(tuple(conv.shape), 805) if variant != "plain" else None
-    gate = torch.sigmoid(dd.t_normalish((1, Cout, H, W), 806)) if variant == "partial+gate" else None
-    aff = lambda t: t * scale.double().reshape(1, -1, 1, 1, 1) + shift.double().reshape(1, -1, 1, 1, 1)
-    if variant == "plain":
-        ref = F.relu(aff(conv))
-    elif variant == "residual":
-        ref = F.relu(aff(conv) + extra.double())
-    else:
-        ref = F.relu(aff(conv + extra.double()))
-        if gate is not None:
-            ref = gate.double().unsqueeze(2) * ref
-    ws = sa.modules.pack_conv_weight_bf16s(dev(w), 19)
-    kw = dict(residual=dev(extra)) if variant == "residual" else (dict(partial=dev(extra)) if extra is not None else {})
-    if gate is not None:
-        kw["gate"] = dev(gate)
-    outs = {}
-    for pipe in ("1", "0"):
-        monkeypatch.setenv("SS_CONV_PIPE", pipe)
-        outs[pipe] = sa.modules.conv3d_bf16s_hip(dev(x), ws, Cout, dev(scale), dev(shift), True, 19, **kw).cpu()
-    e_p, e_t = float((outs["1"].double() - ref).abs().max()), float((outs["0"].double() - ref).abs().max())
-    REPORT[f"conv3d_f16p/{variant}"] = e_p
-    assert e_p <= 1.5 * e_t + 1e-6, (e_p, e_t)
-    assert float((outs["1"] - outs["0"]).abs().max()) <= 2e-5
 
 
 @pytest.mark.parametrize("in_mul", [1e-6, 1.0, 1e6])

@@ -62,9 +62,11 @@ def main():
         if args.sweep and cout > 1:
             for tile in range(5 if stride == 1 else 4):
                 os.environ["SS_CONV_TILE"] = str(tile)
+                sa._lib.load().ss_reload_tuning()
                 ms = timeit(lambda: M.conv3d_hip(x, wp, sc, sh, k, stride, True), args.iters)
                 rows.append(dict(name=f"{name} [tile {tile}]", ms=ms, gflop=gf, tflops=gf / ms, frac=gf / ms / PEAK_TF))
             os.environ.pop("SS_CONV_TILE", None)
+            sa._lib.load().ss_reload_tuning()
             return
         if M.CONV_ENGINE != "f32" and k == 3 and stride == 1 and cout > 1:
             ws = M.pack_conv_weight_bf16s(wt)
