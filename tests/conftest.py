@@ -17,7 +17,8 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
-    return {k: np.load(os.path.join(d, k + ".npz")) for k in ("ops", "stack", "segment")}
+    return {k: np.load(os.path.join(d, k + ".npz")) for k in ("ops", "stack", "segment", "segment_full")
+            if os.path.exists(os.path.join(d, k + ".npz"))}
 
 
 @pytest.fixture

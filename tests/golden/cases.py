@@ -121,11 +121,36 @@ SEGMENT = {
     "s256_md128": (1, 256, 256, 128),          # the disparity range of BASELINE.json configs[1-3]: D8 = 32, D4 = 64
     "s192x256_md192": (1, 192, 256, 192),      # ... of configs[4]: D8 = 48, D4 = 96; H/32 = 6 pads the attention windows
 }
-_SEGMENT_SEED = {"s128": 800, "s96x160_b2": 804, "s256_md128": 808, "s192x256_md192": 812}
+_SEGMENT_SEED = {"s128": 800, "s96x160_b2": 804, "s256_md128": 808, "s192x256_md192": 812,
+                 "s256_md128_cal": 816, "f1024_md128_cal": 820, "f2048_md192_cal": 824}
+
+# "_cal": BatchNorm running statistics CALIBRATED on the fixture's own input (one pass of the reference with batch
+# statistics, momentum 1), as a trained network has them: every layer's activations are normalised, so the costs of a
+# pixel's 24 candidates spread over O(1) instead of 0.05 and the hard picks of the graph (24 of D4 attention weights,
+# models/SemStereo.py:299-303; 2 of 24 costs, models/submodule.py:436-437) sit far from fp32 rounding.  The calibrated
+# statistics are stored in the fixture (`<name>/bn/<state_dict key>`): they are inputs of the case.
+SEGMENT_CAL = {
+    "s256_md128_cal": (1, 256, 256, 128),
+}
+# Full sizes of BASELINE.json configs[1] / configs[4]: the fixture (segment_full.npz) holds checksum records only --
+# per stage (sum, sum of squares, 64 sampled voxels), and `pred`, `pred_att`, the candidate set and the reference's
+# decision gaps at FULL_SAMPLES sampled pixels.
+SEGMENT_FULL = {
+    "f1024_md128_cal": (1, 1024, 1024, 128),
+    "f2048_md192_cal": (1, 2048, 2048, 192),
+}
+FULL_SAMPLES = 2048
+
+
+def segment_shape(name):
+    for table in (SEGMENT, SEGMENT_CAL, SEGMENT_FULL):
+        if name in table:
+            return table[name]
+    raise KeyError(name)
 
 
 def segment_inputs(name):
-    B, H, W, maxdisp = SEGMENT[name]
+    B, H, W, maxdisp = segment_shape(name)
     s = _SEGMENT_SEED[name]
     fl8, fr8 = dd.stereo_features(B, 256, H // 8, W // 8, s, max_shift=3)
     fl4, fr4 = dd.stereo_features(B, 128, H // 4, W // 4, s + 1, max_shift=6)
@@ -143,6 +168,32 @@ def ssr_inputs(name):
     weights = dd.t_normalish((B, 6, 4 * h, 4 * w), s + 1)
     label = dd.t_normalish((B, 6, 4 * h, 4 * w), s + 2) * 2.0
     return depth_low, weights, label
+
+
+def segment_params(name, fixture=None):
+    """The parameter dict of a segment case: oracle.hot_segment.deterministic_params(), with the calibrated BatchNorm
+    statistics of a "_cal" case taken from its fixture file (an np.load mapping)."""
+    from oracle import hot_segment as oseg
+    P = oseg.deterministic_params()
+    if name.endswith("_cal"):
+        pre = name + "/bn/"
+        found = [k for k in fixture.files if k.startswith(pre)]
+        assert found, f"{name}: the fixture holds no calibrated BatchNorm statistics"
+        for k in found:
+            key = k[len(pre):]
+            assert key in P and P[key].shape == tuple(fixture[k].shape), key
+            P[key] = torch.from_numpy(np.asarray(fixture[k], dtype=np.float32).copy())
+    return P
+
+
+def candidate_set_hash(samples, m4):
+    """16-bit hash per pixel of its candidate list: samples [B,k,H,W] (float or int disparities in [-m4, m4)) ->
+    uint16 [B,H,W].  Lets the full-size fixtures pin the candidate set of EVERY pixel in 2 bytes."""
+    s = np.asarray(samples).astype(np.int64) + int(m4) + 1                      # 1 .. 2*m4
+    k = s.shape[1]
+    mult = (2 * np.arange(k, dtype=np.int64) + 1).reshape(1, k, 1, 1) * 40503   # odd multipliers, position dependent
+    h = (s * mult).sum(axis=1) * 2654435761
+    return ((h >> 16) & 0xFFFF).astype(np.uint16)
 
 
 def sample_index(numel, n=64, salt=0):

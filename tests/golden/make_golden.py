@@ -142,40 +142,117 @@ def gen_stack(ms):
     print("stack.npz:", {k: v.shape for k, v in out.items()})
 
 
-def gen_segment(ms):
-    out = {}
-    for n, (B, H, W, maxdisp) in cases.SEGMENT.items():
-        net, P = build_ref_net(ms, maxdisp)
-        fl4, fr4, fl8, fr8, _ = cases.segment_inputs(n)
-        z = lambda c, s: torch.zeros(B, c, H // s, W // s)
-        # out-of-scope producers replaced by replays of closed-form tensors
-        net.feature = Replay([z(1, 2)] * 5, [z(1, 2)] * 5)
-        net.feature_up = Replay(([z(1, 2)] * 5, [z(1, 2)] * 5))
-        net.head_l = Replay(torch.zeros(B, 6, H, W)); net.head_r = Replay(torch.zeros(B, 6, H, W))
-        net.chal_0 = Replay(z(64, 2)); net.chal_3 = Replay(z(384, 16)); net.chal_4 = Replay(z(256, 32))
-        net.chal_1 = Replay(fl4, fr4)
-        net.chal_2 = Replay(fl8, fr8)
-        cap = {}
-        originals = {}
-        for name in ("build_gwc_volume_norm", "regression_topk", "disparity_regression"):
-            orig = originals[name] = getattr(ms, name)
-            def wrap(*a, _o=orig, _n=name, **k):
-                r = _o(*a, **k)
-                cap.setdefault(_n, []).append((a, r))
-                return r
-            setattr(ms, name, wrap)
-        hooks = []
-        for name in ("patch", "hourglass_att", "classif_att_", "concat_stem", "hourglass", "classif"):
-            hooks.append(getattr(net, name).register_forward_hook(
-                lambda m_, i_, o_, _n=name: cap.__setitem__(_n, o_)))
-        hooks.append(net.ssr_upsample.register_forward_pre_hook(
-            lambda m_, i_: cap.setdefault("ssr_in", []).append(i_[0])))
+OWNED = ("patch", "corr_feature_att_8", "hourglass_att", "classif_att_", "gamma", "beta", "concat_feature",
+         "concat_stem", "concat_feature_att_4", "hourglass", "classif")
+STAGES = ("build_gwc_volume_norm", "patch", "hourglass_att", "classif_att_", "concat_stem", "hourglass", "classif")
+
+
+class _FProxy:
+    """models.SemStereo's `F` (torch.nn.functional) with softmax recorded: the attention probabilities the reference
+    sorts (models/SemStereo.py:298-299) are an anonymous intermediate of forward()."""
+
+    def __init__(self, real, log):
+        self._real, self._log = real, log
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+    def softmax(self, x, dim=None, **k):
+        y = self._real.softmax(x, dim=dim, **k)
+        self._log.append((tuple(x.shape), dim, y))
+        return y
+
+
+def run_reference_segment(ms, net, B, H, W, feats):
+    """One eval-mode pass of the reference's forward() with the out-of-scope producers replaced by replays of the
+    closed-form feature maps; returns the captured intermediates."""
+    fl4, fr4, fl8, fr8 = feats
+    z = lambda c, s: torch.zeros(B, c, H // s, W // s)
+    saved = {k: getattr(net, k) for k in ("feature", "feature_up", "head_l", "head_r", "chal_0", "chal_1", "chal_2", "chal_3", "chal_4")}
+    net.feature = Replay([z(1, 2)] * 5, [z(1, 2)] * 5)
+    net.feature_up = Replay(([z(1, 2)] * 5, [z(1, 2)] * 5))
+    net.head_l = Replay(torch.zeros(B, 6, H, W)); net.head_r = Replay(torch.zeros(B, 6, H, W))
+    net.chal_0 = Replay(z(64, 2)); net.chal_3 = Replay(z(384, 16)); net.chal_4 = Replay(z(256, 32))
+    net.chal_1 = Replay(fl4, fr4)
+    net.chal_2 = Replay(fl8, fr8)
+    cap, originals, softmaxes = {}, {}, []
+    for name in ("build_gwc_volume_norm", "regression_topk", "disparity_regression"):
+        orig = originals[name] = getattr(ms, name)
+        def wrap(*a, _o=orig, _n=name, **k):
+            r = _o(*a, **k)
+            cap.setdefault(_n, []).append((a, r))
+            return r
+        setattr(ms, name, wrap)
+    realF = ms.F
+    ms.F = _FProxy(realF, softmaxes)
+    hooks = []
+    for name in ("patch", "hourglass_att", "classif_att_", "concat_stem", "hourglass", "classif"):
+        hooks.append(getattr(net, name).register_forward_hook(lambda m_, i_, o_, _n=name: cap.__setitem__(_n, o_)))
+    hooks.append(net.ssr_upsample.register_forward_pre_hook(lambda m_, i_: cap.setdefault("ssr_in", []).append(i_[0])))
+    try:
         with torch.no_grad():
             net(torch.zeros(B, 3, H, W), torch.zeros(B, 3, H, W))
+    finally:
         for h in hooks:
             h.remove()
         for name, orig in originals.items():
             setattr(ms, name, orig)
+        ms.F = realF
+        for k, v in saved.items():
+            setattr(net, k, v)
+    probs = [y for shp, dim, y in softmaxes if len(shp) == 5 and dim == 2]
+    assert len(probs) == 1, [(shp, dim) for shp, dim, _ in softmaxes]
+    cap["aw_prob"] = probs[0]                                       # [B,1,D4,H4,W4], models/SemStereo.py:298
+    return cap
+
+
+def calibrate_batchnorm(ms, net, B, H, W, feats):
+    """Running statistics := the statistics of this input (one pass with batch statistics, momentum 1), for every
+    BatchNorm of the hot segment -- what training leaves behind.  Returns {state_dict key: tensor}."""
+    bns = {}
+    for prefix in OWNED:
+        mod = getattr(net, prefix)
+        if isinstance(mod, nn.Module):
+            for name, m in mod.named_modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    bns[prefix + ("." + name if name else "")] = m
+    for m in bns.values():
+        m.momentum = 1.0
+        m.train()
+    run_reference_segment(ms, net, B, H, W, feats)
+    out = {}
+    for key, m in bns.items():
+        m.eval()
+        m.momentum = 0.1
+        out[key + ".running_mean"] = m.running_mean.detach().clone()
+        out[key + ".running_var"] = m.running_var.detach().clone()
+    return out
+
+
+def decision_gaps(cap):
+    """The reference's own margins at its two hard picks, per pixel [B,H4,W4]:
+    gap24_rel = (p24 - p25) / p24 of the sorted attention probabilities (the top-24 cut, :299-303);
+    gap2 = 2nd - 3rd largest of the 24 matching costs (the top-2 cut of regression_topk, models/submodule.py:436-437)."""
+    p = cap["aw_prob"].squeeze(1).sort(dim=1, descending=True).values
+    gap24 = (p[:, 23] - p[:, 24]) / p[:, 23]
+    (cost_sq, samples, k), pred = cap["regression_topk"][0]
+    c = cost_sq.sort(dim=1, descending=True).values
+    return gap24, c[:, 1] - c[:, 2]
+
+
+def gen_segment(ms):
+    out = {}
+    table = dict(cases.SEGMENT)
+    table.update(cases.SEGMENT_CAL)
+    for n, (B, H, W, maxdisp) in table.items():
+        net, P = build_ref_net(ms, maxdisp)
+        fl4, fr4, fl8, fr8, _ = cases.segment_inputs(n)
+        feats = (fl4, fr4, fl8, fr8)
+        if n.endswith("_cal"):
+            for key, v in calibrate_batchnorm(ms, net, B, H, W, feats).items():
+                assert key in P, key
+                out[f"{n}/bn/{key}"] = f32(v)
+        cap = run_reference_segment(ms, net, B, H, W, feats)
         (cost_sq, samples, k), pred = cap["regression_topk"][0]
         assert k == 2
         out[f"{n}/pred"] = f32(pred)
@@ -183,15 +260,70 @@ def gen_segment(ms):
         out[f"{n}/pred_att0"] = f32(cap["disparity_regression"][0][1])
         out[f"{n}/pred_att"] = f32(cap["ssr_in"][0].squeeze(1))
         assert torch.equal(cap["ssr_in"][1], pred)
-        for i, key in enumerate(("build_gwc_volume_norm", "patch", "hourglass_att", "classif_att_", "concat_stem",
-                                 "hourglass", "classif")):
+        for i, key in enumerate(STAGES):
             t = cap[key][0][1] if key == "build_gwc_volume_norm" else cap[key]
             out[f"{n}/sum/{key}"] = summary(t, i)
         out[f"{n}/cost_att"] = f32(cap["classif_att_"])       # [B,1,D8,H8,W8]: small
-        print(n, "pred", tuple(pred.shape), "samples", tuple(samples.shape),
-              "pred range", float(pred.min()), float(pred.max()))
+        gap24, gap2 = decision_gaps(cap)
+        out[f"{n}/gap24_rel"], out[f"{n}/gap2"] = f32(gap24), f32(gap2)
+        # the reference's 24 attention weights per pixel: lets the matching branch be checked on the reference's OWN
+        # candidates (no top-24 difference upstream), where the only hard pick left is the top-2 of the costs
+        ind = (samples + maxdisp // 4).long().unsqueeze(1)
+        out[f"{n}/att_topk"] = f32(torch.gather(cap["aw_prob"], 2, ind).squeeze(1))
+        print(n, "pred", tuple(pred.shape), "range", float(pred.min()), float(pred.max()),
+              "| min gap24_rel %.2e  min gap2 %.2e  median gap2 %.2e  cost std over candidates %.3f" %
+              (float(gap24.min()), float(gap2.min()), float(gap2.median()), float(cost_sq.std(dim=1).mean())))
     np.savez_compressed(os.path.join(HERE, "segment.npz"), **out)
     print("segment.npz:", len(out), "arrays")
+
+
+def gen_segment_full(ms, only=None):
+    """Checksum records at the full sizes of BASELINE.json configs[1] / configs[4]."""
+    path = os.path.join(HERE, "segment_full.npz")
+    out = dict(np.load(path)) if (only and os.path.exists(path)) else {}
+    for n, (B, H, W, maxdisp) in cases.SEGMENT_FULL.items():
+        if only and n not in only:
+            continue
+        import time
+        t0 = time.time()
+        net, P = build_ref_net(ms, maxdisp)
+        fl4, fr4, fl8, fr8, _ = cases.segment_inputs(n)
+        feats = (fl4, fr4, fl8, fr8)
+        for key, v in calibrate_batchnorm(ms, net, B, H, W, feats).items():
+            out[f"{n}/bn/{key}"] = f32(v)
+        cap = run_reference_segment(ms, net, B, H, W, feats)
+        (cost_sq, samples, k), pred = cap["regression_topk"][0]
+        H4, W4 = H // 4, W // 4
+        idx = torch.from_numpy(cases.sample_index(B * H4 * W4, cases.FULL_SAMPLES, salt=77))
+        flat = lambda t: t.reshape(B, -1, H4 * W4).permute(0, 2, 1).reshape(B * H4 * W4, -1)[idx]     # [n, channels]
+        gap24, gap2 = decision_gaps(cap)
+        out[f"{n}/pixels"] = idx.numpy().astype(np.int64)
+        out[f"{n}/pred"] = f32(flat(pred)[:, 0])
+        out[f"{n}/pred_att"] = f32(flat(cap["ssr_in"][0])[:, 0])
+        out[f"{n}/pred_att0"] = f32(flat(cap["disparity_regression"][0][1])[:, 0])
+        out[f"{n}/samples"] = flat(samples).numpy().astype(np.int16)
+        out[f"{n}/gap24_rel"], out[f"{n}/gap2"] = f32(flat(gap24)[:, 0]), f32(flat(gap2)[:, 0])
+        out[f"{n}/cost"] = f32(flat(cost_sq))
+        for i, key in enumerate(STAGES):
+            t = cap[key][0][1] if key == "build_gwc_volume_norm" else cap[key]
+            out[f"{n}/sum/{key}"] = summary(t, i)
+        # whole-map statistics of the outputs and of the margins (how many pixels of the map sit near a tie)
+        out[f"{n}/pred_sum"] = summary(pred, 50)
+        out[f"{n}/pred_att_sum"] = summary(cap["ssr_in"][0], 51)
+        # the whole maps, compactly: pred itself (the north-star output), a 16-bit hash of every pixel's candidate list,
+        # and the pixels where the reference's own margins are below the tests' DELTA (the only places where another
+        # fp32 evaluation may legitimately pick differently)
+        out[f"{n}/pred_map"] = f32(pred.squeeze(1))
+        out[f"{n}/pred_att_map"] = f32(cap["ssr_in"][0].squeeze(1))
+        out[f"{n}/candidate_hash"] = cases.candidate_set_hash(samples.numpy(), maxdisp // 4)
+        out[f"{n}/risk24"] = np.flatnonzero((gap24 < 1e-4).reshape(-1).numpy()).astype(np.int32)
+        out[f"{n}/risk2"] = np.flatnonzero((gap2 < 1e-4).reshape(-1).numpy()).astype(np.int32)
+        out[f"{n}/gap_stats"] = np.array([float(gap24.min()), float(gap24.median()), float((gap24 < 1e-4).float().mean()),
+                                          float(gap2.min()), float(gap2.median()), float((gap2 < 1e-4).float().mean())])
+        print(n, "pred range", float(pred.min()), float(pred.max()), "gap stats", out[f"{n}/gap_stats"], "%.0f s" % (time.time() - t0))
+        del cap, net
+    np.savez_compressed(path, **out)
+    print("segment_full.npz:", len(out), "arrays,", os.path.getsize(path) // 1024, "KiB")
 
 
 def gen_ssr(ref):
@@ -211,10 +343,17 @@ def gen_ssr(ref):
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
-    gen_ssr(load_ref_oplib())
-    gen_ops(load_ref_oplib())
+    what = sys.argv[1:] or ["ssr", "ops", "stack", "segment", "full"]
+    if "ssr" in what:
+        gen_ssr(load_ref_oplib())
+    if "ops" in what:
+        gen_ops(load_ref_oplib())
     ms = load_ref_model_module()
-    gen_stack(ms)
-    gen_segment(ms)
-    for f in ("ops.npz", "stack.npz", "segment.npz"):
+    if "stack" in what:
+        gen_stack(ms)
+    if "segment" in what:
+        gen_segment(ms)
+    if "full" in what or any(w in cases.SEGMENT_FULL for w in what):      # ~1 min and ~5 min of CPU, ~25 GB at 2048^2
+        gen_segment_full(ms, only=[w for w in what if w in cases.SEGMENT_FULL] or None)
+    for f in ("ops.npz", "stack.npz", "segment.npz", "segment_full.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

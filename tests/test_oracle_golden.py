@@ -86,13 +86,20 @@ def test_stack(golden, name):
     _eq(y, golden["stack"][f"stack/{name}"], atol=2e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", sorted(cases.SEGMENT))
+@pytest.mark.parametrize("name", sorted(cases.SEGMENT) + sorted(cases.SEGMENT_CAL))
 def test_hot_segment(golden, name):
-    P = oseg.deterministic_params()
+    g = golden["segment"]
+    P = cases.segment_params(name, g)            # "_cal": BatchNorm statistics calibrated by the reference run (fixture)
     fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
     r = oseg.hot_segment(P, fl4, fr4, fl8, fr8, maxdisp, keep=True)
-    g = golden["segment"]
     assert np.array_equal(r["samples"].numpy().astype(np.int16), g[f"{name}/samples"])
+    # the reference's margins at its two hard picks, restated from the oracle's intermediates (what the GPU tests'
+    # explained-deviation criterion rests on)
+    p = torch.softmax(r["att_weights"], dim=2).squeeze(1).sort(dim=1, descending=True).values
+    _eq((p[:, 23] - p[:, 24]) / p[:, 23], g[f"{name}/gap24_rel"], atol=2e-6)
+    c = r["cost"].squeeze(1).sort(dim=1, descending=True).values
+    _eq(c[:, 1] - c[:, 2], g[f"{name}/gap2"], atol=2e-5)
+    _eq(r["att_topk"].squeeze(1), g[f"{name}/att_topk"], atol=1e-7, rtol=1e-5)
     _eq(r["pred_att0"], g[f"{name}/pred_att0"], atol=1e-5)
     _eq(r["pred_att"], g[f"{name}/pred_att"], atol=1e-5)
     _eq(r["pred"], g[f"{name}/pred"], atol=1e-5)
@@ -118,3 +125,31 @@ def test_param_table_matches_reference_names():
     assert P["concat_stem.conv.weight"].shape == (32, 64, 3, 3, 3)
     assert P["patch.weight"].shape == (32, 1, 1, 3, 3)
     assert all(v.dtype == torch.float32 for v in P.values())
+
+
+def test_hot_segment_full_size_checksums(golden):
+    """BASELINE.json configs[1]'s size (1024 x 1024, maxdisp 128): the oracle against the reference's checksum record
+    (per-stage sums and sampled voxels; pred, pred_att, candidates and margins at 2048 sampled pixels).  ~25 s of CPU."""
+    name = "f1024_md128_cal"
+    g = golden["segment_full"]
+    B, H, W, maxdisp = cases.segment_shape(name)
+    P = cases.segment_params(name, g)
+    fl4, fr4, fl8, fr8, _ = cases.segment_inputs(name)
+    r = oseg.hot_segment(P, fl4, fr4, fl8, fr8, maxdisp, keep=True)
+    H4, W4 = H // 4, W // 4
+    idx = torch.as_tensor(g[f"{name}/pixels"])
+    flat = lambda t: t.reshape(B, -1, H4 * W4).permute(0, 2, 1).reshape(B * H4 * W4, -1)[idx]       # noqa: E731
+    same = (flat(r["samples"]).numpy().astype(np.int16) == g[f"{name}/samples"]).all(axis=1)
+    gap24, gap2 = g[f"{name}/gap24_rel"], g[f"{name}/gap2"]
+    assert not (~same & (gap24 >= 1e-5)).any()                   # same ATen kernels: only exact-tie pixels could differ
+    err = np.abs(flat(r["pred"])[:, 0].numpy() - g[f"{name}/pred"])
+    assert not ((err > 1e-3) & (gap2 >= 1e-5) & same).any() and np.median(err) <= 1e-6
+    _eq(flat(r["pred_att"].unsqueeze(1))[:, 0][torch.as_tensor(same)], g[f"{name}/pred_att"][same], atol=1e-4)
+    for i, (key, t) in enumerate((("build_gwc_volume_norm", None), ("patch", r["corr_volume"]), ("hourglass_att", None),
+                                  ("classif_att_", r["cost_att"]))):
+        if t is None:
+            continue
+        rec = g[f"{name}/sum/{key}"]
+        a = t.double().reshape(-1)
+        np.testing.assert_allclose(a[cases.sample_index(a.numel(), 64, i)].numpy(), rec[2:], atol=2e-5)
+        np.testing.assert_allclose((a * a).sum().item(), rec[1], rtol=1e-5)

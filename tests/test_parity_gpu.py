@@ -820,11 +820,77 @@ def test_patch_and_gate_fusion(sa):
 # hot segment: features -> pred, against the REFERENCE's fixture and against the oracle
 # --------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("name", sorted(cases.SEGMENT))
+# The graph has two HARD picks: the 24 largest of D4 attention probabilities (models/SemStereo.py:299-303) and the 2 largest
+# of 24 matching costs (models/submodule.py:436-437).  Where the reference's own margin at a pick is below the rounding
+# error of an fp32 evaluation, ANY implementation (a different summation order, another BLAS, the reference on another
+# machine) may pick differently, and the output then moves by whole candidates.  The fixtures therefore store the
+# reference's margins per pixel (gap24_rel, gap2: tests/golden/make_golden.py:decision_gaps) and the tests assert that
+# EVERY deviation is explained by a margin below DELTA; everything else must meet the 1e-3 px target of BASELINE.json,
+# with no percentage allowance.  DELTA = 1e-4: ~10x the error the HIP path is allowed on the quantities compared
+# (probabilities to 1e-5 relative, costs to 1e-5 absolute: the per-module bounds above), and ~1e-3 of the typical margin.
+DELTA24_REL = 1e-4
+DELTA2 = 1e-4
+RF_RADIUS = 36      # quarter-resolution pixels a changed candidate set can reach through concat_stem + hourglass2 (two
+                    # stride-2 stages, 4x4 attention windows at 1/16 of the quarter resolution) + classif
+
+
+def _dilate(mask, r):
+    """[B,H,W] bool -> every pixel within Chebyshev distance r of a set pixel."""
+    import torch.nn.functional as F
+    if not bool(mask.any()):
+        return mask
+    return F.max_pool2d(mask.float().unsqueeze(1), 2 * r + 1, stride=1, padding=r).squeeze(1) > 0
+
+
+def _explained_deviation_check(name, r, g, prefix):
+    """Assert the explained-flip criterion for one run `r` of the hot segment against fixture arrays g[prefix + ...]
+    (full maps).  Returns the statistics it put into REPORT."""
+    samples_ref = torch.as_tensor(g[f"{prefix}/samples"].astype(np.int64))
+    gap24 = torch.as_tensor(g[f"{prefix}/gap24_rel"])
+    gap2 = torch.as_tensor(g[f"{prefix}/gap2"])
+    set_differs = (r["samples"].cpu().long() != samples_ref).any(dim=1)                        # [B,H,W]
+    err_att = (r["pred_att"].cpu() - torch.as_tensor(g[f"{prefix}/pred_att"])).abs()
+    err = (r["pred"].cpu() - torch.as_tensor(g[f"{prefix}/pred"])).abs().squeeze(1)
+    REPORT[f"segment/{name}/pixels_with_other_candidates"] = int(set_differs.sum())
+    REPORT[f"segment/{name}/largest_gap24_rel_among_them"] = float(gap24[set_differs].max()) if bool(set_differs.any()) else 0.0
+    REPORT[f"segment/{name}/epe_vs_ref"] = float(err.mean())
+    REPORT[f"segment/{name}/pred_pixels_beyond_1e-3"] = int((err > 1e-3).sum())
+    # (i) a candidate set may differ only where the reference's 24th / 25th probabilities are within DELTA24_REL
+    bad = set_differs & (gap24 >= DELTA24_REL)
+    assert not bool(bad.any()), (f"{int(bad.sum())} pixel(s) select other candidates although the reference's margin is "
+                                 f"{float(gap24[bad].min()):.2e} .. {float(gap24[bad].max()):.2e} >= {DELTA24_REL}")
+    # pred_att (the soft-argmax over the 24 selected) is continuous except through that pick
+    bad = (err_att > 1e-3) & ~set_differs
+    assert not bool(bad.any()), f"pred_att off by up to {float(err_att[bad].max()):.2e} px on {int(bad.sum())} pixel(s) with identical candidates"
+    # (ii) pred may be off by more than 1e-3 px only where the reference's 2nd / 3rd costs are within DELTA2, or inside
+    # the receptive field of a pixel whose candidate set differs
+    near = _dilate(set_differs, RF_RADIUS)
+    tie = gap2 < DELTA2
+    bad = (err > 1e-3) & ~tie & ~near
+    assert not bool(bad.any()), (f"pred off by up to {float(err[bad].max()):.2e} px on {int(bad.sum())} pixel(s) with identical "
+                                 f"candidates around and a reference top-2 margin of >= {float(gap2[bad].min()):.2e}")
+    REPORT[f"segment/{name}/pred_beyond_1e-3_at_top2_ties"] = int(((err > 1e-3) & tie).sum())
+    REPORT[f"segment/{name}/pred_beyond_1e-3_near_other_candidates"] = int(((err > 1e-3) & ~tie & near).sum())
+    ok = ~tie & ~near
+    if bool(ok.any()):
+        REPORT[f"segment/{name}/max_err_where_no_excuse"] = float(err[ok].max())
+    return set_differs, err
+
+
+def _segment_case(sa, golden, name):
+    maxdisp = cases.segment_shape(name)[3]
+    seg = sa.HotSegment(maxdisp)
+    P = cases.segment_params(name, golden["segment"])
+    res = seg.load_state_dict(P, strict=False)
+    assert not res.unexpected_keys and all(k.endswith("num_batches_tracked") for k in res.missing_keys)
+    return seg.cuda().eval(), P
+
+
+@pytest.mark.parametrize("name", sorted(cases.SEGMENT) + sorted(cases.SEGMENT_CAL))
 def test_hot_segment_vs_reference_fixture(sa, golden, name):
     if sa.modules.CONV_ENGINE == "bf16x3" and name not in ("s128", "s96x160_b2"):
-        pytest.skip("SS_CONV_ENGINE=bf16x3: the 3-product form's ~1e-5 conv error flips more top-2 picks than these bounds allow")
-    seg, P = _segment(sa, cases.SEGMENT[name][3])
+        pytest.skip("SS_CONV_ENGINE=bf16x3: the 3-product form's ~1e-5 conv error is beyond the margins assumed here")
+    seg, P = _segment_case(sa, golden, name)
     fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
     before = dict(sa.modules.PATH_COUNTS)
     with torch.no_grad():
@@ -832,29 +898,39 @@ def test_hot_segment_vs_reference_fixture(sa, golden, name):
     assert sa.modules.PATH_COUNTS["torch"] == before["torch"]
     g = golden["segment"]
     check(f"segment/{name}/pred_att0", r["pred_att0"], g[f"{name}/pred_att0"], 1e-3)
-    same = (r["samples"].cpu().numpy().astype(np.int16) == g[f"{name}/samples"]).mean()
-    REPORT[f"segment/{name}/samples_equal_fraction"] = float(same)
-    err_att = (r["pred_att"].cpu() - torch.as_tensor(g[f"{name}/pred_att"])).abs()
-    err = (r["pred"].cpu() - torch.as_tensor(g[f"{name}/pred"])).abs()
-    REPORT[f"segment/{name}/epe_vs_ref"] = float(err.mean())
-    REPORT[f"segment/{name}/pred_fraction_within_1e-3"] = float((err <= 1e-3).float().mean())
-    if err.numel() <= 2048:
-        assert same == 1.0, f"top-24 candidate sets differ from the reference on {100 * (1 - same):.3f}% of entries"
+    set_differs, err = _explained_deviation_check(name, r, g, name)
+    assert float(err.median()) <= 1e-5
+    if name in ("s128", "s96x160_b2"):
+        # the two small fixtures have been bit-stable on every build so far: keep them as strict canaries
+        assert not bool(set_differs.any())
         check(f"segment/{name}/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
-        REPORT[f"segment/{name}/pred"] = float(err.max())
-        # measured max error 2.4e-6; one pixel is allowed beyond 1e-3 px: the 2-D convolutions on the path are
-        # MIOpen calls whose algorithm (hence rounding) may differ from box to box, and regression_topk's hard
-        # top-2 pick turns a last-bit difference into a whole-candidate jump where two costs tie
-        assert float(err.median()) <= 1e-5 and int((err > 1e-3).sum()) <= 1, float(err.max())
-    else:
-        # Thousands of pixels on closed-form (untrained) weights: the hard picks of the graph -- 24 of up to
-        # 96 attention weights (models/SemStereo.py:299-303), then 2 of 24 costs (models/submodule.py:436-437)
-        # -- are decided by fp32 rounding on ~0.1 % of the pixels in any implementation, and a pixel whose
-        # candidate set differs perturbs its 3-D receptive field (bench.py's
-        # float64-truth leg).  Everything else must agree to 1e-3 px.
-        assert same >= 0.9995
-        assert float((err_att <= 1e-3).float().mean()) >= 0.999
-        assert float((err <= 1e-3).float().mean()) >= 0.99 and float(err.median()) <= 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(cases.SEGMENT) + sorted(cases.SEGMENT_CAL))
+def test_matching_branch_on_the_reference_candidates(sa, golden, name):
+    """models/SemStereo.py:314-323 fed the REFERENCE's 24 candidates and attention weights (fixture): no top-24 difference
+    can exist upstream, so every pixel must be within 1e-3 px of the reference's `pred` unless the reference's own 2nd / 3rd
+    largest costs are within DELTA2 -- no receptive-field excuse, no percentage."""
+    if sa.modules.CONV_ENGINE == "bf16x3" and name not in ("s128", "s96x160_b2"):
+        pytest.skip("SS_CONV_ENGINE=bf16x3: beyond the margins assumed here")
+    seg, P = _segment_case(sa, golden, name)
+    fl4, fr4, _, _, maxdisp = cases.segment_inputs(name)
+    g = golden["segment"]
+    samples = torch.as_tensor(g[f"{name}/samples"].astype(np.float32))
+    att = torch.as_tensor(g[f"{name}/att_topk"]).unsqueeze(1)
+    with torch.no_grad():
+        pred = seg.matching_branch(dev(fl4), dev(fr4), dev(att), dev(samples))
+    err = (pred.cpu() - torch.as_tensor(g[f"{name}/pred"])).abs().squeeze(1)
+    gap2 = torch.as_tensor(g[f"{name}/gap2"])
+    tie = gap2 < DELTA2
+    REPORT[f"matching/{name}/epe_vs_ref"] = float(err.mean())
+    REPORT[f"matching/{name}/max_err_off_ties"] = float(err[~tie].max())
+    REPORT[f"matching/{name}/pixels_beyond_1e-3_at_ties"] = int(((err > 1e-3) & tie).sum())
+    REPORT[f"matching/{name}/smallest_flipped_gap2"] = float(gap2[err > 1e-3].max()) if bool((err > 1e-3).any()) else 0.0
+    bad = (err > 1e-3) & ~tie
+    assert not bool(bad.any()), (f"{int(bad.sum())} pixel(s) off by up to {float(err[bad].max()):.2e} px although the "
+                                 f"reference's top-2 margin there is >= {float(gap2[bad].min()):.2e}")
+    assert float(err[~tie].max()) <= 1e-3 and float(err.median()) <= 1e-5
 
 
 def test_matching_branch_as_close_to_float64_truth_as_the_fp32_oracle(sa):
@@ -916,3 +992,107 @@ def test_reference_shaped_composition_on_gpu(sa, golden):
     check("segment_unfused/pred", r["pred"], g[f"{name}/pred"], 1e-3)
     (r["pred"].sum() + r["pred_att"].sum()).backward()
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in ins)
+
+
+# --------------------------------------------------------------------------------------
+# behaviour at the edges of fp32 (the two documented differences of the fp16 form from an fp32 convolution)
+# --------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("poison", [float("nan"), float("inf")])
+def test_conv3d_f16_form_nonfinite_inputs(sa, poison):
+    """INTENDED BEHAVIOUR.  The reference's fp32 Conv3d confines a NaN / inf input voxel to its 3x3x3 receptive field.  The
+    two-term fp16 form scales each staged chunk by the power of two of its maximum, so a non-finite voxel makes the scale of
+    the WORKGROUP TILES that stage it non-finite: every output whose receptive field holds the voxel is non-finite (as in
+    the reference), outputs of the same tiles may be too (a superset), and every output of a tile that never stages the
+    voxel is bit-identical to the clean run.  The exact-fp32 engine (SS_CONV_ENGINE=f32) reproduces the reference's set."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin = Cout = 32
+    D, H, W = 6, 24, 96
+    x = F.relu(dd.t_normalish((1, Cin, D, H, W), 731))
+    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 732, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    one, zero = dev(torch.ones(Cout)), dev(torch.zeros(Cout))
+    ws = sa.modules.pack_conv_weight_bf16s(dev(w), 19)
+    clean = sa.modules.conv3d_bf16s_hip(dev(x), ws, Cout, one, zero, False, 19).cpu()
+    pz, py, px = 3, 10, 40
+    xp = x.clone()
+    xp[0, 5, pz, py, px] = poison
+    y = sa.modules.conv3d_bf16s_hip(dev(xp), ws, Cout, one, zero, False, 19).cpu()
+    y32 = sa.modules.conv3d_hip(dev(xp), sa.modules.pack_conv_weight(dev(w)), one, zero, 3, 1, False).cpu()
+    rf = torch.zeros(D, H, W, dtype=torch.bool)
+    rf[pz - 1:pz + 2, py - 1:py + 2, px - 1:px + 2] = True
+    bad = ~torch.isfinite(y[0])
+    assert bool(bad[:, rf].all()), "an output whose receptive field holds the non-finite voxel is finite"
+    bad32 = ~torch.isfinite(y32[0])
+    assert bool(bad32[:, rf].all()) and not bool(bad32[:, ~rf].any()), "the exact-fp32 engine must confine it to the receptive field"
+    # tiles are at most 2 x 8 x 32 outputs with a one-voxel halo: anything further than that from the voxel never staged it
+    far = torch.ones(D, H, W, dtype=torch.bool)
+    far[max(pz - 3, 0):pz + 4, max(py - 9, 0):py + 10, max(px - 33, 0):px + 34] = False
+    assert torch.equal(y[0][:, far], clean[0][:, far]), "a tile that never stages the voxel changed"
+    REPORT[f"conv3d_f16x3_nonfinite/{poison}/outputs_nonfinite_beyond_rf"] = int(bad[:, ~rf].sum())
+
+
+def test_conv3d_f16_form_tiny_inputs_flush(sa):
+    """INTENDED BEHAVIOUR.  The block-floating scale of a staged chunk is clamped at 2^-111 (split_f16.h: E_MIN), so a tile
+    whose inputs are ALL below ~2^-111 = 3.9e-34 contributes zero where an fp32 convolution would return values of that
+    size (|y| < 1e-32): an absolute difference below 1e-32, far under any tolerance of the path.  Inputs at 1e-30 and up keep
+    full relative precision (test_conv3d_f16_form_block_floating_ranges)."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    Cin = Cout = 32
+    D, H, W = 3, 9, 40
+    x = (F.relu(dd.t_normalish((1, Cin, D, H, W), 741)).double() * 2.0 ** -118).float()
+    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 742, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    shift = dd.t_uniform((Cout,), 743, -0.2, 0.2)
+    ref = F.conv3d(x.double(), w.double(), None, 1, 1) + shift.double().reshape(1, -1, 1, 1, 1)
+    y = sa.modules.conv3d_bf16s_hip(dev(x), sa.modules.pack_conv_weight_bf16s(dev(w), 19), Cout, dev(torch.ones(Cout)), dev(shift),
+                                    False, 19).cpu()
+    assert bool(torch.isfinite(y).all())
+    assert float((y.double() - ref).abs().max()) <= 1e-32 + 1e-7 * 0.2           # the shift's own fp32 rounding
+    REPORT["conv3d_f16x3_tiny/max_abs_diff"] = float((y.double() - ref).abs().max())
+
+
+def test_cabi_is_reentrant_two_threads_two_streams(sa):
+    """SURVEY.md section 8(b), threading: nn.DataParallel drives the ops from one Python thread per GPU, so the launchers
+    must keep no global mutable state and honour the calling thread's current stream.  Two threads, each on its own HIP
+    stream, run different entry points of the C ABI concurrently (ctypes releases the GIL during the calls) for many
+    iterations; every result must be bit-identical to the single-threaded one."""
+    import threading
+    from oracle import detdata as dd
+    a, b = dev(dd.t_normalish((2, 64, 24, 128), 751)), dev(dd.t_normalish((2, 64, 24, 128), 752))
+    x = dev(torch.relu(dd.t_normalish((1, 32, 6, 24, 96), 753)))
+    w = dd.t_uniform((32, 32, 3, 3, 3), 754, -1, 1) * (3.0 / (32 * 27)) ** 0.5
+    ws = sa.modules.pack_conv_weight_bf16s(dev(w), 19)
+    one, zero = dev(torch.ones(32)), dev(torch.zeros(32))
+    cost = dev(dd.t_normalish((2, 24, 48, 64), 755))
+    cand = dev(dd.distinct_sorted_candidates(2, 24, 48, 64, 32, 756))
+    jobs = {
+        "gwc": lambda: sa.ops.build_gwc_volume_norm(a, b, 8, 8),
+        "conv": lambda: sa.modules.conv3d_bf16s_hip(x, ws, 32, one, zero, True, 19),
+        "topk": lambda: sa.ops.regression_topk(cost, cand, 2),
+        "concat": lambda: sa.ops.build_concat_volume(a, b, 6),
+    }
+    want = {k: f().clone() for k, f in jobs.items()}
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(order):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(40):
+                    for k in order:
+                        got = jobs[k]()
+                        if it % 8 == 0:
+                            st.synchronize()
+                            if not torch.equal(got, want[k]):
+                                errors.append(f"{k} differs in iteration {it} of thread {order[0]}")
+            st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(o,)) for o in (("gwc", "conv", "topk", "concat"), ("conv", "concat", "gwc", "topk"))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
