@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (5): bumped on any signature change or new entry point the Python binding requires. */
+/* ABI version (6): bumped on any signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
  * measurement aids) are read from the environment ONCE per process; call this after changing
@@ -122,6 +122,12 @@ int ss_disparity_variance_fwd(const float* prob, const float* disparity, float* 
  * logits [B,2m,H,W] -> prob (nullable) [B,2m,H,W], disp [B,H,W], var [B,1,H,W] */
 int ss_softmax_regression_fwd(const float* logits, float* prob, float* disp, float* var,
                               int B, int maxdisp, int H, int W, ss_stream_t stream);
+/* The same with the trilinear up-sampling in front of it fused in (models/SemStereo.py:279-285):
+ * coarse [B,1,maxdisp,H/2,W/2] = classif_att_'s output; up [B,2*maxdisp,H,W] receives
+ * F.interpolate(coarse, [2*maxdisp,H,W], mode='trilinear') (align_corners=False, exact 2x in every dimension: H, W even),
+ * disp [B,H,W] and var [B,1,H,W] the soft-argmax and variance of softmax(up) over the disparity axis.  2*maxdisp <= 128. */
+int ss_upsample_softmax_regression_fwd(const float* coarse, float* up, float* disp, float* var,
+                                       int B, int maxdisp, int H, int W, ss_stream_t stream);
 
 /* Fused models/SemStereo.py:286-293 (variance gate, Propagation x2 [models/submodule.py:290-307],
  * 5-sample SpatialTransformer_grid, channel-mean correlation, softmax over the 5 samples):
@@ -159,6 +165,15 @@ int ss_ssr_param_count(void);
 /* channelAtt gating (models/SemStereo.py:101-102): out[b,c,d,y,x] = sigmoid(att[b,c,y,x]) * cv[b,c,d,y,x] */
 int ss_channel_gate_fwd(const float* att_logits, const float* cv, float* out,
                         int B, int C, int D, int H, int W, ss_stream_t stream);
+
+/* channelAtt.im_att (models/SemStereo.py:89-100; BasicConv, models/submodule.py:89-116) in one launch:
+ *   out[b,cv,y,x] = W2[cv,:] . relu(scale1 * (W1 . im[b,:,y,x]) + shift1) + bias2[cv]     (sigmoid of it when `sigmoid`)
+ * im [B,Cin,H,W]; w1_split / w2_split: W1 [Cmid,Cin], W2 [Cout,Cmid] packed by ss_pack_pointwise_weights_bf16s;
+ * scale1 / shift1: the eval-mode BatchNorm2d folded to an affine (NULL: identity); bias2 may be NULL.
+ * Built for the reference's two gates: (Cin, Cmid, Cout) = (256, 128, 32) and (128, 64, 32). */
+int ss_channel_att_logits_fwd(const float* im, const void* w1_split, const float* scale1, const float* shift1,
+                              const void* w2_split, const float* bias2, float* out,
+                              int B, int Cin, int Cmid, int Cout, int H, int W, int sigmoid, ss_stream_t stream);
 
 /* ---- 3-D aggregation stack -------------------------------------------------------------
  * Conv3d(bias=False) [+ BatchNorm3d in eval] [+ residual] [+ ReLU]: convbn_3d

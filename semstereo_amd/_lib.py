@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -32,10 +32,12 @@ _SIGNATURES = {
     "ss_disparity_regression_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "ss_disparity_variance_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ss_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ss_upsample_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_regression_topk_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_sample_strength_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_topk_candidates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_channel_gate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_channel_att_logits_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_ssr_upsample_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_bf16s_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -334,10 +334,15 @@ __global__ __launch_bounds__(256) void topk_candidates_split(const float* __rest
 
 // softmax over D + expectation + variance (models/SemStereo.py:281-285): 64 pixels x 4 waves, the
 // D axis split over the waves in 16-plane chunks whose exponentials stay in registers.
-template <int NCH>   // 16-plane chunks per wave: D <= 64*NCH
+// UP: the logits are the 2x trilinear up-sampling (F.interpolate(..., mode='trilinear'), align_corners=False,
+// models/SemStereo.py:279) of `logits` = the 1/8-scale classifier output [B,1,D/2,H/2,W/2], computed here on the fly in
+// ATen's own nesting -- per coarse plane the bilinear (h, w) value, then the blend along D -- and also written to `up`
+// [B,D,H,W] for the candidate selection that follows: one pass instead of upsample_trilinear3d + this kernel.
+template <int NCH, bool UP>   // 16-plane chunks per wave: D <= 64*NCH
 __global__ __launch_bounds__(256) void softmax_regress_split(const float* __restrict__ logits, float* __restrict__ prob,
                                                               float* __restrict__ disp, float* __restrict__ var,
-                                                              int D, int m, long long plane, long long total) {
+                                                              float* __restrict__ up, int D, int m, int W,
+                                                              long long plane, long long total) {
     __shared__ float red[4][64];
     __shared__ float part[4 * NCH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -347,14 +352,51 @@ __global__ __launch_bounds__(256) void softmax_regress_split(const float* __rest
     const float* lp = logits + b * D * plane + pix;
     float e[NCH][16];
     float mx = -INFINITY;
+    if constexpr (UP) {
+        // source coordinates of ATen's area_pixel_compute_source_index(scale = 0.5, align_corners = false)
+        const int H = (int)(plane / W), W8 = W / 2, H8 = H / 2, D8 = D / 2;
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        const float sx = fmaxf(0.5f * (x + 0.5f) - 0.5f, 0.f), sy = fmaxf(0.5f * (y + 0.5f) - 0.5f, 0.f);
+        const int x0 = (int)sx, y0 = (int)sy;
+        const int x1 = x0 + (x0 < W8 - 1), y1 = y0 + (y0 < H8 - 1);
+        const float lx1 = sx - x0, lx0 = 1.f - lx1, ly1 = sy - y0, ly0 = 1.f - ly1;
+        const long long plane8 = (long long)H8 * W8;
+        const float* cp = logits + b * D8 * plane8;
+        const int o00 = y0 * W8 + x0, o01 = y0 * W8 + x1, o10 = y1 * W8 + x0, o11 = y1 * W8 + x1;
 #pragma unroll
-    for (int n = 0; n < NCH; ++n)
+        for (int n = 0; n < NCH; ++n) {
+            const int dA = (n * 4 + wave) * 16;                   // first fine plane of this chunk (wave-uniform)
+            float P[10];                                          // bilinear values of coarse planes dA/2 - 1 .. dA/2 + 8
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int d = (n * 4 + wave) * 16 + k;
-            e[n][k] = (active && d < D) ? lp[d * plane] : -INFINITY;
-            mx = fmaxf(mx, e[n][k]);
+            for (int j = 0; j < 10; ++j) {
+                const int c = min(max(dA / 2 - 1 + j, 0), D8 - 1);
+                const float* q = cp + c * plane8;
+                const float v00 = q[o00], v01 = q[o01], v10 = q[o10], v11 = q[o11];
+                P[j] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int d = dA + k;
+                // even d = 2c: planes c - 1 (0.25) and c (0.75), d = 0: plane 0 alone; odd d = 2c + 1: planes c (0.75), c + 1 (0.25)
+                float v;
+                if (k & 1) v = 0.75f * P[k / 2 + 1] + 0.25f * P[k / 2 + 2];
+                else v = (d == 0) ? (1.f * P[1] + 0.f * P[1]) : (0.25f * P[k / 2] + 0.75f * P[k / 2 + 1]);
+                const bool ok = active && d < D;
+                if (ok) up[(b * D + d) * plane + pix] = v;
+                e[n][k] = ok ? v : -INFINITY;
+                mx = fmaxf(mx, e[n][k]);
+            }
         }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NCH; ++n)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int d = (n * 4 + wave) * 16 + k;
+                e[n][k] = (active && d < D) ? lp[d * plane] : -INFINITY;
+                mx = fmaxf(mx, e[n][k]);
+            }
+    }
     red[wave][lane] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
@@ -466,10 +508,26 @@ int ss_softmax_regress_split_launch(const float* logits, float* prob, float* dis
     const long long plane = (long long)H * W, total = (long long)B * plane;
     dim3 grid((unsigned)ss::ceil_div_ll(total, 64));
     if (D <= 64)
-        hipLaunchKernelGGL(softmax_regress_split<1>, grid, dim3(256), 0, st, logits, prob, disp, var, D, maxdisp, plane, total);
+        hipLaunchKernelGGL((softmax_regress_split<1, false>), grid, dim3(256), 0, st, logits, prob, disp, var, nullptr, D, maxdisp, W, plane, total);
     else if (D <= 128)
-        hipLaunchKernelGGL(softmax_regress_split<2>, grid, dim3(256), 0, st, logits, prob, disp, var, D, maxdisp, plane, total);
+        hipLaunchKernelGGL((softmax_regress_split<2, false>), grid, dim3(256), 0, st, logits, prob, disp, var, nullptr, D, maxdisp, W, plane, total);
     else
         return 1;   // caller falls back to the one-thread-per-pixel kernel
     return 0;
+}
+
+extern "C" int ss_upsample_softmax_regression_fwd(const float* coarse, float* up, float* disp, float* var, int B, int maxdisp,
+                                                  int H, int W, ss_stream_t stream) {
+    SS_REQUIRE(coarse && up && disp && var);
+    SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0);
+    const int D = 2 * maxdisp;
+    if ((H & 1) || (W & 1) || D > 128 || (D & 1)) return SS_ERR_UNSUPPORTED;       // exact 2x in every dimension
+    const long long plane = (long long)H * W, total = (long long)B * plane;
+    dim3 grid((unsigned)ss::ceil_div_ll(total, 64));
+    hipStream_t st = ss::as_stream(stream);
+    if (D <= 64)
+        hipLaunchKernelGGL((softmax_regress_split<1, true>), grid, dim3(256), 0, st, coarse, nullptr, disp, var, up, D, maxdisp, W, plane, total);
+    else
+        hipLaunchKernelGGL((softmax_regress_split<2, true>), grid, dim3(256), 0, st, coarse, nullptr, disp, var, up, D, maxdisp, W, plane, total);
+    return ss::check_launch();
 }

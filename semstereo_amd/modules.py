@@ -451,16 +451,18 @@ class BasicConv(nn.Module):
         self.train(ref.training)
         return self
 
-    def forward(self, x, gate_logits=None):
+    def forward(self, x, gate_logits=None, gate=None):
         """gate_logits [B,Cout,H,W] (3-D form only): fuses the channelAtt gate that follows `concat_stem`
-        in the model (models/SemStereo.py:319-320) into the conv epilogue."""
-        if self.is_3d and not self.deconv and _inference(self, x, gate_logits):
+        in the model (models/SemStereo.py:319-320) into the conv epilogue; `gate`: its sigmoid, already computed."""
+        if self.is_3d and not self.deconv and _inference(self, x, gate_logits, gate):
             PATH_COUNTS["hip"] += 1
-            g = None if gate_logits is None else torch.sigmoid(gate_logits).contiguous()     # [B,Cout,H,W]: tiny
+            g = gate if gate is not None else (None if gate_logits is None else torch.sigmoid(gate_logits).contiguous())
             return run_convbn(self, "bc", self.conv, self.bn if self.use_bn else None, x, relu=bool(self.relu), gate=g)
+        if gate is not None:
+            assert gate_logits is None
         if self.is_3d:
             PATH_COUNTS["torch"] += 1
-        elif not self.deconv and gate_logits is None and _inference(self, x):
+        elif not self.deconv and gate_logits is None and gate is None and _inference(self, x):
             y = run_conv2d(self, "bc2d", self.conv, self.bn if self.use_bn else None, x, bool(self.relu))
             if y is not None:
                 return y
@@ -471,6 +473,8 @@ class BasicConv(nn.Module):
             x = F.relu(x)
         if gate_logits is not None:
             x = torch.sigmoid(gate_logits).unsqueeze(2) * x
+        if gate is not None:
+            x = gate.unsqueeze(2) * x
         return x
 
 
@@ -511,22 +515,22 @@ def stem_broadcast_half(stem, left, att):
     return ops.stem_left(q, att)
 
 
-def stem_volume_half(stem, right_vol, partial, gate_logits=None):
+def stem_volume_half(stem, right_vol, partial, gate=None):
     """`stem` over its last C input channels (`right_vol` [B,C,nd,H,W]) continuing `partial`, then BatchNorm, ReLU
-    and the optional channelAtt gate on the total."""
-    assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, right_vol, partial, gate_logits)
+    and the optional channelAtt gate (`gate` [B,Cout,H,W]: the SIGMOID of the gate's logits) on the total."""
+    assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, right_vol, partial, gate)
     nterms = _tiled_nterms()
     _, _, wr, scale, shift = _stem_halves_params(stem, right_vol.shape[1])
-    g = None if gate_logits is None else torch.sigmoid(gate_logits).contiguous()
+    g = None if gate is None else gate.contiguous()
     return conv3d_bf16s_hip(right_vol, wr, stem.conv.out_channels, scale, shift, bool(stem.relu), nterms, None, g, partial=partial)
 
 
-def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate_logits=None):
+def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate=None):
     """`stem` (a 3x3x3 stride-1 BasicConv with 2C input channels) applied to cat(att * left broadcast over the
     candidates, right_vol) WITHOUT building the left half of that volume or convolving it: by linearity its
     contribution (stem_broadcast_half) initialises the accumulators of the right half's convolution
     (stem_volume_half) (models/SemStereo.py:241-244, 316-320).  Split-bf16 engines, inference only."""
-    return stem_volume_half(stem, right_vol, stem_broadcast_half(stem, left, att), gate_logits)
+    return stem_volume_half(stem, right_vol, stem_broadcast_half(stem, left, att), gate)
 
 
 ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launches) | "fused" (one kernel per window)
@@ -835,16 +839,53 @@ class channelAtt(nn.Module):
         self.train(ref.training)
         return self
 
-    def logits(self, im):
-        return self.im_att(im)
+    def _hip_params(self):
+        """im_att as ss_channel_att_logits_fwd wants it, or None when the module is not the reference's shape:
+        BasicConv(1x1 Conv2d, no bias -> BatchNorm2d -> ReLU) -> 1x1 Conv2d(+bias), widths (256,128,32) / (128,64,32)."""
+        a, b = self.im_att[0], self.im_att[1]
+        c1 = getattr(a, "conv", None)
+        ok = (len(self.im_att) == 2 and isinstance(c1, nn.Conv2d) and isinstance(b, nn.Conv2d) and getattr(a, "relu", False)
+              and c1.kernel_size == (1, 1) and b.kernel_size == (1, 1) and c1.bias is None and c1.stride == (1, 1)
+              and b.stride == (1, 1) and c1.groups == 1 and b.groups == 1 and c1.padding == (0, 0) and b.padding == (0, 0)
+              and (c1.in_channels, c1.out_channels, b.out_channels) in ((256, 128, 32), (128, 64, 32))
+              and b.in_channels == c1.out_channels)
+        if not ok:
+            return None
+        bn = a.bn if getattr(a, "use_bn", True) else None
+        srcs = [c1.weight, b.weight] + ([b.bias] if b.bias is not None else []) + \
+               ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+        def build():
+            sc, sh = fold_bn(bn) if bn is not None else (None, None)
+            return (pack_pointwise_weight_bf16s(c1.weight), sc, sh, pack_pointwise_weight_bf16s(b.weight),
+                    None if b.bias is None else b.bias.detach().float().contiguous())
+        return _cache(self).get("im_att", srcs, build)
+
+    def logits(self, im, sigmoid=False):
+        """im_att(im) [B,cv_chan,H,W] (its sigmoid when `sigmoid`): one HIP launch in inference for the reference's shapes."""
+        if _inference(self, im) and im.is_cuda:
+            prm = self._hip_params()
+            if prm is not None:
+                PATH_COUNTS["hip"] += 1
+                w1, sc, sh, w2, b2 = prm
+                im = im if im.is_contiguous() else im.contiguous()
+                dev = _lib.require_device(im)
+                B, Cin, H, W = im.shape
+                c1, c2 = self.im_att[0].conv, self.im_att[1]
+                out = torch.empty((B, c2.out_channels, H, W), dtype=im.dtype, device=im.device)
+                with torch.cuda.device(dev):
+                    call("ss_channel_att_logits_fwd", ptr(im), ptr(w1), ptr(sc), ptr(sh), ptr(w2), ptr(b2), ptr(out),
+                         B, Cin, c1.out_channels, c2.out_channels, H, W, int(bool(sigmoid)))
+                return out
+        att = self.im_att(im)
+        return torch.sigmoid(att) if sigmoid else att
 
     def forward(self, cv, im):
-        att = self.im_att(im)
         if _inference(self, cv, im):
             PATH_COUNTS["hip"] += 1
-            return ops.channel_gate(att, cv)
+            return ops.channel_gate(self.logits(im), cv)
         PATH_COUNTS["torch"] += 1
-        return torch.sigmoid(att.unsqueeze(2)) * cv
+        return torch.sigmoid(self.im_att(im).unsqueeze(2)) * cv
 
 
 class SSR_upsample(nn.Module):

@@ -228,6 +228,27 @@ def softmax_regression(logits, maxdisp, want_prob=False):
     return disp, var, prob
 
 
+def upsample_softmax_regression(coarse, maxdisp, H, W):
+    """Fused models/SemStereo.py:279-285: trilinear 2x up-sampling of the classifier output `coarse` [B,1,maxdisp,H/2,W/2]
+    to [B,1,2*maxdisp,H,W], softmax over the disparity axis, its expectation and variance -- one kernel.
+    -> (att_weights [B,1,2m,H,W], disp [B,H,W], var [B,1,H,W]).  Inference only; needs exact 2x and 2*maxdisp <= 128."""
+    coarse = _c(coarse)
+    dev = _lib.require_device(coarse)
+    B = coarse.shape[0]
+    assert tuple(coarse.shape[1:]) == (1, maxdisp, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0
+    up = torch.empty((B, 1, 2 * maxdisp, H, W), dtype=coarse.dtype, device=coarse.device)
+    disp = torch.empty((B, H, W), dtype=coarse.dtype, device=coarse.device)
+    var = torch.empty((B, 1, H, W), dtype=coarse.dtype, device=coarse.device)
+    with torch.cuda.device(dev):
+        call("ss_upsample_softmax_regression_fwd", ptr(coarse), ptr(up), ptr(disp), ptr(var), B, int(maxdisp), H, W)
+    return up, disp, var
+
+
+def upsample_softmax_regression_applies(coarse, maxdisp, H, W):
+    return (coarse.dim() == 5 and tuple(coarse.shape[1:]) == (1, maxdisp, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0
+            and 2 * maxdisp <= 128)
+
+
 def _topk_reference_math(cost, disparity_samples, k):
     _, ind = cost.sort(dim=1, descending=True, stable=True)
     pool = ind[:, :k]

@@ -84,10 +84,13 @@ class HotSegment(nn.Module):
         else:
             cost_att = self.corr_feature_att_8(self.patch(corr), fl8)
         cost_att = self.classif_att_(self.hourglass_att(cost_att))                             # :277-278
-        att_weights = F.interpolate(cost_att, [m4 * 2, H4, W4], mode="trilinear")              # :279
-        if fast:
+        if fast and ops.upsample_softmax_regression_applies(cost_att, m4, H4, W4):
+            att_weights, pred0, var = ops.upsample_softmax_regression(cost_att, m4, H4, W4)    # :279-285 fused
+        elif fast:
+            att_weights = F.interpolate(cost_att, [m4 * 2, H4, W4], mode="trilinear")          # :279
             pred0, var, _ = ops.softmax_regression(att_weights.squeeze(1), m4)                 # :281-285 fused
         else:
+            att_weights = F.interpolate(cost_att, [m4 * 2, H4, W4], mode="trilinear")          # :279
             prob0 = F.softmax(att_weights.squeeze(1), dim=1)
             pred0 = ops.disparity_regression(prob0, m4)
             var = ops.disparity_variance(prob0, m4, pred0.unsqueeze(1))
@@ -114,23 +117,21 @@ class HotSegment(nn.Module):
     # ---- models/SemStereo.py:314-323 ---------------------------------------------------
     def matching_prelude(self, fl4, fr4):
         """:314-315 and the image half of :320 -- the 2-D convolutions that do not depend on the attention
-        branch (fast path only): concat features of both views in one batch (shared weights) and the logits
-        of the concat_feature_att_4 gate."""
-        both = torch.cat((fl4, fr4), dim=0)
+        branch (fast path only): concat features of both views and the concat_feature_att_4 gate (sigmoid applied)."""
         cf = self.concat_feature
-        y = None
-        # conv3x3 + BN + ReLU, conv3x3 (models/SemStereo.py:222-226), reference-built or twin: both on the split engine
-        if (len(cf) == 2 and isinstance(cf[1], nn.Conv2d) and isinstance(getattr(cf[0], "conv", None), nn.Conv2d)
-                and getattr(cf[0], "relu", False) and M._inference(cf, both)):
-            bn = cf[0].bn if getattr(cf[0], "use_bn", True) else None
-            y = M.run_conv2d(cf[0], "bc2d", cf[0].conv, bn, both, True)
-            if y is not None:
-                z = M.run_conv2d(cf, "cf1", cf[1], None, y, False)
-                y = z if z is not None else cf[1](y)
-        if y is None:
-            y = cf(both)
-        cl, cr = y.split(fl4.shape[0], dim=0)
-        return cl, cr, self.concat_feature_att_4.logits(fl4)
+
+        def one_view(x):
+            # conv3x3 + BN + ReLU, conv3x3 (models/SemStereo.py:222-226), reference-built or twin: both on the split engine
+            if (len(cf) == 2 and isinstance(cf[1], nn.Conv2d) and isinstance(getattr(cf[0], "conv", None), nn.Conv2d)
+                    and getattr(cf[0], "relu", False) and M._inference(cf, x)):
+                bn = cf[0].bn if getattr(cf[0], "use_bn", True) else None
+                y = M.run_conv2d(cf[0], "bc2d", cf[0].conv, bn, x, True)
+                if y is not None:
+                    z = M.run_conv2d(cf, "cf1", cf[1], None, y, False)
+                    return z if z is not None else cf[1](y)
+            return cf(x)
+        # one pair of launches per view: batching the two views needed a 34 MB torch.cat in front (28 us of ATen copy)
+        return one_view(fl4), one_view(fr4), self.concat_feature_att_4.logits(fl4, sigmoid=True)
 
     def matching_branch(self, fl4, fr4, att_topk, samples, prelude=None):
         fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, att_topk)
@@ -141,10 +142,10 @@ class HotSegment(nn.Module):
                 # nor convolved (modules.stem_of_broadcast_and_volume); only the warped right half is a volume
                 partial = M.stem_broadcast_half(self.concat_stem, cl, att_topk)                # :319, broadcast half
                 right = ops.concat_volume_sampled(None, cr, samples, att_topk)                 # :316 + :318, warped half
-                volume = M.stem_volume_half(self.concat_stem, right, partial, gate4)           # :319 + :320
+                volume = M.stem_volume_half(self.concat_stem, right, partial, gate4)           # :319 + :320 (gate4: sigmoid done)
             else:
                 volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                  # :316 + :318 fused
-                volume = self.concat_stem(volume, gate4)                                       # :319 + :320 fused
+                volume = self.concat_stem(volume, gate=gate4)                                  # :319 + :320 fused
         else:
             cl = self.concat_feature(fl4)                                                      # :314
             cr = self.concat_feature(fr4)                                                      # :315
