@@ -239,7 +239,10 @@ def main():
             plain, timed = M.conv3d_bf16s_hip, timer.wrap("concat_stem", M.conv3d_bf16s_hip)
             M.conv3d_bf16s_hip = lambda *a, **k: (timed if (k.get("gate") is not None or (len(a) > 8 and a[8] is not None))
                                                   else plain)(*a, **k)
+        # the cost-volume kernel of the step: build_gwc_volume_norm fused with `patch` and the channelAtt gate
+        # (models/SemStereo.py:273-276, ss_gwc_patch_gate_fwd); the volume kernel alone when that fusion is off
         semstereo_amd.segment.ops.build_gwc_volume_norm = timer.wrap("gwc", semstereo_amd.ops.build_gwc_volume_norm)
+        semstereo_amd.segment.ops.gwc_patch_gate = timer.wrap("gwc_fused", semstereo_amd.ops.gwc_patch_gate)
 
     def step():
         with torch.no_grad():
@@ -360,16 +363,23 @@ def main():
                                "note": f"{nterms} {typ} products per fp32 product (fp16 and bf16 MFMA peaks are equal); fp32-equivalent rate {eq:.1f} TFLOP/s = "
                                        f"{eq / MFMA_F32_PEAK_TFLOPS:.2f} x the {MFMA_F32_PEAK_TFLOPS} TFLOP/s fp32-MFMA peak",
                                "fp32_equivalent_tflops": eq}
-    ms = timer.mean_ms("gwc")
+    ms, fused_gwc = timer.mean_ms("gwc"), False
+    if not ms:
+        ms, fused_gwc = timer.mean_ms("gwc_fused"), True
     if ms:
+        # algorithmic bytes of SURVEY.md section 8(d): both feature maps in, the [B,32,D8,H8,W8] volume out (the fused
+        # kernel also reads the [B,32,H8,W8] gate logits and writes the volume AFTER `patch` and the gate: same size)
         nbytes = 4.0 * (2 * 256 * H8 * W8 + 32 * D8 * H8 * W8) * B
         ach = nbytes / (ms * 1e-3) / 1e9
-        res["roofline_cost_volume"] = {"kernel": "gwc_volume_v4<8,true> (build_gwc_volume_norm, live shape)",
+        res["roofline_cost_volume"] = {"kernel": ("gwc_patch_gate_v4<8,true> (build_gwc_volume_norm + patch + channelAtt gate, "
+                                                  "models/SemStereo.py:273-276, live shape)" if fused_gwc
+                                                  else "gwc_volume_v4<8,true> (build_gwc_volume_norm, live shape)"),
                                        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms,
                                        "algorithmic_bytes_per_launch": nbytes,
-                                       "note": "inside the timed region at this batch (a 25 us kernel: ~2 us of event overhead "
-                                               "and a partly filled chip); BASELINE.json configs[2] (batch 8) is below"}
+                                       "note": "inside the timed region at this batch (a partly filled chip, the 2-D convolutions of "
+                                               "the matching branch running beside it on the second stream); BASELINE.json "
+                                               "configs[2] (batch 8) is below"}
         # the cost-volume kernel at BASELINE.json configs[2] (batch 8, the HBM-roofline configuration),
         # 20 back-to-back launches between two HIP events on the launch stream
         g8 = torch.Generator(device=device).manual_seed(7)
@@ -410,6 +420,28 @@ def main():
         res["hbm_copy_measured_gbs"] = copy_gbs
         res["roofline_cost_volume_b8"]["frac_of_measured_copy"] = res["roofline_cost_volume_b8"]["achieved"] / copy_gbs
         del src, dst
+        # the fused form of the step (volume -> patch -> gate in one launch) at the same batch 8
+        g8 = torch.Generator(device=device).manual_seed(7)
+        a8 = torch.randn(8, 256, H8, W8, generator=g8, device=device)
+        b8 = torch.randn(8, 256, H8, W8, generator=g8, device=device)
+        gl8 = torch.randn(8, 32, H8, W8, generator=g8, device=device)
+        if semstereo_amd.ops.gwc_patch_gate_applies(a8, maxdisp // 8, 32):
+            run = lambda: semstereo_amd.ops.gwc_patch_gate(a8, b8, maxdisp // 8, 32, seg.patch.weight, gl8)     # noqa: E731
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            msf = e0.elapsed_time(e1) / 20
+            res["roofline_cost_volume_fused_b8"] = {
+                "kernel": "gwc_patch_gate_v4<8,true,stream>, batch 8: volume + patch + gate in one launch", "bound": "hbm",
+                "achieved": nb8 / (msf * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": nb8 / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msf, "algorithmic_bytes_per_launch": nb8,
+                "traffic": None, "replaces_ms": None}
+        del a8, b8, gl8
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and EPE: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the
         # same workload: about 10-30 s of CPU work.  ATen's CPU kernels stop scaling (the slice

@@ -61,6 +61,12 @@ int ss_groupwise_correlation_fwd(const float* fea1, const float* fea2, float* ou
 int ss_gwc_volume_fwd(const float* ref, const float* tgt, float* out,
                       int B, int C, int H, int W, int maxdisp, int groups, int normalize,
                       ss_stream_t stream);
+/* models/SemStereo.py:273-276 in one launch: build_gwc_volume[_norm] -> `patch` (depthwise Conv3d, kernel (1,3,3),
+ * padding (0,1,1), no bias; patch_w [G,1,1,3,3]) -> channelAtt gate (sigmoid(gate_logits[b,g,y,x]) broadcast over the
+ * disparities; NULL: no gate).  Bit-identical to ss_gwc_volume_fwd + ss_depthwise_patch_fwd.  Needs W % 4 == 0,
+ * maxdisp % 4 == 0, C / groups in {4, 8}, 16-byte aligned pointers: SS_ERR_UNSUPPORTED otherwise (use the two calls). */
+int ss_gwc_patch_gate_fwd(const float* ref, const float* tgt, const float* patch_w, const float* gate_logits, float* out,
+                          int B, int C, int H, int W, int maxdisp, int groups, int normalize, ss_stream_t stream);
 /* gradients of the UN-normalised volume w.r.t. ref and tgt (both fully written). */
 int ss_gwc_volume_bwd(const float* grad_out, const float* ref, const float* tgt,
                       float* grad_ref, float* grad_tgt,

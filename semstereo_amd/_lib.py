@@ -20,6 +20,7 @@ _I = ctypes.c_int
 _SIGNATURES = {
     "ss_groupwise_correlation_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ss_gwc_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_gwc_patch_gate_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_gwc_volume_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ss_concat_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_concat_volume_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -292,6 +292,206 @@ __global__ void gwc_volume_bwd_kernel(const float* __restrict__ gout, const floa
     }
 }
 
+
+// ---- models/SemStereo.py:273-276 in one kernel: build_gwc_volume_norm -> `patch` (depthwise (1,3,3) Conv3d) ->
+// channelAtt gate -- the volume never reaches HBM un-stenciled (67 MB write + 67 MB read per 1024^2 pair saved).
+//   out[b,g,d,y,x] = sigmoid(gate[b,g,y,x]) * sum_{ky,kx} wp[g,ky,kx] * V[b,g,d,y+ky-1,x+kx-1]       (V = 0 outside the image)
+// A workgroup owns (b, g, FRO = 6 output rows, 128 columns) and computes V on FRC = 8 rows (one halo row each side) exactly
+// as gwc_volume_v4 does (same tile of the normalised right image in LDS, same fmaf order), 8 disparities at a time,
+// into an LDS tile [8 d][8 rows][136]; the two seam columns (x = xt0 - 1, xt0 + 128) are computed by 128 threads from two
+// parked columns of the left image.  The 3x3 stencil and the gate are then applied from LDS in depthwise_patch_v4's own
+// order (rows outside the image skipped, columns outside contribute fmaf(w, 0)), so the result is bit-identical to the
+// two-kernel form.
+constexpr int FRO = 6, FRC = FRO + 2, FVP = XT + 8;
+
+template <int CG>
+__device__ __forceinline__ void l2_normalise4(float4 (&v)[CG]) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        s.x = ss::add_rn(s.x, ss::mul_rn(v[c].x, v[c].x));
+        s.y = ss::add_rn(s.y, ss::mul_rn(v[c].y, v[c].y));
+        s.z = ss::add_rn(s.z, ss::mul_rn(v[c].z, v[c].z));
+        s.w = ss::add_rn(s.w, ss::mul_rn(v[c].w, v[c].w));
+    }
+    s.x = sqrtf(s.x) + kEps; s.y = sqrtf(s.y) + kEps;
+    s.z = sqrtf(s.z) + kEps; s.w = sqrtf(s.w) + kEps;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        v[c].x = v[c].x / s.x; v[c].y = v[c].y / s.y;
+        v[c].z = v[c].z / s.z; v[c].w = v[c].w / s.w;
+    }
+}
+
+template <int CG, bool NORM, bool STREAM>
+__global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __restrict__ ref, const float* __restrict__ tgt,
+                                                             const float* __restrict__ wpatch, const float* __restrict__ gate,
+                                                             float* __restrict__ out, int C, int H, int W, int m, int G) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int LW = XT + 2 * m + 8;                              // right-image tile: image columns xt0 - m - 4 .. xt0 + 128 + m + 3
+    float* tn = lds;                                            // [CG][FRC][LW]
+    float* vt = lds + CG * FRC * LW;                            // [8][FRC][FVP]: index 4 + j <-> image column xt0 + j
+    float* rh = vt + 8 * FRC * FVP;                             // [2][FRC][CG]: the left image at the two seam columns
+    const int tid = threadIdx.x;
+    const int xt0 = blockIdx.x * XT;
+    const int y0 = blockIdx.y * FRO - 1;                        // first COMPUTED row (the halo row above the output rows)
+    const int b = blockIdx.z / G, g = blockIdx.z % G;
+    const size_t plane = (size_t)H * W;
+    const float* refg = ref + ((size_t)b * C + (size_t)g * CG) * plane;
+    const float* tgtg = tgt + ((size_t)b * C + (size_t)g * CG) * plane;
+
+    const int LQ = LW / 4;
+    for (int q = tid; q < FRC * LQ; q += 32 * FRC) {
+        const int row = q / LQ, qi = q - row * LQ;
+        const int col0 = xt0 - m - 4 + qi * 4;
+        const int y = y0 + row;
+        float4 v[CG];
+        if ((unsigned)y < (unsigned)H && col0 >= 0 && col0 < W) {
+            const float* p = tgtg + (size_t)y * W + col0;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) v[c] = *reinterpret_cast<const float4*>(p + c * plane);
+            if (NORM) l2_normalise4<CG>(v);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < CG; ++c) *reinterpret_cast<float4*>(&tn[(c * FRC + row) * LW + qi * 4]) = v[c];
+    }
+    if (tid < 2 * FRC) {                                        // the left image at x = xt0 - 1 and x = xt0 + 128
+        const int side = tid / FRC, row = tid % FRC;
+        const int xx = side ? xt0 + XT : xt0 - 1, y = y0 + row;
+        float v[CG];
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            v[c] = in ? refg[c * plane + (size_t)y * W + xx] : 0.f;
+            s = ss::add_rn(s, ss::mul_rn(v[c], v[c]));
+        }
+        const float den = sqrtf(s) + kEps;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) rh[(side * FRC + row) * CG + c] = (NORM && in) ? v[c] / den : v[c];
+    }
+    const int tx = tid & 31, ty = tid >> 5;
+    const int x0 = xt0 + tx * 4;
+    const int y = y0 + ty;
+    const bool active = ((unsigned)y < (unsigned)H) && (x0 < W);
+    float r[CG][4];
+    {
+        float4 v[CG];
+        if (active) {
+            const float* p = refg + (size_t)y * W + x0;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) v[c] = *reinterpret_cast<const float4*>(p + c * plane);
+            if (NORM) l2_normalise4<CG>(v);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < CG; ++c) { r[c][0] = v[c].x; r[c][1] = v[c].y; r[c][2] = v[c].z; r[c][3] = v[c].w; }
+    }
+    float wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = wpatch[g * 9 + k];
+    __syncthreads();
+
+    const int D = 2 * m;
+    const float den = (float)CG;
+    float* outg = out + ((size_t)(b * G + g) * D) * plane;
+    const float* gateg = gate ? gate + (size_t)(b * G + g) * plane : nullptr;
+    for (int d0 = 0; d0 < D; d0 += 8) {
+        // ---- V for this thread's row and 4 columns, 8 disparities (gwc_volume_v4's arithmetic) ----
+        float acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
+        const int base = tx * 4 + D - d0 - 8 + 4;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const float* lp = &tn[(c * FRC + ty) * LW + base];
+            float w[12];
+            *reinterpret_cast<float4*>(&w[0]) = *reinterpret_cast<const float4*>(lp);
+            *reinterpret_cast<float4*>(&w[4]) = *reinterpret_cast<const float4*>(lp + 4);
+            *reinterpret_cast<float4*>(&w[8]) = *reinterpret_cast<const float4*>(lp + 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(r[c][j], w[j + 8 - i], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int col = x0 - (d0 + i - m);
+            float4 o;
+            o.x = (active && (unsigned)(col + 0) < (unsigned)W) ? acc[i][0] / den : 0.f;
+            o.y = (active && (unsigned)(col + 1) < (unsigned)W) ? acc[i][1] / den : 0.f;
+            o.z = (active && (unsigned)(col + 2) < (unsigned)W) ? acc[i][2] / den : 0.f;
+            o.w = (active && (unsigned)(col + 3) < (unsigned)W) ? acc[i][3] / den : 0.f;
+            *reinterpret_cast<float4*>(&vt[(i * FRC + ty) * FVP + 4 + tx * 4]) = o;
+        }
+        if (tid < 2 * FRC * 8) {                                // the seam columns: (side, row, disparity) per thread
+            const int i = tid & 7, row = (tid >> 3) % FRC, side = tid / (8 * FRC);
+            const int xx = side ? xt0 + XT : xt0 - 1;
+            const int col = xx - (d0 + i - m);
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) a = fmaf(rh[(side * FRC + row) * CG + c], tn[(c * FRC + row) * LW + (col - xt0 + m + 4)], a);
+            const bool ok = (unsigned)xx < (unsigned)W && (unsigned)(y0 + row) < (unsigned)H && (unsigned)col < (unsigned)W;
+            vt[(i * FRC + row) * FVP + (side ? 4 + XT : 3)] = ok ? a / den : 0.f;
+        }
+        __syncthreads();
+        // ---- depthwise 3x3 + gate from LDS: 8 d x 6 rows x 32 quads = 6 quads per thread ----
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int idx = tid + 256 * k;
+            const int lx = idx & 31, rq = idx >> 5;
+            const int rr = rq % FRO, i = rq / FRO;
+            const int yo = y0 + 1 + rr, xo = xt0 + lx * 4;
+            if (yo >= H || xo >= W) continue;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                if ((unsigned)(yo + ky - 1) >= (unsigned)H) continue;            // (as depthwise_patch_v4: the row is skipped)
+                const float* vp = &vt[(i * FRC + rr + ky) * FVP + lx * 4];
+                const float4 L = *reinterpret_cast<const float4*>(vp), M = *reinterpret_cast<const float4*>(vp + 4),
+                             R = *reinterpret_cast<const float4*>(vp + 8);
+                const float x[6] = {L.w, M.x, M.y, M.z, M.w, R.x};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(wv[ky * 3 + kx], x[j + kx], o[j]);
+            }
+            if (gateg) {
+                const float4 gl = *reinterpret_cast<const float4*>(gateg + (size_t)yo * W + xo);
+                o[0] = ss::mul_rn(1.0f / (1.0f + expf(-gl.x)), o[0]);
+                o[1] = ss::mul_rn(1.0f / (1.0f + expf(-gl.y)), o[1]);
+                o[2] = ss::mul_rn(1.0f / (1.0f + expf(-gl.z)), o[2]);
+                o[3] = ss::mul_rn(1.0f / (1.0f + expf(-gl.w)), o[3]);
+            }
+            float* op = outg + (size_t)(d0 + i) * plane + (size_t)yo * W + xo;
+            if (STREAM) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f ov = {o[0], o[1], o[2], o[3]};
+                __builtin_nontemporal_store(ov, reinterpret_cast<v4f*>(op));
+            } else {
+                *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int CG, bool NORM, bool STREAM>
+int launch_gpg(const float* ref, const float* tgt, const float* wpatch, const float* gate, float* out, int B, int C, int H,
+               int W, int m, int G, hipStream_t st) {
+    dim3 grid(ss::ceil_div(W, XT), ss::ceil_div(H, FRO), B * G);
+    const size_t lds = ((size_t)CG * FRC * (XT + 2 * m + 8) + 8 * FRC * FVP + 2 * FRC * CG) * sizeof(float);
+    auto kern = gwc_patch_gate_v4<CG, NORM, STREAM>;
+    if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(32 * FRC), lds, st, ref, tgt, wpatch, gate, out, C, H, W, m, G);
+    return ss::check_launch();
+}
+
 template <int CG, bool NORM, bool STREAM>
 int launch_v4_as(const float* ref, const float* tgt, float* out, int B, int C, int H, int W, int m, int G,
                  hipStream_t st) {
@@ -343,6 +543,36 @@ extern "C" int ss_gwc_volume_fwd(const float* ref, const float* tgt, float* out,
     else
         hipLaunchKernelGGL(gwc_volume_generic<false>, grid, block, bytes(gx, gr), st, ref, tgt, out, C, H, W, m, groups);
     return ss::check_launch();
+}
+
+extern "C" int ss_gwc_patch_gate_fwd(const float* ref, const float* tgt, const float* patch_w, const float* gate_logits,
+                                     float* out, int B, int C, int H, int W, int maxdisp, int groups, int normalize,
+                                     ss_stream_t stream) {
+    SS_REQUIRE(ref && tgt && patch_w && out);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && maxdisp > 0 && groups > 0);
+    SS_REQUIRE(C % groups == 0);
+    SS_REQUIRE((long long)B * groups <= 65535);
+    const int Cg = C / groups, m = maxdisp;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(tgt) | reinterpret_cast<uintptr_t>(out) |
+                           reinterpret_cast<uintptr_t>(gate_logits);
+    const size_t lds = ((size_t)Cg * FRC * (XT + 2 * m + 8) + 8 * FRC * FVP + 2 * FRC * Cg) * sizeof(float);
+    if ((bits & 15) != 0 || W % 4 != 0 || m % 4 != 0 || (Cg != 8 && Cg != 4) || lds > 150 * 1024) return SS_ERR_UNSUPPORTED;
+    hipStream_t st = ss::as_stream(stream);
+    const size_t out_bytes = (size_t)B * groups * 2 * m * H * W * sizeof(float);
+    bool stream_out = out_bytes > ((size_t)192 << 20);           // as ss_gwc_volume_fwd: beyond the infinity cache
+    if (ss::tuning().gwc_stream >= 0) stream_out = ss::tuning().gwc_stream == 1;
+#define SS_GPG(CGV)                                                                                                           \
+    if (Cg == CGV) {                                                                                                          \
+        if (normalize)                                                                                                        \
+            return stream_out ? launch_gpg<CGV, true, true>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, st)   \
+                              : launch_gpg<CGV, true, false>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, st); \
+        return stream_out ? launch_gpg<CGV, false, true>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, st)      \
+                          : launch_gpg<CGV, false, false>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, st);    \
+    }
+    SS_GPG(8)
+    SS_GPG(4)
+#undef SS_GPG
+    return SS_ERR_UNSUPPORTED;
 }
 
 extern "C" int ss_groupwise_correlation_fwd(const float* fea1, const float* fea2, float* out, int B, int C, int H,

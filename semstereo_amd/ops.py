@@ -86,6 +86,30 @@ def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups):
     return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), int(maxdisp), int(num_groups), True)
 
 
+def gwc_patch_gate_applies(fea, maxdisp, num_groups):
+    """Shapes ss_gwc_patch_gate_fwd is built for (otherwise: the volume kernel + the patch kernel)."""
+    B, C, H, W = fea.shape
+    cg = C // num_groups
+    lds = (cg * 8 * (128 + 2 * maxdisp + 8) + 8 * 8 * 136 + 16 * cg) * 4
+    return W % 4 == 0 and maxdisp % 4 == 0 and cg in (4, 8) and lds <= 150 * 1024 and B * num_groups <= 65535
+
+
+def gwc_patch_gate(refimg_fea, targetimg_fea, maxdisp, num_groups, patch_weight, gate_logits=None, normalize=True):
+    """Fused models/SemStereo.py:273-276: build_gwc_volume_norm -> patch (depthwise (1,3,3)) -> channelAtt gate in one
+    kernel; bit-identical to the two-kernel form.  patch_weight [G,1,1,3,3]; gate_logits [B,G,H,W] or None.  Inference only."""
+    _check_pair(refimg_fea, targetimg_fea, num_groups)
+    ref, tgt, w = _c(refimg_fea), _c(targetimg_fea), _c(patch_weight.detach())
+    g = None if gate_logits is None else _c(gate_logits)
+    dev = _lib.require_device(ref, tgt, w, g)
+    B, C, H, W = ref.shape
+    assert w.numel() == num_groups * 9 and (g is None or g.shape == (B, num_groups, H, W))
+    out = torch.empty((B, num_groups, 2 * maxdisp, H, W), dtype=ref.dtype, device=ref.device)
+    with torch.cuda.device(dev):
+        call("ss_gwc_patch_gate_fwd", ptr(ref), ptr(tgt), ptr(w), ptr(g), ptr(out), B, C, H, W, int(maxdisp), int(num_groups),
+             int(normalize))
+    return out
+
+
 def _group_corr(fea1, fea2, groups, normalize):
     _check_pair(fea1, fea2, groups)
     if _needs_grad(fea1, fea2):

@@ -44,6 +44,7 @@ class HotSegment(nn.Module):
     #: `accelerate()` alone, with its forward() untouched.  True: the fused kernels of this file.
     FUSED = os.environ.get("SS_FUSED", "1") != "0"
     STEM_BY_HALVES = os.environ.get("SS_STEM_HALVES", "1") != "0"      # concat_stem's broadcast half by linearity
+    GWC_PATCH_FUSED = os.environ.get("SS_GWC_PATCH_FUSED", "1") != "0"  # gwc volume -> patch -> gate in one kernel
 
     def __init__(self, maxdisp, c8=256, c4=128):
         super().__init__()
@@ -78,10 +79,15 @@ class HotSegment(nn.Module):
         m8, m4 = self.maxdisp // 8, self.maxdisp // 4
         H4, W4 = fl4.shape[-2:]
         fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, fl8, fr8)
-        corr = ops.build_gwc_volume_norm(fl8, fr8, m8, fl8.shape[1] // 8)                      # :273
-        if fast:
+        groups = fl8.shape[1] // 8
+        if fast and HotSegment.GWC_PATCH_FUSED and isinstance(self.patch, M.DepthwisePatch) and ops.gwc_patch_gate_applies(fl8, m8, groups):
+            M.PATH_COUNTS["hip"] += 1
+            cost_att = ops.gwc_patch_gate(fl8, fr8, m8, groups, self.patch.weight, self.corr_feature_att_8.logits(fl8))   # :273-276 fused
+        elif fast:
+            corr = ops.build_gwc_volume_norm(fl8, fr8, m8, groups)                             # :273
             cost_att = self.patch(corr, self.corr_feature_att_8.logits(fl8))                   # :274 + :276 fused
         else:
+            corr = ops.build_gwc_volume_norm(fl8, fr8, m8, groups)                             # :273
             cost_att = self.corr_feature_att_8(self.patch(corr), fl8)
         cost_att = self.classif_att_(self.hourglass_att(cost_att))                             # :277-278
         if fast and ops.upsample_softmax_regression_applies(cost_att, m4, H4, W4):

@@ -1167,3 +1167,39 @@ def test_upsample_softmax_regression_kernel(sa, shape):
     # identical to the two-step form on the GPU
     d2, v2, _ = sa.ops.softmax_regression(up.squeeze(1), m)
     assert float((d2 - disp).abs().max()) <= 1e-6 and float((v2 - var).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [
+    # (B, C, H, W, m, G, gate)
+    (1, 256, 16, 128, 16, 32, True),      # the live split (8 channels per group), one column tile
+    (2, 64, 13, 256, 16, 8, True),        # two column tiles: the seam columns; H not a multiple of the 6-row tile
+    (1, 64, 7, 260, 24, 8, True),         # maxdisp 192's range; a ragged third column tile
+    (1, 32, 5, 64, 8, 8, False),          # narrower than a tile; 4 channels per group; no gate
+    (1, 64, 1, 128, 16, 8, True),         # a single row
+])
+def test_gwc_patch_gate_fused_is_bit_identical_to_the_two_kernels(sa, shape):
+    """models/SemStereo.py:273-276 in one kernel (ss_gwc_patch_gate_fwd) against build_gwc_volume_norm followed by the
+    gated `patch` kernel: same arithmetic in the same order, so the same bits; and against the oracle's composition."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, C, H, W, m, G, with_gate = shape
+    a, b = dd.t_normalish((B, C, H, W), 790), dd.t_normalish((B, C, H, W), 791)
+    wp = dd.t_uniform((G, 1, 1, 3, 3), 792, -1, 1)
+    gate = dd.t_normalish((B, G, H, W), 793) if with_gate else None
+    assert sa.ops.gwc_patch_gate_applies(a, m, G)
+    fused = sa.ops.gwc_patch_gate(dev(a), dev(b), m, G, dev(wp), None if gate is None else dev(gate))
+    patch = sa.modules.DepthwisePatch(G).cuda().eval()
+    with torch.no_grad():
+        patch.weight.copy_(wp)
+        two = patch(sa.ops.build_gwc_volume_norm(dev(a), dev(b), m, G), None if gate is None else dev(gate))
+    assert fused.shape == two.shape == (B, G, 2 * m, H, W)
+    assert torch.equal(fused, two), f"max diff {float((fused - two).abs().max()):.3e}"
+    ref = F.conv3d(oops.build_gwc_volume_norm(a, b, m, G), wp, None, 1, (0, 1, 1), 1, G)
+    if gate is not None:
+        ref = torch.sigmoid(gate).unsqueeze(2) * ref
+    check(f"gwc_patch_gate/{shape}", fused, ref, 3e-6)
+    # un-normalised form
+    f2 = sa.ops.gwc_patch_gate(dev(a), dev(b), m, G, dev(wp), None, normalize=False)
+    with torch.no_grad():
+        t2 = patch(sa.ops.build_gwc_volume(dev(a), dev(b), m, G))
+    assert torch.equal(f2, t2)
