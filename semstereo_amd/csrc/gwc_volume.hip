@@ -332,6 +332,7 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
     float* tn = lds;                                            // [CG][FRC][LW]
     float* vt = lds + CG * FRC * LW;                            // [8][FRC][FVP]: index 4 + j <-> image column xt0 + j
     float* rh = vt + 8 * FRC * FVP;                             // [2][FRC][CG]: the left image at the two seam columns
+    float* sgt = rh + 2 * FRC * CG;                             // [FRO][XT]: sigmoid of the gate logits of the output pixels
     const int tid = threadIdx.x;
     const int xt0 = blockIdx.x * XT;
     const int y0 = blockIdx.y * FRO - 1;                        // first COMPUTED row (the halo row above the output rows)
@@ -359,19 +360,22 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
         for (int c = 0; c < CG; ++c) *reinterpret_cast<float4*>(&tn[(c * FRC + row) * LW + qi * 4]) = v[c];
     }
     if (tid < 2 * FRC) {                                        // the left image at x = xt0 - 1 and x = xt0 + 128
+        // (normalised as the aligned quad that holds the column, through the same code as every other pixel: a scalar
+        // restatement of the normalisation compiled to a result one ulp away)
         const int side = tid / FRC, row = tid % FRC;
-        const int xx = side ? xt0 + XT : xt0 - 1, y = y0 + row;
-        float v[CG];
-        const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-        float s = 0.f;
+        const int xq = side ? xt0 + XT : xt0 - 4, y = y0 + row;
+        float4 v[CG];
+        if ((unsigned)y < (unsigned)H && xq >= 0 && xq < W) {
+            const float* p = refg + (size_t)y * W + xq;
 #pragma unroll
-        for (int c = 0; c < CG; ++c) {
-            v[c] = in ? refg[c * plane + (size_t)y * W + xx] : 0.f;
-            s = ss::add_rn(s, ss::mul_rn(v[c], v[c]));
+            for (int c = 0; c < CG; ++c) v[c] = *reinterpret_cast<const float4*>(p + c * plane);
+            if (NORM) l2_normalise4<CG>(v);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const float den = sqrtf(s) + kEps;
 #pragma unroll
-        for (int c = 0; c < CG; ++c) rh[(side * FRC + row) * CG + c] = (NORM && in) ? v[c] / den : v[c];
+        for (int c = 0; c < CG; ++c) rh[(side * FRC + row) * CG + c] = side ? v[c].x : v[c].w;
     }
     const int tx = tid & 31, ty = tid >> 5;
     const int x0 = xt0 + tx * 4;
@@ -401,6 +405,17 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
     const float den = (float)CG;
     float* outg = out + ((size_t)(b * G + g) * D) * plane;
     const float* gateg = gate ? gate + (size_t)(b * G + g) * plane : nullptr;
+    // the gate of the tile's 6 x 128 output pixels: ONE sigmoid per pixel (not one per output), parked in LDS
+    if (gateg && ty < FRO) {
+        const int yo = y0 + 1 + ty;
+        float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yo < H && x0 < W) {
+            const float4 gl = *reinterpret_cast<const float4*>(gateg + (size_t)yo * W + x0);
+            sg = make_float4(1.0f / (1.0f + expf(-gl.x)), 1.0f / (1.0f + expf(-gl.y)), 1.0f / (1.0f + expf(-gl.z)),
+                             1.0f / (1.0f + expf(-gl.w)));
+        }
+        *reinterpret_cast<float4*>(&sgt[ty * XT + tx * 4]) = sg;
+    }
     for (int d0 = 0; d0 < D; d0 += 8) {
         // ---- V for this thread's row and 4 columns, 8 disparities (gwc_volume_v4's arithmetic) ----
         float acc[8][4];
@@ -440,41 +455,44 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
             vt[(i * FRC + row) * FVP + (side ? 4 + XT : 3)] = ok ? a / den : 0.f;
         }
         __syncthreads();
-        // ---- depthwise 3x3 + gate from LDS: 8 d x 6 rows x 32 quads = 6 quads per thread ----
+        // ---- depthwise 3x3 + gate from LDS: thread (ty, tx) owns disparity d0 + ty, 4 columns, ALL 6 output rows: the 8
+        // computed rows slide through registers (one 16-byte + two 4-byte LDS reads per row instead of nine 16-byte reads
+        // per output quad: this phase was bound by LDS bandwidth) ----
+        if (x0 < W) {
+            float win[3][6];                                    // rows yo - 1, yo, yo + 1 of the current output row
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int idx = tid + 256 * k;
-            const int lx = idx & 31, rq = idx >> 5;
-            const int rr = rq % FRO, i = rq / FRO;
-            const int yo = y0 + 1 + rr, xo = xt0 + lx * 4;
-            if (yo >= H || xo >= W) continue;
-            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int rr = 0; rr < FRC; ++rr) {
+                const float* vp = &vt[(ty * FRC + rr) * FVP + 4 + tx * 4];
+                const float4 M = *reinterpret_cast<const float4*>(vp);
+                const float l = vp[-1], rgt = vp[4];
+                const int slot = rr % 3;
+                win[slot][0] = l; win[slot][1] = M.x; win[slot][2] = M.y; win[slot][3] = M.z; win[slot][4] = M.w; win[slot][5] = rgt;
+                if (rr < 2) continue;
+                const int orow = rr - 2, yo = y0 + 1 + orow;      // output row whose window is complete
+                if (yo >= H) continue;
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                if ((unsigned)(yo + ky - 1) >= (unsigned)H) continue;            // (as depthwise_patch_v4: the row is skipped)
-                const float* vp = &vt[(i * FRC + rr + ky) * FVP + lx * 4];
-                const float4 L = *reinterpret_cast<const float4*>(vp), M = *reinterpret_cast<const float4*>(vp + 4),
-                             R = *reinterpret_cast<const float4*>(vp + 8);
-                const float x[6] = {L.w, M.x, M.y, M.z, M.w, R.x};
+                for (int ky = 0; ky < 3; ++ky) {
+                    if ((unsigned)(yo + ky - 1) >= (unsigned)H) continue;        // (as depthwise_patch_v4: the row is skipped)
+                    const float* x = win[(orow + ky) % 3];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = fmaf(wv[ky * 3 + kx], x[j + kx], o[j]);
-            }
-            if (gateg) {
-                const float4 gl = *reinterpret_cast<const float4*>(gateg + (size_t)yo * W + xo);
-                o[0] = ss::mul_rn(1.0f / (1.0f + expf(-gl.x)), o[0]);
-                o[1] = ss::mul_rn(1.0f / (1.0f + expf(-gl.y)), o[1]);
-                o[2] = ss::mul_rn(1.0f / (1.0f + expf(-gl.z)), o[2]);
-                o[3] = ss::mul_rn(1.0f / (1.0f + expf(-gl.w)), o[3]);
-            }
-            float* op = outg + (size_t)(d0 + i) * plane + (size_t)yo * W + xo;
-            if (STREAM) {
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                v4f ov = {o[0], o[1], o[2], o[3]};
-                __builtin_nontemporal_store(ov, reinterpret_cast<v4f*>(op));
-            } else {
-                *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                        for (int j = 0; j < 4; ++j) o[j] = fmaf(wv[ky * 3 + kx], x[j + kx], o[j]);
+                }
+                if (gateg) {
+                    const float4 sg = *reinterpret_cast<const float4*>(&sgt[orow * XT + tx * 4]);
+                    o[0] = ss::mul_rn(sg.x, o[0]); o[1] = ss::mul_rn(sg.y, o[1]);
+                    o[2] = ss::mul_rn(sg.z, o[2]); o[3] = ss::mul_rn(sg.w, o[3]);
+                }
+                float* op = outg + (size_t)(d0 + ty) * plane + (size_t)yo * W + x0;
+                if (STREAM) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f ov = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(ov, reinterpret_cast<v4f*>(op));
+                } else {
+                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
         }
         __syncthreads();
@@ -485,7 +503,7 @@ template <int CG, bool NORM, bool STREAM>
 int launch_gpg(const float* ref, const float* tgt, const float* wpatch, const float* gate, float* out, int B, int C, int H,
                int W, int m, int G, hipStream_t st) {
     dim3 grid(ss::ceil_div(W, XT), ss::ceil_div(H, FRO), B * G);
-    const size_t lds = ((size_t)CG * FRC * (XT + 2 * m + 8) + 8 * FRC * FVP + 2 * FRC * CG) * sizeof(float);
+    const size_t lds = ((size_t)CG * FRC * (XT + 2 * m + 8) + 8 * FRC * FVP + 2 * FRC * CG + FRO * XT) * sizeof(float);
     auto kern = gwc_patch_gate_v4<CG, NORM, STREAM>;
     if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(32 * FRC), lds, st, ref, tgt, wpatch, gate, out, C, H, W, m, G);
@@ -555,7 +573,7 @@ extern "C" int ss_gwc_patch_gate_fwd(const float* ref, const float* tgt, const f
     const int Cg = C / groups, m = maxdisp;
     const uintptr_t bits = reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(tgt) | reinterpret_cast<uintptr_t>(out) |
                            reinterpret_cast<uintptr_t>(gate_logits);
-    const size_t lds = ((size_t)Cg * FRC * (XT + 2 * m + 8) + 8 * FRC * FVP + 2 * FRC * Cg) * sizeof(float);
+    const size_t lds = ((size_t)Cg * FRC * (XT + 2 * m + 8) + 8 * FRC * FVP + 2 * FRC * Cg + FRO * XT) * sizeof(float);
     if ((bits & 15) != 0 || W % 4 != 0 || m % 4 != 0 || (Cg != 8 && Cg != 4) || lds > 150 * 1024) return SS_ERR_UNSUPPORTED;
     hipStream_t st = ss::as_stream(stream);
     const size_t out_bytes = (size_t)B * groups * 2 * m * H * W * sizeof(float);

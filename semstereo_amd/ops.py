@@ -90,7 +90,7 @@ def gwc_patch_gate_applies(fea, maxdisp, num_groups):
     """Shapes ss_gwc_patch_gate_fwd is built for (otherwise: the volume kernel + the patch kernel)."""
     B, C, H, W = fea.shape
     cg = C // num_groups
-    lds = (cg * 8 * (128 + 2 * maxdisp + 8) + 8 * 8 * 136 + 16 * cg) * 4
+    lds = (cg * 8 * (128 + 2 * maxdisp + 8) + 8 * 8 * 136 + 16 * cg + 6 * 128) * 4
     return W % 4 == 0 and maxdisp % 4 == 0 and cg in (4, 8) and lds <= 150 * 1024 and B * num_groups <= 65535
 
 
