@@ -89,6 +89,13 @@ int ss_concat_volume_bwd(const float* grad_out, float* grad_ref, float* grad_tgt
 int ss_warp_sampled_fwd(const float* x, const float* y, const float* disp,
                         float* y_warped, float* x_warped,
                         int B, int C, int H, int W, int nd, ss_stream_t stream);
+/* its backward (autograd of the reference's meshgrid -> normalise -> F.grid_sample composition): grad_y_warped,
+ * grad_x_warped [B,C,nd,H,W] (either may be NULL) -> grad_x = sum over the candidates of grad_x_warped, grad_y (scatter of
+ * the bilinear weights; zeroed here, accumulated with fp32 atomics), grad_disp [B,nd,H,W] (the live use at
+ * models/SemStereo.py:291, where the candidates derive from pred_att).  Outputs may be NULL when not needed. */
+int ss_warp_sampled_bwd(const float* grad_y_warped, const float* grad_x_warped, const float* y, const float* disp,
+                        float* grad_x, float* grad_y, float* grad_disp, int B, int C, int H, int W, int nd,
+                        ss_stream_t stream);
 /* Fused form of SemStereo.concat_volume_generator + `att_topk * volume`
  * (models/SemStereo.py:241-244, 318): out[b,0:C,j] = att[b,j] * left[b,:],
  * out[b,C:2C,j] = att[b,j] * warp(right)[b,:,j].  att [B,nd,H,W] may be NULL (no gating).
@@ -157,6 +164,10 @@ int ss_topk_candidates_fwd(const float* logits, const float* strength, float* sa
  * the matching candidates.  cost, samples [B,nd,H,W] -> [B,1,H,W].  1 <= k <= min(nd, 32). */
 int ss_regression_topk_fwd(const float* cost, const float* samples, float* out,
                            int B, int nd, int H, int W, int k, ss_stream_t stream);
+/* its backward: grad_out [B,1,H,W] -> grad_cost, grad_samples [B,nd,H,W] (fully written; zero outside the k selected
+ * candidates; no gradient through the selection itself, as autograd of the reference's sort/gather composition gives). */
+int ss_regression_topk_bwd(const float* grad_out, const float* cost, const float* samples, float* grad_cost,
+                           float* grad_samples, int B, int nd, int H, int W, int k, ss_stream_t stream);
 
 /* SSR_upsample.forward(depth_low, weights, pred_label)   models/submodule.py:412-431 (calls: SemStereo.py:311, 324)
  * 4x bilinear up-sampling of the 1/4-scale disparity + class-probability-gated residual, one kernel.

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "ss_concat_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_concat_volume_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_warp_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_warp_sampled_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_concat_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_stem_left_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_stem_left_fused_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -35,6 +36,7 @@ _SIGNATURES = {
     "ss_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_upsample_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_regression_topk_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_regression_topk_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_sample_strength_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_topk_candidates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_channel_gate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -183,6 +183,45 @@ __global__ __launch_bounds__(256) void topk_regress_kernel(const float* __restri
     }
 }
 
+// backward of regression_topk (models/submodule.py:434-442): with pool = the k selected candidates, p = softmax(cost[pool]),
+// y = sum_j p_j s_j:   dL/dcost[pool_j] = g * p_j * (s_j - y),   dL/dsamples[pool_j] = g * p_j,   0 for the others
+// (the sort is piecewise constant: no gradient through the selection, as in autograd of the reference's composition).
+__global__ __launch_bounds__(256) void topk_regress_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ cost,
+                                                                const float* __restrict__ samples, float* __restrict__ gcost,
+                                                                float* __restrict__ gsamples, int nd, int k, long long plane,
+                                                                long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long pix = i % plane, b = i / plane;
+    const float* cp = cost + b * nd * plane + pix;
+    const float* sp = samples + b * nd * plane + pix;
+    float* gc = gcost + b * nd * plane + pix;
+    float* gs = gsamples + b * nd * plane + pix;
+    for (int j = 0; j < nd; ++j) { gc[j * plane] = 0.f; gs[j * plane] = 0.f; }
+    const float g = gout[i];
+    float pv = INFINITY; int pi = -1; float top = 0.f, sum = 0.f;
+    for (int s = 0; s < k; ++s) {
+        float bv; int bi; select_next(cp, nd, plane, pv, pi, bv, bi);
+        if (s == 0) top = bv;
+        sum = ss::add_rn(sum, expf(bv - top));
+        pv = bv; pi = bi;
+    }
+    pv = INFINITY; pi = -1; float y = 0.f;
+    for (int s = 0; s < k; ++s) {
+        float bv; int bi; select_next(cp, nd, plane, pv, pi, bv, bi);
+        y = ss::add_rn(y, ss::mul_rn(sp[bi * plane], expf(bv - top) / sum));
+        pv = bv; pi = bi;
+    }
+    pv = INFINITY; pi = -1;
+    for (int s = 0; s < k; ++s) {
+        float bv; int bi; select_next(cp, nd, plane, pv, pi, bv, bi);
+        const float p = expf(bv - top) / sum;
+        gs[bi * plane] = g * p;
+        gc[bi * plane] = g * p * (sp[bi * plane] - y);
+        pv = bv; pi = bi;
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ att, const float* __restrict__ cv,
                                                     float* __restrict__ out, int D, long long plane, long long nvec) {
@@ -285,6 +324,17 @@ extern "C" int ss_regression_topk_fwd(const float* cost, const float* samples, f
         case 4: hipLaunchKernelGGL(topk_regress_kernel<4>, grid, block, 0, st, cost, samples, out, nd, k, plane, total); break;
         default: hipLaunchKernelGGL(topk_regress_kernel<0>, grid, block, 0, st, cost, samples, out, nd, k, plane, total); break;
     }
+    return ss::check_launch();
+}
+
+extern "C" int ss_regression_topk_bwd(const float* grad_out, const float* cost, const float* samples, float* grad_cost,
+                                      float* grad_samples, int B, int nd, int H, int W, int k, ss_stream_t stream) {
+    SS_REQUIRE(grad_out && cost && samples && grad_cost && grad_samples);
+    SS_REQUIRE(B > 0 && nd > 0 && H > 0 && W > 0);
+    SS_REQUIRE(k >= 1 && k <= nd && k <= 32);
+    const long long plane = (long long)H * W, total = (long long)B * plane;
+    hipLaunchKernelGGL(topk_regress_bwd_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0, ss::as_stream(stream),
+                       grad_out, cost, samples, grad_cost, grad_samples, nd, k, plane, total);
     return ss::check_launch();
 }
 

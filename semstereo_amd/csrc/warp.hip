@@ -238,6 +238,61 @@ __global__ __launch_bounds__(256) void warp_right_gated(const float* __restrict_
     }
 }
 
+// ---- backward of SpatialTransformer_grid (autograd of the reference's meshgrid -> normalise -> F.grid_sample composition,
+// models/submodule.py:265-288): one thread per (b, j, h, w), loop over the channels.
+//   grad_y[b,c,tap] += w_tap * g[b,c,j,h,w]                         (scatter through hardware fp32 atomics)
+//   grad_disp[b,j,h,w] = -(half_w * sum_c gix_c) / half_w           gix as ATen's grid_sampler backward accumulates it
+// (the row coordinate does not depend on the disparity).  grad_x = sum_j grad_x_warped is the second kernel.
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ gyw, const float* __restrict__ y,
+                                                        const float* __restrict__ disp, float* __restrict__ gy,
+                                                        float* __restrict__ gdisp, int C, int H, int W, int nd, float half_w,
+                                                        float half_h, long long total) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int w = (int)(idx % W);
+    long long t = idx / W;
+    const int h = (int)(t % H); t /= H;
+    const int j = (int)(t % nd);
+    const long long b = t / nd;
+    const long long plane = (long long)H * W;
+    const long long pix = (long long)h * W + w;
+    const float dv = disp[(b * nd + j) * plane + pix];
+    const Taps tp = make_taps(dv, h, w, H, W, half_w, half_h);
+    // fs = iy_se - iy, fn = iy - iy_nw (make_taps' names: w_nw = fs * fe ...): recover the row fractions
+    const float gyc = (float)h / half_h - 1.0f;
+    const float iy = ss::mul_rn(gyc + 1.0f, half_h);
+    const float fn = iy - floorf(iy), fs = 1.0f - fn;
+    float gix = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float g = gyw[((b * C + c) * nd + j) * plane + pix];
+        const float* yp = y + (b * C + c) * plane;
+        float* gp = gy + (b * C + c) * plane;
+        const float a = tp.o_nw >= 0 ? yp[tp.o_nw] : 0.f, bq = tp.o_ne >= 0 ? yp[tp.o_ne] : 0.f;
+        const float cq = tp.o_sw >= 0 ? yp[tp.o_sw] : 0.f, d = tp.o_se >= 0 ? yp[tp.o_se] : 0.f;
+        if (gy != nullptr) {
+            if (tp.o_nw >= 0) unsafeAtomicAdd(gp + tp.o_nw, tp.w_nw * g);
+            if (tp.o_ne >= 0) unsafeAtomicAdd(gp + tp.o_ne, tp.w_ne * g);
+            if (tp.o_sw >= 0) unsafeAtomicAdd(gp + tp.o_sw, tp.w_sw * g);
+            if (tp.o_se >= 0) unsafeAtomicAdd(gp + tp.o_se, tp.w_se * g);
+        }
+        gix -= a * fs * g;
+        gix += bq * fs * g;
+        gix -= cq * fn * g;
+        gix += d * fn * g;
+    }
+    if (gdisp != nullptr) gdisp[(b * nd + j) * plane + pix] = -((half_w * gix) / half_w);
+}
+
+__global__ __launch_bounds__(256) void sum_over_candidates_kernel(const float* __restrict__ gxw, float* __restrict__ gx, int nd,
+                                                                   long long plane, long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;     // over B*C*H*W
+    if (i >= total) return;
+    const long long bc = i / plane, pix = i % plane;
+    float s = 0.f;
+    for (int j = 0; j < nd; ++j) s += gxw[(bc * nd + j) * plane + pix];
+    gx[i] = s;
+}
+
 template <int MODE>
 int launch(const float* x, const float* y, const float* disp, const float* gate, float* out0, float* out1, int B,
            int C, int H, int W, int nd, hipStream_t st) {
@@ -280,6 +335,29 @@ extern "C" int ss_warp_sampled_fwd(const float* x, const float* y, const float* 
     SS_REQUIRE(x && y && disp && y_warped);
     SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nd > 0);
     return launch<MODE_WARP>(x, y, disp, nullptr, y_warped, x_warped, B, C, H, W, nd, ss::as_stream(stream));
+}
+
+extern "C" int ss_warp_sampled_bwd(const float* grad_y_warped, const float* grad_x_warped, const float* y, const float* disp,
+                                   float* grad_x, float* grad_y, float* grad_disp, int B, int C, int H, int W, int nd,
+                                   ss_stream_t stream) {
+    SS_REQUIRE(y && disp);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nd > 0);
+    hipStream_t st = ss::as_stream(stream);
+    const long long plane = (long long)H * W;
+    if (grad_y_warped != nullptr && (grad_y != nullptr || grad_disp != nullptr)) {
+        if (grad_y != nullptr && hipMemsetAsync(grad_y, 0, (size_t)B * C * plane * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+        const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
+        const long long total = (long long)B * nd * plane, blocks = ss::ceil_div_ll(total, 256);
+        if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y_warped, y, disp, grad_y, grad_disp, C, H,
+                           W, nd, half_w, half_h, total);
+    }
+    if (grad_x_warped != nullptr && grad_x != nullptr) {
+        const long long total = (long long)B * C * plane, blocks = ss::ceil_div_ll(total, 256);
+        if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(sum_over_candidates_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_x_warped, grad_x, nd, plane, total);
+    }
+    return ss::check_launch();
 }
 
 extern "C" int ss_concat_sampled_fwd(const float* left, const float* right, const float* disp, const float* att,

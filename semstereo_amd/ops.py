@@ -297,11 +297,11 @@ class _RegressionTopk(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         cost, samples = ctx.saved_tensors
-        with torch.enable_grad():
-            c = cost.detach().requires_grad_(True)
-            s = samples.detach().requires_grad_(True)
-            y = _topk_reference_math(c, s, ctx.k)
-            gc, gs = torch.autograd.grad(y, (c, s), g)
+        g = _c(g)
+        B, nd, H, W = cost.shape
+        gc, gs = torch.empty_like(cost), torch.empty_like(samples)
+        with torch.cuda.device(cost.device):
+            call("ss_regression_topk_bwd", ptr(g), ptr(cost), ptr(samples), ptr(gc), ptr(gs), B, nd, H, W, ctx.k)
         return gc, gs, None
 
 
@@ -351,12 +351,17 @@ class _WarpSampled(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gyw, gxw):
         x, y, disp = ctx.saved_tensors
-        with torch.enable_grad():
-            yy = y.detach().requires_grad_(True)
-            dd = disp.detach().requires_grad_(True)
-            out = _warp_reference_math(x, yy, dd)
-            gy, gd = torch.autograd.grad(out, (yy, dd), gyw)
-        return gxw.sum(dim=2), gy, gd
+        B, C, H, W = y.shape
+        nd = disp.shape[1]
+        need_x, need_y, need_d = ctx.needs_input_grad
+        gyw = _c(gyw) if (need_y or need_d) else None
+        gxw = _c(gxw) if need_x else None
+        gx = torch.empty_like(x) if need_x else None
+        gy = torch.empty_like(y) if need_y else None
+        gd = torch.empty_like(disp) if need_d else None
+        with torch.cuda.device(y.device):
+            call("ss_warp_sampled_bwd", ptr(gyw), ptr(gxw), ptr(y), ptr(disp), ptr(gx), ptr(gy), ptr(gd), B, C, H, W, nd)
+        return gx, gy, gd
 
 
 def SpatialTransformer_grid(x, y, disp_range_samples):
