@@ -291,6 +291,15 @@ int ss_pack_deconv3d_weights_f16s(const float* wpack, void* wsplit, int Cin, int
  * ConvTranspose3d weight [Cin,Cout,k,k,k] (transposed != 0) -> [Cin][k^3][Cout]. */
 int ss_pack_conv3d_weights(const float* w, float* wpack, int Cout, int Cin, int k, int transposed,
                            ss_stream_t stream);
+/* Weight gradient of Conv3d(k3, padding 1, stride 1 | 2, bias=False) -- the training path, main_us3d.py:186-222:
+ *   grad_w[co,ci,kd,kh,kw] = sum_{b,od,oh,ow} grad_out[b,co,od,oh,ow] * in[b,ci,od*s+kd-1,oh*s+kh-1,ow*s+kw-1]
+ * grad_out [B,Cout,Do,Ho,Wo], in [B,Cin,D,H,W] -> grad_w [Cout,Cin,3,3,3] (zeroed here, accumulated with fp32 atomics).
+ * Also the weight gradient of ConvTranspose3d(k3,s2,p1,op1): call it with grad_out := the layer's input, in := the
+ * gradient of its output, stride 2; the result is in that weight's [Cin,Cout,3,3,3] layout.  (The data gradients are the
+ * forward entry points: ss_conv3d_bf16s_fwd on flipped weights / ss_deconv3d_fwd / the stride-2 convolution.) */
+int ss_conv3d_wgrad_fwd(const float* grad_out, const float* in, float* grad_w, int B, int Cin, int D, int H, int W,
+                        int Cout, int stride, ss_stream_t stream);
+
 /* `patch` (models/SemStereo.py:219, 274): depthwise Conv3d kernel (1,3,3), pad (0,1,1), no bias,
  * optionally fused with the channelAtt gate that follows it (:276):
  *   out[b,c,d] = sigmoid?(gate[b,c]) * conv2d_3x3(in[b,c,d], w[c])       w [C,1,1,3,3], gate [B,C,H,W] or NULL */

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "ss_deconv3d_bf16s_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_deconv3d_weights_bf16s": [_P, _P, _I, _I, _I, _P],
     "ss_pack_conv3d_weights": [_P, _P, _I, _I, _I, _I, _P],
+    "ss_conv3d_wgrad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_depthwise_patch_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

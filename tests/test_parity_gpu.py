@@ -1233,3 +1233,103 @@ def test_backward_warp_and_topk_in_hip(sa):
         go = _grads(lambda p, q: oops.regression_topk(p, q, k), [c, s], lambda yy: seed)
         check(f"bwd/topk/{name}/cost", gh[0], go[0], 2e-6, 1e-6)
         check(f"bwd/topk/{name}/samples", gh[1], go[1], 2e-6, 1e-6)
+
+
+CONV_TRAIN_CASES = [
+    # (B, Cin, Cout, D, H, W, stride)
+    (2, 32, 32, 4, 10, 36, 1),
+    (1, 32, 64, 6, 8, 34, 2),           # stride 2 (even sizes: its data gradient is the k3-s2-p1-op1 transposed conv)
+    (1, 64, 32, 3, 7, 33, 1),           # W odd, ragged tile
+    (1, 40, 48, 2, 6, 20, 1),           # channels not multiples of 32
+    (1, 64, 128, 4, 6, 16, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_TRAIN_CASES)
+def test_conv3d_training_forward_dgrad_wgrad_in_hip(sa, case):
+    """VERDICT r1 missing #2: Conv3d(k3,p1) through the HIP autograd function -- forward, data gradient (the same engine on
+    flipped weights / the transposed-conv kernels) and weight gradient (conv3d_wgrad.hip) -- against autograd of
+    F.conv3d in float64."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, Cin, Cout, D, H, W, stride = case
+    x = dd.t_normalish((B, Cin, D, H, W), 830)
+    w = dd.t_uniform((Cout, Cin, 3, 3, 3), 831, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    conv = torch.nn.Conv3d(Cin, Cout, 3, stride, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, None, stride, 1)
+    seed = dd.t_normalish(tuple(y64.shape), 832)
+    y64.backward(seed.double())
+    conv = conv.cuda()
+    xg = dev(x).requires_grad_(True)
+    before = sa.modules.PATH_COUNTS.get("hip_train", 0)
+    y = sa.modules.conv3d_train(conv, xg)
+    assert sa.modules.PATH_COUNTS.get("hip_train", 0) == before + 1, "the stock PyTorch layer ran"
+    y.backward(dev(seed))
+    scale = lambda t: float(t.abs().max())                                 # noqa: E731
+    e_y = float((y.detach().double().cpu() - y64.detach()).abs().max()) / scale(y64)
+    e_x = float((xg.grad.double().cpu() - x64.grad).abs().max()) / scale(x64.grad)
+    e_w = float((conv.weight.grad.double().cpu() - w64.grad).abs().max()) / scale(w64.grad)
+    REPORT[f"conv3d_train/{case}"] = (e_y, e_x, e_w)
+    assert e_y <= 2e-6 and e_x <= 2e-6 and e_w <= 5e-6, (e_y, e_x, e_w)
+
+
+@pytest.mark.parametrize("case", [(1, 64, 32, 3, 6, 18), (2, 128, 64, 2, 4, 8), (1, 48, 40, 2, 5, 33)])
+def test_deconv3d_training_forward_dgrad_wgrad_in_hip(sa, case):
+    """ConvTranspose3d(k3,s2,p1,op1) of the hourglasses (models/SemStereo.py:124-130) through the HIP autograd function."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, Cin, Cout, D, H, W = case
+    x = dd.t_normalish((B, Cin, D, H, W), 840)
+    w = dd.t_uniform((Cin, Cout, 3, 3, 3), 841, -1, 1) * (3.0 / (Cin * 27 / 8)) ** 0.5
+    dc = torch.nn.ConvTranspose3d(Cin, Cout, 3, padding=1, output_padding=1, stride=2, bias=False)
+    with torch.no_grad():
+        dc.weight.copy_(w)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv_transpose3d(x64, w64, None, stride=2, padding=1, output_padding=1)
+    seed = dd.t_normalish(tuple(y64.shape), 842)
+    y64.backward(seed.double())
+    dc = dc.cuda()
+    xg = dev(x).requires_grad_(True)
+    before = sa.modules.PATH_COUNTS.get("hip_train", 0)
+    y = sa.modules.deconv3d_train(dc, xg)
+    assert sa.modules.PATH_COUNTS.get("hip_train", 0) == before + 1
+    y.backward(dev(seed))
+    scale = lambda t: float(t.abs().max())                                 # noqa: E731
+    e_y = float((y.detach().double().cpu() - y64.detach()).abs().max()) / scale(y64)
+    e_x = float((xg.grad.double().cpu() - x64.grad).abs().max()) / scale(x64.grad)
+    e_w = float((dc.weight.grad.double().cpu() - w64.grad).abs().max()) / scale(w64.grad)
+    REPORT[f"deconv3d_train/{case}"] = (e_y, e_x, e_w)
+    assert e_y <= 2e-6 and e_x <= 2e-6 and e_w <= 5e-6, (e_y, e_x, e_w)
+
+
+def test_hot_segment_training_step_runs_on_the_hip_stack(sa):
+    """A training-mode pass of the hot segment (BatchNorm with batch statistics, autograd on: main_us3d.py:186-222): every
+    3x3x3 convolution and transposed convolution runs the HIP autograd functions, every parameter receives a finite
+    gradient, and the gradients agree with the same pass on the stock PyTorch layers (SS_TRAIN_HIP=0)."""
+    name = "s128"
+    fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
+    grads = {}
+    for hip in (True, False):
+        seg, P = _segment(sa, maxdisp)
+        seg.train()
+        sa.modules.TRAIN_HIP = hip
+        try:
+            before = sa.modules.PATH_COUNTS.get("hip_train", 0)
+            r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
+            n = sa.modules.PATH_COUNTS.get("hip_train", 0) - before
+            assert (n >= 20) if hip else (n == 0), n       # 2 x (4 convs + 2 deconvs) + stem + 2 classifier convs = 15 ... plus 2-D none
+            (r["pred"].mean() + r["pred_att"].mean()).backward()
+        finally:
+            sa.modules.TRAIN_HIP = True
+        grads[hip] = {k: v.grad.detach().clone() for k, v in seg.named_parameters() if v.grad is not None}
+    assert set(grads[True]) == set(grads[False]) and len(grads[True]) > 60
+    worst = 0.0
+    for k, g in grads[True].items():
+        assert bool(torch.isfinite(g).all()), k
+        ref = grads[False][k]
+        worst = max(worst, float((g - ref).abs().max()) / (float(ref.abs().max()) + 1e-12))
+    REPORT["segment_train/worst_relative_grad_diff"] = worst
+    assert worst <= 5e-3, worst           # top-k picks and batch statistics amplify fp32 rounding; typical 1e-5
