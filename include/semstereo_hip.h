@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (6): bumped on any signature change or new entry point the Python binding requires. */
+/* ABI version (7): bumped on any signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
  * measurement aids) are read from the environment ONCE per process; call this after changing
@@ -45,6 +45,11 @@ const char* ss_status_string(int status);
 /* hipGetErrorString of the last SS_ERR_LAUNCH on this thread ("" if none). */
 const char* ss_last_hip_error(void);
 
+/* ---- disparity ranges -------------------------------------------------------------------
+ * Every volume / regression entry point takes (dmin, ndisp): plane p of a volume holds disparity dmin + p.
+ *   signed op set    models/submodule.py   (models/SemStereo.py):      dmin = -maxdisp, ndisp = 2 * maxdisp
+ *   unsigned op set  models/submodule_.py  (what models/SemStereo_WHU.py:279,305 is written for): dmin = 0, ndisp = maxdisp */
+
 /* ---- group-wise correlation ----------------------------------------------------------
  * groupwise_correlation(fea1, fea2, num_groups)       models/submodule.py:190-196
  * groupwise_correlation_norm(...)                     models/submodule.py:213-221
@@ -54,32 +59,33 @@ int ss_groupwise_correlation_fwd(const float* fea1, const float* fea2, float* ou
                                  int B, int C, int H, int W, int groups, int normalize,
                                  ss_stream_t stream);
 
-/* build_gwc_volume(ref, tgt, maxdisp, num_groups)      models/submodule.py:198-211
- * build_gwc_volume_norm(...)                           models/submodule.py:224-238 (live: SemStereo.py:273)
- * out[b,g,d,y,x] = corr(ref[...,x], tgt[...,x-(d-maxdisp)]) for d in [0, 2*maxdisp), 0 where
- * the partner column leaves the image.  [B,C,H,W]^2 -> [B,G,2*maxdisp,H,W] */
+/* build_gwc_volume(ref, tgt, maxdisp, num_groups)      models/submodule.py:198-211   (unsigned: models/submodule_.py:188-198)
+ * build_gwc_volume_norm(...)                           models/submodule.py:224-238 (live: SemStereo.py:273; unsigned :211-221)
+ * out[b,g,p,y,x] = corr(ref[...,x], tgt[...,x-(dmin+p)]) for p in [0, ndisp), 0 where
+ * the partner column leaves the image.  [B,C,H,W]^2 -> [B,G,ndisp,H,W] */
 int ss_gwc_volume_fwd(const float* ref, const float* tgt, float* out,
-                      int B, int C, int H, int W, int maxdisp, int groups, int normalize,
+                      int B, int C, int H, int W, int dmin, int ndisp, int groups, int normalize,
                       ss_stream_t stream);
 /* models/SemStereo.py:273-276 in one launch: build_gwc_volume[_norm] -> `patch` (depthwise Conv3d, kernel (1,3,3),
  * padding (0,1,1), no bias; patch_w [G,1,1,3,3]) -> channelAtt gate (sigmoid(gate_logits[b,g,y,x]) broadcast over the
  * disparities; NULL: no gate).  Bit-identical to ss_gwc_volume_fwd + ss_depthwise_patch_fwd.  Needs W % 4 == 0,
- * maxdisp % 4 == 0, C / groups in {4, 8}, 16-byte aligned pointers: SS_ERR_UNSUPPORTED otherwise (use the two calls). */
+ * dmin % 4 == 0, ndisp % 8 == 0, C / groups in {4, 8}, 16-byte aligned pointers: SS_ERR_UNSUPPORTED otherwise (use the two calls). */
 int ss_gwc_patch_gate_fwd(const float* ref, const float* tgt, const float* patch_w, const float* gate_logits, float* out,
-                          int B, int C, int H, int W, int maxdisp, int groups, int normalize, ss_stream_t stream);
+                          int B, int C, int H, int W, int dmin, int ndisp, int groups, int normalize, ss_stream_t stream);
 /* gradients of the UN-normalised volume w.r.t. ref and tgt (both fully written). */
 int ss_gwc_volume_bwd(const float* grad_out, const float* ref, const float* tgt,
                       float* grad_ref, float* grad_tgt,
-                      int B, int C, int H, int W, int maxdisp, int groups,
+                      int B, int C, int H, int W, int dmin, int ndisp, int groups,
                       ss_stream_t stream);
 
-/* build_concat_volume(ref, tgt, maxdisp)               models/submodule.py:173-187
- * out[b,0:C,d,y,x] = ref[b,:,y,x], out[b,C:2C,d,y,x] = tgt[b,:,y,x-(d-maxdisp)], BOTH 0 where
- * the partner column leaves the image.  [B,C,H,W]^2 -> [B,2C,2*maxdisp,H,W] */
+/* build_concat_volume(ref, tgt, maxdisp)               models/submodule.py:173-187   (unsigned: models/submodule_.py:166-177)
+ * out[b,0:C,p,y,x] = ref[b,:,y,x], out[b,C:2C,p,y,x] = tgt[b,:,y,x-(dmin+p)], 0 where the partner column leaves
+ * the image -- in BOTH halves with mask_left != 0 (the signed form), in the right half only with mask_left == 0 (the
+ * unsigned form copies the left image unmasked).  [B,C,H,W]^2 -> [B,2C,ndisp,H,W] */
 int ss_concat_volume_fwd(const float* ref, const float* tgt, float* out,
-                         int B, int C, int H, int W, int maxdisp, ss_stream_t stream);
+                         int B, int C, int H, int W, int dmin, int ndisp, int mask_left, ss_stream_t stream);
 int ss_concat_volume_bwd(const float* grad_out, float* grad_ref, float* grad_tgt,
-                         int B, int C, int H, int W, int maxdisp, ss_stream_t stream);
+                         int B, int C, int H, int W, int dmin, int ndisp, int mask_left, ss_stream_t stream);
 
 /* SpatialTransformer_grid(x, y, disp_range_samples)    models/submodule.py:265-288
  * y_warped[b,c,j,h,w] = bilinear(y[b,c], row h, col w - disp[b,j,h,w]) with zeros padding and
@@ -121,26 +127,26 @@ int ss_stem_left_fused_fwd(const float* left, const void* wsplit, const float* a
 int ss_warp_correlation_fwd(const float* x, const float* y, const float* disp, float* out,
                             int B, int C, int H, int W, int nd, ss_stream_t stream);
 
-/* disparity_regression(x, maxdisp)                     models/submodule.py:164-170
- * out[b,y,x] = sum_d prob[b,d,y,x] * (d - maxdisp), d in [0, 2*maxdisp).  [B,2m,H,W] -> [B,H,W] */
-int ss_disparity_regression_fwd(const float* prob, float* out, int B, int maxdisp, int H, int W,
+/* disparity_regression(x, maxdisp)                     models/submodule.py:164-170   (unsigned: models/submodule_.py:159-163)
+ * out[b,y,x] = sum_p prob[b,p,y,x] * (dmin + p), p in [0, ndisp).  [B,ndisp,H,W] -> [B,H,W] */
+int ss_disparity_regression_fwd(const float* prob, float* out, int B, int dmin, int ndisp, int H, int W,
                                 ss_stream_t stream);
-int ss_disparity_regression_bwd(const float* grad_out, float* grad_prob, int B, int maxdisp, int H, int W,
+int ss_disparity_regression_bwd(const float* grad_out, float* grad_prob, int B, int dmin, int ndisp, int H, int W,
                                 ss_stream_t stream);
-/* disparity_variance(x, maxdisp, disparity)            models/submodule.py:257-263
- * out[b,0,y,x] = sum_d prob[b,d,y,x] * ((d - maxdisp) - disparity[b,0,y,x])^2 */
+/* disparity_variance(x, maxdisp, disparity)            models/submodule.py:257-263   (unsigned: models/submodule_.py:239-245)
+ * out[b,0,y,x] = sum_p prob[b,p,y,x] * ((dmin + p) - disparity[b,0,y,x])^2 */
 int ss_disparity_variance_fwd(const float* prob, const float* disparity, float* out,
-                              int B, int maxdisp, int H, int W, ss_stream_t stream);
+                              int B, int dmin, int ndisp, int H, int W, ss_stream_t stream);
 /* Fused softmax over D + regression + variance of models/SemStereo.py:281-285:
- * logits [B,2m,H,W] -> prob (nullable) [B,2m,H,W], disp [B,H,W], var [B,1,H,W] */
+ * logits [B,ndisp,H,W] -> prob (nullable) [B,ndisp,H,W], disp [B,H,W], var [B,1,H,W] */
 int ss_softmax_regression_fwd(const float* logits, float* prob, float* disp, float* var,
-                              int B, int maxdisp, int H, int W, ss_stream_t stream);
+                              int B, int dmin, int ndisp, int H, int W, ss_stream_t stream);
 /* The same with the trilinear up-sampling in front of it fused in (models/SemStereo.py:279-285):
- * coarse [B,1,maxdisp,H/2,W/2] = classif_att_'s output; up [B,2*maxdisp,H,W] receives
- * F.interpolate(coarse, [2*maxdisp,H,W], mode='trilinear') (align_corners=False, exact 2x in every dimension: H, W even),
- * disp [B,H,W] and var [B,1,H,W] the soft-argmax and variance of softmax(up) over the disparity axis.  2*maxdisp <= 128. */
+ * coarse [B,1,ndisp/2,H/2,W/2] = classif_att_'s output; up [B,ndisp,H,W] receives
+ * F.interpolate(coarse, [ndisp,H,W], mode='trilinear') (align_corners=False, exact 2x in every dimension: H, W, ndisp
+ * even), disp [B,H,W] and var [B,1,H,W] the soft-argmax and variance of softmax(up) over the disparity axis.  ndisp <= 128. */
 int ss_upsample_softmax_regression_fwd(const float* coarse, float* up, float* disp, float* var,
-                                       int B, int maxdisp, int H, int W, ss_stream_t stream);
+                                       int B, int dmin, int ndisp, int H, int W, ss_stream_t stream);
 
 /* Fused models/SemStereo.py:286-293 (variance gate, Propagation x2 [models/submodule.py:290-307],
  * 5-sample SpatialTransformer_grid, channel-mean correlation, softmax over the 5 samples):
@@ -153,11 +159,11 @@ int ss_sample_strength_fwd(const float* left, const float* right, const float* p
                            int B, int C, int H, int W, ss_stream_t stream);
 /* Fused models/SemStereo.py:295-310 (Propagation_prob [models/submodule.py:361-377] weighted by
  * strength, softmax over D, descending stable sort, top-k, ascending re-sort, gathers, softmax over
- * the k, expectation):  logits [B,1,2m,H,W], strength [B,5,H,W] ->
- *   samples [B,k,H,W] (candidate disparities, ascending, as floats), att_topk [B,1,k,H,W] (their
- *   probabilities), pred_att [B,H,W].  2m <= 128. */
+ * the k, expectation):  logits [B,1,ndisp,H,W], strength [B,5,H,W] ->
+ *   samples [B,k,H,W] (candidate disparities dmin + index, ascending, as floats), att_topk [B,1,k,H,W] (their
+ *   probabilities), pred_att [B,H,W].  ndisp <= 128. */
 int ss_topk_candidates_fwd(const float* logits, const float* strength, float* samples, float* att_topk,
-                           float* pred_att, int B, int maxdisp, int H, int W, int k, ss_stream_t stream);
+                           float* pred_att, int B, int dmin, int ndisp, int H, int W, int k, ss_stream_t stream);
 
 /* regression_topk(cost, disparity_samples, k)         models/submodule.py:434-442
  * per pixel: the k largest costs (ties: lower index first), softmax over them, expectation of

@@ -15,12 +15,26 @@ from . import ops, stack
 TOPK = 24  # models/SemStereo.py:301
 
 
-def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None):
+def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None, unsigned=False):
     """models/SemStereo.py:273-310.  Returns (att_topk [B,1,k,H4,W4],
-    disparity_sample_topk [B,k,H4,W4], pred_att [B,H4,W4])."""
+    disparity_sample_topk [B,k,H4,W4], pred_att [B,H4,W4]).
+    unsigned: models/SemStereo_WHU.py's two differing lines (:279 maxdisp//4 planes, :305 no offset) on the unsigned op
+    set it needs (models/submodule_.py, oracle/ops_unsigned.py)."""
     B, C8, H8, W8 = fl8.shape
     H4, W4 = fl4.shape[2], fl4.shape[3]
     m4 = maxdisp // 4
+    if unsigned:
+        from . import ops_unsigned as uops
+        corr = uops.build_gwc_volume_norm(fl8, fr8, maxdisp // 8, C8 // 8)
+        corr = stack.patch_conv(P, corr)
+        cost_att = stack.channel_att(P, "corr_feature_att_8", corr, fl8)
+        cost_att = stack.hourglass(P, "hourglass_att", cost_att, (4, 4, 4))
+        cost_att = stack.classifier(P, "classif_att_", cost_att)
+        att_weights = F.interpolate(cost_att, [m4, H4, W4], mode="trilinear")              # SemStereo_WHU.py:279
+        prob0 = F.softmax(att_weights.squeeze(1), dim=1)
+        pred0 = uops.disparity_regression(prob0, m4)
+        var = uops.disparity_variance(prob0, m4, pred0.unsqueeze(1))
+        return _attention_tail(P, fl4, fr4, att_weights, pred0, var, 0, out, corr, cost_att)
     corr = ops.build_gwc_volume_norm(fl8, fr8, maxdisp // 8, C8 // 8)                  # :273
     corr = stack.patch_conv(P, corr)                                                   # :274
     cost_att = stack.channel_att(P, "corr_feature_att_8", corr, fl8)                   # :276
@@ -30,6 +44,11 @@ def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None):
     prob0 = F.softmax(att_weights.squeeze(1), dim=1)                                   # :281-282
     pred0 = ops.disparity_regression(prob0, m4)                                        # :283
     var = ops.disparity_variance(prob0, m4, pred0.unsqueeze(1))                        # :285
+    return _attention_tail(P, fl4, fr4, att_weights, pred0, var, -m4, out, corr, cost_att)
+
+
+def _attention_tail(P, fl4, fr4, att_weights, pred0, var, dmin, out, corr, cost_att):
+    """models/SemStereo.py:286-310; `dmin`: the disparity of plane 0 (-maxdisp//4, or 0 in SemStereo_WHU.py:305)."""
     var = torch.sigmoid(P["beta"] + P["gamma"] * var)                                  # :286-287
     var_samples = ops.propagation(var)                                                 # :288
     disp_samples = ops.propagation(pred0.unsqueeze(1))                                 # :289
@@ -42,7 +61,7 @@ def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None):
     _, ind = aw_prob.sort(2, True)                                                     # :299
     ind_k = ind[:, :, :TOPK].sort(2, False)[0]                                         # :302-303
     att_topk = torch.gather(aw_prob, 2, ind_k)                                         # :304
-    samples = ind_k.squeeze(1).float() - m4                                            # :305
+    samples = ind_k.squeeze(1).float() + dmin                                          # :305
     att_prob = F.softmax(torch.gather(aw, 2, ind_k).squeeze(1), dim=1)                 # :307-308
     pred_att = (att_prob * samples).sum(dim=1)                                         # :309-310
     if out is not None:
@@ -72,13 +91,13 @@ def matching_branch(P, fl4, fr4, att_topk, samples, out=None):
 
 
 @torch.no_grad()
-def hot_segment(P, fl4, fr4, fl8, fr8, maxdisp, keep=False):
+def hot_segment(P, fl4, fr4, fl8, fr8, maxdisp, keep=False, unsigned=False):
     """features_left[1], features_right[1] ([B,128,H/4,W/4]) and
     features_left[2], features_right[2] ([B,256,H/8,W/8]) -> dict with
     `pred_att` [B,H4,W4], `pred` [B,1,H4,W4], `samples`, `att_topk` (+ the
     intermediates when keep=True)."""
     out = {} if keep else None
-    att_topk, samples, pred_att = attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out)
+    att_topk, samples, pred_att = attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out, unsigned)
     pred = matching_branch(P, fl4, fr4, att_topk, samples, out)
     res = dict(pred_att=pred_att, pred=pred, samples=samples, att_topk=att_topk)
     if keep:

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -19,26 +19,26 @@ _I = ctypes.c_int
 # name -> argument types (return type is always int status); mirrors include/semstereo_hip.h
 _SIGNATURES = {
     "ss_groupwise_correlation_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "ss_gwc_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "ss_gwc_patch_gate_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "ss_gwc_volume_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "ss_concat_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "ss_concat_volume_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_gwc_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_gwc_patch_gate_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_gwc_volume_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_concat_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_concat_volume_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_warp_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_warp_sampled_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_concat_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_stem_left_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_stem_left_fused_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_warp_correlation_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "ss_disparity_regression_fwd": [_P, _P, _I, _I, _I, _I, _P],
-    "ss_disparity_regression_bwd": [_P, _P, _I, _I, _I, _I, _P],
-    "ss_disparity_variance_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "ss_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "ss_upsample_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ss_disparity_regression_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_disparity_regression_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_disparity_variance_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_upsample_softmax_regression_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_regression_topk_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_regression_topk_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_sample_strength_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "ss_topk_candidates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_topk_candidates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ss_channel_gate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_channel_att_logits_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_ssr_upsample_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -471,10 +471,10 @@ extern "C" int ss_sample_strength_fwd(const float* left, const float* right, con
 }
 
 extern "C" int ss_topk_candidates_fwd(const float* logits, const float* strength, float* samples, float* att_topk,
-                                      float* pred_att, int B, int maxdisp, int H, int W, int k, ss_stream_t stream) {
+                                      float* pred_att, int B, int dmin, int ndisp, int H, int W, int k, ss_stream_t stream) {
     SS_REQUIRE(logits && strength && samples && att_topk && pred_att);
-    SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0 && k > 0);
-    const int D = 2 * maxdisp;
+    SS_REQUIRE(B > 0 && ndisp > 0 && H > 0 && W > 0 && k > 0);
+    const int D = ndisp, maxdisp = -dmin;                       // candidate value of plane d: d - maxdisp = dmin + d
     SS_REQUIRE(k <= D);
     if (D > 128) return SS_ERR_UNSUPPORTED;
     const int T = 128;
@@ -502,9 +502,9 @@ extern "C" int ss_topk_candidates_fwd(const float* logits, const float* strength
 }
 
 // exported for regression.hip's ss_softmax_regression_fwd
-int ss_softmax_regress_split_launch(const float* logits, float* prob, float* disp, float* var, int B, int maxdisp, int H,
-                                    int W, hipStream_t st) {
-    const int D = 2 * maxdisp;
+int ss_softmax_regress_split_launch(const float* logits, float* prob, float* disp, float* var, int B, int dmin, int ndisp,
+                                    int H, int W, hipStream_t st) {
+    const int D = ndisp, maxdisp = -dmin;
     const long long plane = (long long)H * W, total = (long long)B * plane;
     dim3 grid((unsigned)ss::ceil_div_ll(total, 64));
     if (D <= 64)
@@ -516,11 +516,11 @@ int ss_softmax_regress_split_launch(const float* logits, float* prob, float* dis
     return 0;
 }
 
-extern "C" int ss_upsample_softmax_regression_fwd(const float* coarse, float* up, float* disp, float* var, int B, int maxdisp,
-                                                  int H, int W, ss_stream_t stream) {
+extern "C" int ss_upsample_softmax_regression_fwd(const float* coarse, float* up, float* disp, float* var, int B, int dmin,
+                                                  int ndisp, int H, int W, ss_stream_t stream) {
     SS_REQUIRE(coarse && up && disp && var);
-    SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0);
-    const int D = 2 * maxdisp;
+    SS_REQUIRE(B > 0 && ndisp > 0 && H > 0 && W > 0);
+    const int D = ndisp, maxdisp = -dmin;
     if ((H & 1) || (W & 1) || D > 128 || (D & 1)) return SS_ERR_UNSUPPORTED;       // exact 2x in every dimension
     const long long plane = (long long)H * W, total = (long long)B * plane;
     dim3 grid((unsigned)ss::ceil_div_ll(total, 64));

@@ -83,7 +83,7 @@ extern "C" int ss_reload_tuning(void) {
     return SS_OK;
 }
 
-extern "C" int ss_abi_version(void) { return 6; }   // 6: + ss_channel_att_logits_fwd, ss_upsample_softmax_regression_fwd (5: ss_reload_tuning)
+extern "C" int ss_abi_version(void) { return 7; }   // 7: disparity ranges (dmin, ndisp) instead of maxdisp, ss_conv3d_wgrad_fwd, backward entry points; 6: + ss_channel_att_logits_fwd, ss_upsample_softmax_regression_fwd (5: ss_reload_tuning)
 
 extern "C" const char* ss_status_string(int status) {
     switch (status) {

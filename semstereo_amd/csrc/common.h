@@ -41,6 +41,16 @@ const Tuning& tuning();
 int ensure_dynamic_lds(const void* kernel, int bytes);
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Disparity ranges.  Every volume / regression entry point takes (dmin, ndisp): plane p holds disparity dmin + p.  The
+// reference's signed op set (models/submodule.py) is dmin = -maxdisp, ndisp = 2 * maxdisp; the unsigned one
+// (models/submodule_.py, the form models/SemStereo_WHU.py is written for) is dmin = 0, ndisp = maxdisp.
+// range_halo: columns of halo per side an LDS tile needs (the largest |shift|), rounded up to a multiple of 4.
+inline int range_halo(int dmin, int ndisp) {
+    const int a = -dmin, b = dmin + ndisp - 1;
+    const int m = a > b ? a : b;
+    return m <= 0 ? 0 : (m + 3) / 4 * 4;
+}
 __host__ __device__ inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 
 // Unfused multiply / add (the reference materialises the product tensor, i.e. rounds it,
@@ -61,8 +71,8 @@ __device__ __forceinline__ float exp_fast(float x) {
 }  // namespace ss
 
 // attention_tail.hip: wave-split softmax+regression+variance; returns non-zero if D is out of its range
-int ss_softmax_regress_split_launch(const float* logits, float* prob, float* disp, float* var, int B, int maxdisp, int H,
-                                    int W, hipStream_t st);
+int ss_softmax_regress_split_launch(const float* logits, float* prob, float* disp, float* var, int B, int dmin, int ndisp,
+                                    int H, int W, hipStream_t st);
 
 #define SS_REQUIRE(cond)              \
     do {                                \

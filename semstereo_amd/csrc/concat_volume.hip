@@ -1,7 +1,10 @@
-// Dense concatenation cost volume over a signed disparity range (gfx950).
+// Dense concatenation cost volume over a disparity range [dmin, dmin + D) (gfx950): plane p holds disparity s = dmin + p.
 //
-//   out[b,   c, d,y,x] = ref[b,c,y,x]            if 0 <= x-(d-m) < W else 0
-//   out[b, C+c, d,y,x] = tgt[b,c,y,x-(d-m)]      if 0 <= x-(d-m) < W else 0      d in [0,2m)
+//   out[b,   c, p,y,x] = ref[b,c,y,x]            if 0 <= x-s < W else 0          (unmasked with mask_left == 0)
+//   out[b, C+c, p,y,x] = tgt[b,c,y,x-s]          if 0 <= x-s < W else 0
+// The reference's signed form (models/submodule.py:173-187) is dmin = -maxdisp, D = 2*maxdisp, both halves masked; its
+// unsigned form (models/submodule_.py:166-177, the op set models/SemStereo_WHU.py needs) is dmin = 0, D = maxdisp with the
+// left half copied unmasked.  Below, mh = the halo of the LDS tile per side, off = mh - dmin.
 //
 // Replaces build_concat_volume (reference models/submodule.py:173-187).  Pure data movement:
 // 4*(2*C + 2*C*2m)*H*W bytes per pair, all of it coalesced 16-B-per-lane traffic: one workgroup
@@ -16,8 +19,10 @@ namespace {
 constexpr int XT = 128, RT = 8;
 
 __global__ __launch_bounds__(256) void concat_volume_v4(const float* __restrict__ ref, const float* __restrict__ tgt,
-                                                         float* __restrict__ out, int C, int H, int W, int m) {
+                                                         float* __restrict__ out, int C, int H, int W, int mh, int dmin,
+                                                         int D, int mask_left) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [RT][LW]
+    const int m = mh, off = mh - dmin;
     const int LW = XT + 2 * m, LQ = LW / 4;
     const int tid = threadIdx.x;
     const int xt0 = blockIdx.x * XT, y0 = blockIdx.y * RT;
@@ -39,11 +44,10 @@ __global__ __launch_bounds__(256) void concat_volume_v4(const float* __restrict_
     if (active) r = *reinterpret_cast<const float4*>(refp + (size_t)y * W + x0);
     __syncthreads();
     if (!active) return;
-    const int D = 2 * m;
     float* outl = out + ((((size_t)b * 2 * C + c) * D) * H + y) * W + x0;
     float* outr = out + ((((size_t)b * 2 * C + C + c) * D) * H + y) * W + x0;
     for (int d0 = 0; d0 < D; d0 += 8) {
-        const float* lp = &lds[ty * LW + tx * 4 + D - d0 - 8];
+        const float* lp = &lds[ty * LW + tx * 4 + off - d0 - 8];
         float w[12];
         *reinterpret_cast<float4*>(&w[0]) = *reinterpret_cast<const float4*>(lp);
         *reinterpret_cast<float4*>(&w[4]) = *reinterpret_cast<const float4*>(lp + 4);
@@ -51,11 +55,12 @@ __global__ __launch_bounds__(256) void concat_volume_v4(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int d = d0 + i;
-            const int col = x0 - (d - m);
+            const int col = x0 - (d + dmin);
             const bool v0 = (unsigned)(col + 0) < (unsigned)W, v1 = (unsigned)(col + 1) < (unsigned)W;
             const bool v2 = (unsigned)(col + 2) < (unsigned)W, v3 = (unsigned)(col + 3) < (unsigned)W;
             float4 a, t;
-            a.x = v0 ? r.x : 0.f; a.y = v1 ? r.y : 0.f; a.z = v2 ? r.z : 0.f; a.w = v3 ? r.w : 0.f;
+            a.x = (v0 || !mask_left) ? r.x : 0.f; a.y = (v1 || !mask_left) ? r.y : 0.f;
+            a.z = (v2 || !mask_left) ? r.z : 0.f; a.w = (v3 || !mask_left) ? r.w : 0.f;
             t.x = v0 ? w[8 - i] : 0.f; t.y = v1 ? w[9 - i] : 0.f; t.z = v2 ? w[10 - i] : 0.f; t.w = v3 ? w[11 - i] : 0.f;
             *reinterpret_cast<float4*>(outl + (size_t)d * plane) = a;
             *reinterpret_cast<float4*>(outr + (size_t)d * plane) = t;
@@ -65,8 +70,8 @@ __global__ __launch_bounds__(256) void concat_volume_v4(const float* __restrict_
 
 // any W / maxdisp: one element per thread, grid-stride over the OUTPUT.
 __global__ void concat_volume_generic(const float* __restrict__ ref, const float* __restrict__ tgt,
-                                      float* __restrict__ out, int C, int H, int W, int m, long long total) {
-    const int D = 2 * m;
+                                      float* __restrict__ out, int C, int H, int W, int dmin, int D, int mask_left,
+                                      long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % W);
@@ -75,19 +80,20 @@ __global__ void concat_volume_generic(const float* __restrict__ ref, const float
         const int d = (int)(t % D); t /= D;
         const int c2 = (int)(t % (2 * C));
         const long long b = t / (2 * C);
-        const int col = x - (d - m);
+        const int col = x - (d + dmin);
         float v = 0.f;
-        if ((unsigned)col < (unsigned)W) {
-            if (c2 < C) v = ref[((b * C + c2) * H + y) * W + x];
-            else v = tgt[((b * C + (c2 - C)) * H + y) * W + col];
+        if (c2 < C) {
+            if ((unsigned)col < (unsigned)W || !mask_left) v = ref[((b * C + c2) * H + y) * W + x];
+        } else if ((unsigned)col < (unsigned)W) {
+            v = tgt[((b * C + (c2 - C)) * H + y) * W + col];
         }
         out[i] = v;
     }
 }
 
 __global__ void concat_volume_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gref,
-                                         float* __restrict__ gtgt, int C, int H, int W, int m, long long total) {
-    const int D = 2 * m;
+                                         float* __restrict__ gtgt, int C, int H, int W, int dmin, int D, int mask_left,
+                                         long long total) {
     const long long plane = (long long)H * W;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -101,8 +107,8 @@ __global__ void concat_volume_bwd_kernel(const float* __restrict__ gout, float* 
         const float* gr = gout + ((b * 2 * C + C + c) * D) * plane + (long long)y * W;
         float ar = 0.f, at = 0.f;
         for (int d = 0; d < D; ++d) {
-            const int s = d - m;
-            if ((unsigned)(x - s) < (unsigned)W) ar += gl[d * plane + x];
+            const int s = d + dmin;
+            if ((unsigned)(x - s) < (unsigned)W || !mask_left) ar += gl[d * plane + x];
             if ((unsigned)(x + s) < (unsigned)W) at += gr[d * plane + x + s];
         }
         gref[i] = ar;
@@ -113,33 +119,33 @@ __global__ void concat_volume_bwd_kernel(const float* __restrict__ gout, float* 
 }  // namespace
 
 extern "C" int ss_concat_volume_fwd(const float* ref, const float* tgt, float* out, int B, int C, int H, int W,
-                                    int maxdisp, ss_stream_t stream) {
+                                    int dmin, int ndisp, int mask_left, ss_stream_t stream) {
     SS_REQUIRE(ref && tgt && out);
-    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && maxdisp > 0);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ndisp > 0);
     hipStream_t st = ss::as_stream(stream);
-    const int m = maxdisp;
+    const int mh = ss::range_halo(dmin, ndisp);
     const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(tgt) |
                            reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    if (aligned && W % 4 == 0 && m % 4 == 0 && (long long)B * C <= 65535 &&
-        (size_t)RT * (XT + 2 * m) * 4 <= 64 * 1024) {
+    if (aligned && W % 4 == 0 && dmin % 4 == 0 && ndisp % 8 == 0 && (long long)B * C <= 65535 &&
+        (size_t)RT * (XT + 2 * mh) * 4 <= 64 * 1024) {
         dim3 grid(ss::ceil_div(W, XT), ss::ceil_div(H, RT), B * C);
-        hipLaunchKernelGGL(concat_volume_v4, grid, dim3(256), (size_t)RT * (XT + 2 * m) * sizeof(float), st, ref, tgt,
-                           out, C, H, W, m);
+        hipLaunchKernelGGL(concat_volume_v4, grid, dim3(256), (size_t)RT * (XT + 2 * mh) * sizeof(float), st, ref, tgt,
+                           out, C, H, W, mh, dmin, ndisp, mask_left);
         return ss::check_launch();
     }
-    const long long total = (long long)B * 2 * C * 2 * m * H * W;
+    const long long total = (long long)B * 2 * C * ndisp * H * W;
     const int blocks = (int)std::min<long long>(ss::ceil_div_ll(total, 256), 256 * 32);
-    hipLaunchKernelGGL(concat_volume_generic, dim3(blocks), dim3(256), 0, st, ref, tgt, out, C, H, W, m, total);
+    hipLaunchKernelGGL(concat_volume_generic, dim3(blocks), dim3(256), 0, st, ref, tgt, out, C, H, W, dmin, ndisp, mask_left, total);
     return ss::check_launch();
 }
 
 extern "C" int ss_concat_volume_bwd(const float* grad_out, float* grad_ref, float* grad_tgt, int B, int C, int H,
-                                    int W, int maxdisp, ss_stream_t stream) {
+                                    int W, int dmin, int ndisp, int mask_left, ss_stream_t stream) {
     SS_REQUIRE(grad_out && grad_ref && grad_tgt);
-    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && maxdisp > 0);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ndisp > 0);
     const long long total = (long long)B * C * H * W;
     const int blocks = (int)std::min<long long>(ss::ceil_div_ll(total, 256), 256 * 32);
     hipLaunchKernelGGL(concat_volume_bwd_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), grad_out, grad_ref,
-                       grad_tgt, C, H, W, maxdisp, total);
+                       grad_tgt, C, H, W, dmin, ndisp, mask_left, total);
     return ss::check_launch();
 }

@@ -34,8 +34,10 @@ template <int CG, bool NORM, bool STREAM>  // RT rows x 128 columns per workgrou
 __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict__ ref,
                                                       const float* __restrict__ tgt,
                                                       float* __restrict__ out,
-                                                      int C, int H, int W, int m, int G) {
+                                                      int C, int H, int W, int m, int G, int dmin, int D) {
+    // m: halo columns per side of the LDS tile (ss::range_halo); plane p holds disparity dmin + p; off = m - dmin
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [CG][RT][LW]
+    const int off = m - dmin;
     const int LW = XT + 2 * m;
     const int tid = threadIdx.x;
     const int xt0 = blockIdx.x * XT;
@@ -119,17 +121,16 @@ __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict
     __syncthreads();
     if (!active) return;
 
-    // ---- all 2m disparities of these 4 columns, 8 at a time ----
-    // LDS column of image column xx is xx - xt0 + m, so output (d, x0+j) reads index
-    // tx*4 + j + 2m - d = base + (j + 8 - i) with d = d0 + i, base = tx*4 + 2m - d0 - 8.
-    const int D = 2 * m;
+    // ---- all D disparities of these 4 columns, 8 at a time ----
+    // LDS column of image column xx is xx - xt0 + m, so output (plane d, x0+j), disparity dmin + d, reads index
+    // tx*4 + j + m - dmin - d = base + (j + 8 - i) with d = d0 + i, base = tx*4 + off - d0 - 8.
     float* outp = out + (((size_t)(b * G + g) * D) * H + y) * W + x0;
     const float den = (float)CG;
     for (int d0 = 0; d0 < D; d0 += 8) {
         float acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
-        const int base = tx * 4 + D - d0 - 8;
+        const int base = tx * 4 + off - d0 - 8;
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
             const float* lp = &lds[(c * RT + ty) * LW + base];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int d = d0 + i;
-            const int col = x0 - (d - m);          // partner column of x0; of x0+j it is col+j
+            const int col = x0 - (d + dmin);       // partner column of x0; of x0+j it is col+j
             float4 o;
             o.x = ((unsigned)(col + 0) < (unsigned)W) ? acc[i][0] / den : 0.f;
             o.y = ((unsigned)(col + 1) < (unsigned)W) ? acc[i][1] / den : 0.f;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict
 // blockDim = (GX, GR); LDS = Cg * GR * (GX + GX + 2m) floats.
 template <bool NORM>
 __global__ void gwc_volume_generic(const float* __restrict__ ref, const float* __restrict__ tgt,
-                                   float* __restrict__ out, int C, int H, int W, int m, int G) {
+                                   float* __restrict__ out, int C, int H, int W, int m, int G, int dmin, int D) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int GX = blockDim.x, GR = blockDim.y;
     const int Cg = C / G;
@@ -214,16 +215,15 @@ __global__ void gwc_volume_generic(const float* __restrict__ ref, const float* _
     __syncthreads();
     const int x = xt0 + threadIdx.x, y = y0 + threadIdx.y;
     if (x >= W || y >= H) return;
-    const int D = 2 * m;
     const float den = (float)Cg;
     float* outp = out + (((size_t)(b * G + g) * D) * H + y) * W + x;
     for (int d = 0; d < D; ++d) {
-        const int li = threadIdx.x + D - d;       // = (x - (d - m)) - (xt0 - m)
+        const int li = threadIdx.x + m - dmin - d;       // = (x - (dmin + d)) - (xt0 - m)
         float acc = 0.f;
         for (int c = 0; c < Cg; ++c)
             acc = ss::add_rn(acc, ss::mul_rn(rn[((size_t)c * GR + threadIdx.y) * GX + threadIdx.x],
                                              tn[((size_t)c * GR + threadIdx.y) * LW + li]));
-        const int col = x - (d - m);
+        const int col = x - (d + dmin);
         outp[(size_t)d * plane] = ((unsigned)col < (unsigned)W) ? acc / den : 0.f;
     }
 }
@@ -263,9 +263,9 @@ __global__ void group_corr_kernel(const float* __restrict__ f1, const float* __r
 // Backward of the un-normalised volume: one thread per input element, loop over d.
 __global__ void gwc_volume_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ ref,
                                       const float* __restrict__ tgt, float* __restrict__ gref,
-                                      float* __restrict__ gtgt, int C, int H, int W, int m, int G,
+                                      float* __restrict__ gtgt, int C, int H, int W, int dmin, int D, int G,
                                       long long total) {
-    const int Cg = C / G, D = 2 * m;
+    const int Cg = C / G;
     const long long plane = (long long)H * W;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -281,7 +281,7 @@ __global__ void gwc_volume_bwd_kernel(const float* __restrict__ gout, const floa
         const float* trow = tgt + row * W;
         float ar = 0.f, at = 0.f;
         for (int d = 0; d < D; ++d) {
-            const int s = d - m;
+            const int s = d + dmin;
             const int xr = x - s;                    // partner of left column x
             if ((unsigned)xr < (unsigned)W) ar += go[d * plane + x] * trow[xr];
             const int xl = x + s;                    // left column whose partner is right column x
@@ -326,8 +326,10 @@ __device__ __forceinline__ void l2_normalise4(float4 (&v)[CG]) {
 template <int CG, bool NORM, bool STREAM>
 __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __restrict__ ref, const float* __restrict__ tgt,
                                                              const float* __restrict__ wpatch, const float* __restrict__ gate,
-                                                             float* __restrict__ out, int C, int H, int W, int m, int G) {
+                                                             float* __restrict__ out, int C, int H, int W, int m, int G,
+                                                             int dmin, int D) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int off = m - dmin;                                   // (m: halo per side, plane p = disparity dmin + p; see gwc_volume_v4)
     const int LW = XT + 2 * m + 8;                              // right-image tile: image columns xt0 - m - 4 .. xt0 + 128 + m + 3
     float* tn = lds;                                            // [CG][FRC][LW]
     float* vt = lds + CG * FRC * LW;                            // [8][FRC][FVP]: index 4 + j <-> image column xt0 + j
@@ -401,7 +403,6 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
     for (int k = 0; k < 9; ++k) wv[k] = wpatch[g * 9 + k];
     __syncthreads();
 
-    const int D = 2 * m;
     const float den = (float)CG;
     float* outg = out + ((size_t)(b * G + g) * D) * plane;
     const float* gateg = gate ? gate + (size_t)(b * G + g) * plane : nullptr;
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
         float acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
-        const int base = tx * 4 + D - d0 - 8 + 4;
+        const int base = tx * 4 + off - d0 - 8 + 4;
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
             const float* lp = &tn[(c * FRC + ty) * LW + base];
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int col = x0 - (d0 + i - m);
+            const int col = x0 - (d0 + i + dmin);
             float4 o;
             o.x = (active && (unsigned)(col + 0) < (unsigned)W) ? acc[i][0] / den : 0.f;
             o.y = (active && (unsigned)(col + 1) < (unsigned)W) ? acc[i][1] / den : 0.f;
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
         if (tid < 2 * FRC * 8) {                                // the seam columns: (side, row, disparity) per thread
             const int i = tid & 7, row = (tid >> 3) % FRC, side = tid / (8 * FRC);
             const int xx = side ? xt0 + XT : xt0 - 1;
-            const int col = xx - (d0 + i - m);
+            const int col = xx - (d0 + i + dmin);
             float a = 0.f;
 #pragma unroll
             for (int c = 0; c < CG; ++c) a = fmaf(rh[(side * FRC + row) * CG + c], tn[(c * FRC + row) * LW + (col - xt0 + m + 4)], a);
@@ -501,91 +502,93 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
 
 template <int CG, bool NORM, bool STREAM>
 int launch_gpg(const float* ref, const float* tgt, const float* wpatch, const float* gate, float* out, int B, int C, int H,
-               int W, int m, int G, hipStream_t st) {
+               int W, int m, int G, int dmin, int D, hipStream_t st) {
     dim3 grid(ss::ceil_div(W, XT), ss::ceil_div(H, FRO), B * G);
     const size_t lds = ((size_t)CG * FRC * (XT + 2 * m + 8) + 8 * FRC * FVP + 2 * FRC * CG + FRO * XT) * sizeof(float);
     auto kern = gwc_patch_gate_v4<CG, NORM, STREAM>;
     if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, grid, dim3(32 * FRC), lds, st, ref, tgt, wpatch, gate, out, C, H, W, m, G);
+    hipLaunchKernelGGL(kern, grid, dim3(32 * FRC), lds, st, ref, tgt, wpatch, gate, out, C, H, W, m, G, dmin, D);
     return ss::check_launch();
 }
 
 template <int CG, bool NORM, bool STREAM>
-int launch_v4_as(const float* ref, const float* tgt, float* out, int B, int C, int H, int W, int m, int G,
+int launch_v4_as(const float* ref, const float* tgt, float* out, int B, int C, int H, int W, int m, int G, int dmin, int D,
                  hipStream_t st) {
     dim3 grid(ss::ceil_div(W, XT), ss::ceil_div(H, RT), B * G);
     size_t lds = (size_t)CG * RT * (XT + 2 * m) * sizeof(float);
-    hipLaunchKernelGGL((gwc_volume_v4<CG, NORM, STREAM>), grid, dim3(32 * RT), lds, st, ref, tgt, out, C, H, W, m, G);
+    hipLaunchKernelGGL((gwc_volume_v4<CG, NORM, STREAM>), grid, dim3(32 * RT), lds, st, ref, tgt, out, C, H, W, m, G, dmin, D);
     return ss::check_launch();
 }
 
 template <int CG>
-int launch_v4(const float* ref, const float* tgt, float* out, int B, int C, int H, int W, int m, int G,
+int launch_v4(const float* ref, const float* tgt, float* out, int B, int C, int H, int W, int m, int G, int dmin, int D,
               int normalize, bool stream_out, hipStream_t st) {
     if (normalize)
-        return stream_out ? launch_v4_as<CG, true, true>(ref, tgt, out, B, C, H, W, m, G, st)
-                          : launch_v4_as<CG, true, false>(ref, tgt, out, B, C, H, W, m, G, st);
-    return stream_out ? launch_v4_as<CG, false, true>(ref, tgt, out, B, C, H, W, m, G, st)
-                      : launch_v4_as<CG, false, false>(ref, tgt, out, B, C, H, W, m, G, st);
+        return stream_out ? launch_v4_as<CG, true, true>(ref, tgt, out, B, C, H, W, m, G, dmin, D, st)
+                          : launch_v4_as<CG, true, false>(ref, tgt, out, B, C, H, W, m, G, dmin, D, st);
+    return stream_out ? launch_v4_as<CG, false, true>(ref, tgt, out, B, C, H, W, m, G, dmin, D, st)
+                      : launch_v4_as<CG, false, false>(ref, tgt, out, B, C, H, W, m, G, dmin, D, st);
 }
 
 }  // namespace
 
 extern "C" int ss_gwc_volume_fwd(const float* ref, const float* tgt, float* out, int B, int C, int H, int W,
-                                 int maxdisp, int groups, int normalize, ss_stream_t stream) {
+                                 int dmin, int ndisp, int groups, int normalize, ss_stream_t stream) {
     SS_REQUIRE(ref && tgt && out);
-    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && maxdisp > 0 && groups > 0);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ndisp > 0 && groups > 0);
     SS_REQUIRE(C % groups == 0);
     SS_REQUIRE((long long)B * groups <= 65535);
     hipStream_t st = ss::as_stream(stream);
-    const int Cg = C / groups, m = maxdisp;
+    const int Cg = C / groups, m = ss::range_halo(dmin, ndisp);
     const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(tgt) |
                            reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    if (aligned && W % 4 == 0 && m % 4 == 0 && (size_t)Cg * RT * (XT + 2 * m) * 4 <= 64 * 1024) {
+    if (aligned && W % 4 == 0 && dmin % 4 == 0 && ndisp % 8 == 0 && (size_t)Cg * RT * (XT + 2 * m) * 4 <= 64 * 1024) {
         // volumes beyond the 256 MB infinity cache cannot stay resident for the consumer: stream them
-        const size_t out_bytes = (size_t)B * groups * 2 * m * H * W * sizeof(float);
+        const size_t out_bytes = (size_t)B * groups * ndisp * H * W * sizeof(float);
         bool stream_out = out_bytes > ((size_t)192 << 20);
         if (ss::tuning().gwc_stream >= 0) stream_out = ss::tuning().gwc_stream == 1;   // tuning aid
-        if (Cg == 8) return launch_v4<8>(ref, tgt, out, B, C, H, W, m, groups, normalize, stream_out, st);
-        if (Cg == 4) return launch_v4<4>(ref, tgt, out, B, C, H, W, m, groups, normalize, stream_out, st);
+        if (Cg == 8) return launch_v4<8>(ref, tgt, out, B, C, H, W, m, groups, dmin, ndisp, normalize, stream_out, st);
+        if (Cg == 4) return launch_v4<4>(ref, tgt, out, B, C, H, W, m, groups, dmin, ndisp, normalize, stream_out, st);
     }
     // generic path: shrink the tile until both normalised tiles fit in 64 KiB of LDS
     int gx = 64, gr = 4;
-    auto bytes = [&](int x, int r) { return (size_t)Cg * r * (2 * x + 2 * m) * sizeof(float); };
+    const int mg = ss::range_halo(dmin, ndisp);
+    auto bytes = [&](int x, int r) { return (size_t)Cg * r * (2 * x + 2 * mg) * sizeof(float); };
     while (gr > 1 && bytes(gx, gr) > 64 * 1024) gr >>= 1;
     while (gx > 16 && bytes(gx, gr) > 64 * 1024) gx >>= 1;
     if (bytes(gx, gr) > 64 * 1024) return SS_ERR_UNSUPPORTED;
     dim3 grid(ss::ceil_div(W, gx), ss::ceil_div(H, gr), B * groups), block(gx, gr);
     if (normalize)
-        hipLaunchKernelGGL(gwc_volume_generic<true>, grid, block, bytes(gx, gr), st, ref, tgt, out, C, H, W, m, groups);
+        hipLaunchKernelGGL(gwc_volume_generic<true>, grid, block, bytes(gx, gr), st, ref, tgt, out, C, H, W, mg, groups, dmin, ndisp);
     else
-        hipLaunchKernelGGL(gwc_volume_generic<false>, grid, block, bytes(gx, gr), st, ref, tgt, out, C, H, W, m, groups);
+        hipLaunchKernelGGL(gwc_volume_generic<false>, grid, block, bytes(gx, gr), st, ref, tgt, out, C, H, W, mg, groups, dmin, ndisp);
     return ss::check_launch();
 }
 
 extern "C" int ss_gwc_patch_gate_fwd(const float* ref, const float* tgt, const float* patch_w, const float* gate_logits,
-                                     float* out, int B, int C, int H, int W, int maxdisp, int groups, int normalize,
+                                     float* out, int B, int C, int H, int W, int dmin, int ndisp, int groups, int normalize,
                                      ss_stream_t stream) {
     SS_REQUIRE(ref && tgt && patch_w && out);
-    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && maxdisp > 0 && groups > 0);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ndisp > 0 && groups > 0);
     SS_REQUIRE(C % groups == 0);
     SS_REQUIRE((long long)B * groups <= 65535);
-    const int Cg = C / groups, m = maxdisp;
+    const int Cg = C / groups, m = ss::range_halo(dmin, ndisp);
     const uintptr_t bits = reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(tgt) | reinterpret_cast<uintptr_t>(out) |
                            reinterpret_cast<uintptr_t>(gate_logits);
     const size_t lds = ((size_t)Cg * FRC * (XT + 2 * m + 8) + 8 * FRC * FVP + 2 * FRC * Cg + FRO * XT) * sizeof(float);
-    if ((bits & 15) != 0 || W % 4 != 0 || m % 4 != 0 || (Cg != 8 && Cg != 4) || lds > 150 * 1024) return SS_ERR_UNSUPPORTED;
+    if ((bits & 15) != 0 || W % 4 != 0 || dmin % 4 != 0 || ndisp % 8 != 0 || (Cg != 8 && Cg != 4) || lds > 150 * 1024)
+        return SS_ERR_UNSUPPORTED;
     hipStream_t st = ss::as_stream(stream);
-    const size_t out_bytes = (size_t)B * groups * 2 * m * H * W * sizeof(float);
+    const size_t out_bytes = (size_t)B * groups * ndisp * H * W * sizeof(float);
     bool stream_out = out_bytes > ((size_t)192 << 20);           // as ss_gwc_volume_fwd: beyond the infinity cache
     if (ss::tuning().gwc_stream >= 0) stream_out = ss::tuning().gwc_stream == 1;
 #define SS_GPG(CGV)                                                                                                           \
     if (Cg == CGV) {                                                                                                          \
         if (normalize)                                                                                                        \
-            return stream_out ? launch_gpg<CGV, true, true>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, st)   \
-                              : launch_gpg<CGV, true, false>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, st); \
-        return stream_out ? launch_gpg<CGV, false, true>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, st)      \
-                          : launch_gpg<CGV, false, false>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, st);    \
+            return stream_out ? launch_gpg<CGV, true, true>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, dmin, ndisp, st)   \
+                              : launch_gpg<CGV, true, false>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, dmin, ndisp, st); \
+        return stream_out ? launch_gpg<CGV, false, true>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, dmin, ndisp, st)      \
+                          : launch_gpg<CGV, false, false>(ref, tgt, patch_w, gate_logits, out, B, C, H, W, m, groups, dmin, ndisp, st);    \
     }
     SS_GPG(8)
     SS_GPG(4)
@@ -608,14 +611,14 @@ extern "C" int ss_groupwise_correlation_fwd(const float* fea1, const float* fea2
 }
 
 extern "C" int ss_gwc_volume_bwd(const float* grad_out, const float* ref, const float* tgt, float* grad_ref,
-                                 float* grad_tgt, int B, int C, int H, int W, int maxdisp, int groups,
+                                 float* grad_tgt, int B, int C, int H, int W, int dmin, int ndisp, int groups,
                                  ss_stream_t stream) {
     SS_REQUIRE(grad_out && ref && tgt && grad_ref && grad_tgt);
-    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && maxdisp > 0 && groups > 0);
+    SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ndisp > 0 && groups > 0);
     SS_REQUIRE(C % groups == 0);
     const long long total = (long long)B * C * H * W;
     const int blocks = (int)std::min<long long>(ss::ceil_div_ll(total, 256), 256 * 32);
     hipLaunchKernelGGL(gwc_volume_bwd_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), grad_out, ref, tgt,
-                       grad_ref, grad_tgt, C, H, W, maxdisp, groups, total);
+                       grad_ref, grad_tgt, C, H, W, dmin, ndisp, groups, total);
     return ss::check_launch();
 }

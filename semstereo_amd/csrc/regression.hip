@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ att
 }
 
 template <int KIND>
-int launch_regress(const float* prob, const float* disp, float* out, int B, int m, int H, int W, hipStream_t st) {
-    const int D = 2 * m;
+int launch_regress(const float* prob, const float* disp, float* out, int B, int dmin, int D, int H, int W, hipStream_t st) {
+    const int m = -dmin;                                       // plane d holds disparity d - m
     const long long plane = (long long)H * W;
     uintptr_t bits = reinterpret_cast<uintptr_t>(prob) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(disp);
     const bool v4 = (plane % 4 == 0) && ((bits & 15) == 0);
@@ -272,40 +272,40 @@ int launch_regress(const float* prob, const float* disp, float* out, int B, int 
 
 }  // namespace
 
-extern "C" int ss_disparity_regression_fwd(const float* prob, float* out, int B, int maxdisp, int H, int W,
+extern "C" int ss_disparity_regression_fwd(const float* prob, float* out, int B, int dmin, int ndisp, int H, int W,
                                            ss_stream_t stream) {
     SS_REQUIRE(prob && out);
-    SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0);
-    return launch_regress<RG_MEAN>(prob, nullptr, out, B, maxdisp, H, W, ss::as_stream(stream));
+    SS_REQUIRE(B > 0 && ndisp > 0 && H > 0 && W > 0);
+    return launch_regress<RG_MEAN>(prob, nullptr, out, B, dmin, ndisp, H, W, ss::as_stream(stream));
 }
 
-extern "C" int ss_disparity_variance_fwd(const float* prob, const float* disparity, float* out, int B, int maxdisp,
+extern "C" int ss_disparity_variance_fwd(const float* prob, const float* disparity, float* out, int B, int dmin, int ndisp,
                                          int H, int W, ss_stream_t stream) {
     SS_REQUIRE(prob && disparity && out);
-    SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0);
-    return launch_regress<RG_VAR>(prob, disparity, out, B, maxdisp, H, W, ss::as_stream(stream));
+    SS_REQUIRE(B > 0 && ndisp > 0 && H > 0 && W > 0);
+    return launch_regress<RG_VAR>(prob, disparity, out, B, dmin, ndisp, H, W, ss::as_stream(stream));
 }
 
-extern "C" int ss_disparity_regression_bwd(const float* grad_out, float* grad_prob, int B, int maxdisp, int H, int W,
+extern "C" int ss_disparity_regression_bwd(const float* grad_out, float* grad_prob, int B, int dmin, int ndisp, int H, int W,
                                            ss_stream_t stream) {
     SS_REQUIRE(grad_out && grad_prob);
-    SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0);
-    const long long plane = (long long)H * W, total = (long long)B * 2 * maxdisp * plane;
+    SS_REQUIRE(B > 0 && ndisp > 0 && H > 0 && W > 0);
+    const long long plane = (long long)H * W, total = (long long)B * ndisp * plane;
     const int blocks = (int)std::min<long long>(ss::ceil_div_ll(total, 256), 256 * 32);
     hipLaunchKernelGGL(regress_bwd_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), grad_out, grad_prob,
-                       2 * maxdisp, maxdisp, plane, total);
+                       ndisp, -dmin, plane, total);
     return ss::check_launch();
 }
 
-extern "C" int ss_softmax_regression_fwd(const float* logits, float* prob, float* disp, float* var, int B, int maxdisp,
+extern "C" int ss_softmax_regression_fwd(const float* logits, float* prob, float* disp, float* var, int B, int dmin, int ndisp,
                                          int H, int W, ss_stream_t stream) {
     SS_REQUIRE(logits && disp && var);
-    SS_REQUIRE(B > 0 && maxdisp > 0 && H > 0 && W > 0);
-    if (ss_softmax_regress_split_launch(logits, prob, disp, var, B, maxdisp, H, W, ss::as_stream(stream)) == 0)
+    SS_REQUIRE(B > 0 && ndisp > 0 && H > 0 && W > 0);
+    if (ss_softmax_regress_split_launch(logits, prob, disp, var, B, dmin, ndisp, H, W, ss::as_stream(stream)) == 0)
         return ss::check_launch();
     const long long plane = (long long)H * W, total = (long long)B * plane;
     hipLaunchKernelGGL(softmax_regress_kernel,dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
-                       ss::as_stream(stream), logits, prob, disp, var, 2 * maxdisp, maxdisp, plane, total);
+                       ss::as_stream(stream), logits, prob, disp, var, ndisp, -dmin, plane, total);
     return ss::check_launch();
 }
 

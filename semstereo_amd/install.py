@@ -27,14 +27,18 @@ from . import ops
 from . import segment
 
 
-def install(model_module, names=ops.REFERENCE_NAMES):
+def install(model_module, names=ops.REFERENCE_NAMES, unsigned=False):
     """setattr(model_module, name, hip_op) for every hot-path callable.  Rebinding
     `models.submodule.X` alone would not be enough: the star-import copied the binding.
+    `unsigned`: the unsigned-range op set (`ops_unsigned`, models/submodule_.py's definitions) -- what
+    models/SemStereo_WHU.py needs in its globals to run at all (see ops_unsigned's docstring).
     Returns {name: previous object} so `uninstall` can restore it."""
+    from . import ops_unsigned
+    lib = ops_unsigned if unsigned else ops
     previous = {}
     for name in names:
         previous[name] = getattr(model_module, name, None)
-        setattr(model_module, name, getattr(ops, name))
+        setattr(model_module, name, getattr(lib, name))
     return previous
 
 

@@ -25,33 +25,44 @@ def _needs_grad(*ts):
 # group-wise correlation volume
 # --------------------------------------------------------------------------------------
 
-def _gwc_forward(ref, tgt, maxdisp, groups, normalize):
+def signed_range(maxdisp):
+    """(dmin, ndisp) of the reference's signed op set (models/submodule.py): disparities [-maxdisp, maxdisp)."""
+    return -int(maxdisp), 2 * int(maxdisp)
+
+
+def unsigned_range(maxdisp):
+    """(dmin, ndisp) of the unsigned op set (models/submodule_.py, the one models/SemStereo_WHU.py is written for)."""
+    return 0, int(maxdisp)
+
+
+def _gwc_forward(ref, tgt, rng, groups, normalize):
     dev = _lib.require_device(ref, tgt)
     B, C, H, W = ref.shape
-    out = torch.empty((B, groups, 2 * maxdisp, H, W), dtype=ref.dtype, device=ref.device)
+    dmin, nd = rng
+    out = torch.empty((B, groups, nd, H, W), dtype=ref.dtype, device=ref.device)
     if out.numel():
         with torch.cuda.device(dev):
-            call("ss_gwc_volume_fwd", ptr(ref), ptr(tgt), ptr(out), B, C, H, W, maxdisp, groups, int(normalize))
+            call("ss_gwc_volume_fwd", ptr(ref), ptr(tgt), ptr(out), B, C, H, W, dmin, nd, groups, int(normalize))
     return out
 
 
 class _GwcVolume(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ref, tgt, maxdisp, groups):
+    def forward(ctx, ref, tgt, rng, groups):
         ref, tgt = _c(ref), _c(tgt)
         ctx.save_for_backward(ref, tgt)
-        ctx.cfg = (maxdisp, groups)
-        return _gwc_forward(ref, tgt, maxdisp, groups, False)
+        ctx.cfg = (rng, groups)
+        return _gwc_forward(ref, tgt, rng, groups, False)
 
     @staticmethod
     def backward(ctx, g):
         ref, tgt = ctx.saved_tensors
-        maxdisp, groups = ctx.cfg
+        (dmin, nd), groups = ctx.cfg
         g = _c(g)
         B, C, H, W = ref.shape
         gref, gtgt = torch.empty_like(ref), torch.empty_like(tgt)
         with torch.cuda.device(ref.device):
-            call("ss_gwc_volume_bwd", ptr(g), ptr(ref), ptr(tgt), ptr(gref), ptr(gtgt), B, C, H, W, maxdisp, groups)
+            call("ss_gwc_volume_bwd", ptr(g), ptr(ref), ptr(tgt), ptr(gref), ptr(gtgt), B, C, H, W, dmin, nd, groups)
         return gref, gtgt, None, None
 
 
@@ -68,33 +79,37 @@ def _group_normalise(x, groups):
     return (v / (torch.linalg.vector_norm(v, 2, dim=2, keepdim=True) + 1e-05)).reshape(B, C, H, W)
 
 
-def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None):
     """models/submodule.py:198-211 -> [B, G, 2*maxdisp, H, W] (signed disparity range)."""
     _check_pair(refimg_fea, targetimg_fea, num_groups)
+    rng = _range or signed_range(maxdisp)
     if _needs_grad(refimg_fea, targetimg_fea):
-        return _GwcVolume.apply(refimg_fea, targetimg_fea, int(maxdisp), int(num_groups))
-    return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), int(maxdisp), int(num_groups), False)
+        return _GwcVolume.apply(refimg_fea, targetimg_fea, rng, int(num_groups))
+    return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), rng, int(num_groups), False)
 
 
-def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups):
+def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None):
     """models/submodule.py:224-238 (the live call, models/SemStereo.py:273)."""
     _check_pair(refimg_fea, targetimg_fea, num_groups)
+    rng = _range or signed_range(maxdisp)
     if _needs_grad(refimg_fea, targetimg_fea):
         # normalise once with autograd-visible ops, then the volume kernel with its HIP backward
         return _GwcVolume.apply(_group_normalise(refimg_fea, num_groups), _group_normalise(targetimg_fea, num_groups),
-                                int(maxdisp), int(num_groups))
-    return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), int(maxdisp), int(num_groups), True)
+                                rng, int(num_groups))
+    return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), rng, int(num_groups), True)
 
 
-def gwc_patch_gate_applies(fea, maxdisp, num_groups):
+def gwc_patch_gate_applies(fea, maxdisp, num_groups, _range=None):
     """Shapes ss_gwc_patch_gate_fwd is built for (otherwise: the volume kernel + the patch kernel)."""
     B, C, H, W = fea.shape
     cg = C // num_groups
-    lds = (cg * 8 * (128 + 2 * maxdisp + 8) + 8 * 8 * 136 + 16 * cg + 6 * 128) * 4
-    return W % 4 == 0 and maxdisp % 4 == 0 and cg in (4, 8) and lds <= 150 * 1024 and B * num_groups <= 65535
+    dmin, nd = _range or signed_range(maxdisp)
+    halo = (max(-dmin, dmin + nd - 1, 0) + 3) // 4 * 4
+    lds = (cg * 8 * (128 + 2 * halo + 8) + 8 * 8 * 136 + 16 * cg + 6 * 128) * 4
+    return W % 4 == 0 and dmin % 4 == 0 and nd % 8 == 0 and cg in (4, 8) and lds <= 150 * 1024 and B * num_groups <= 65535
 
 
-def gwc_patch_gate(refimg_fea, targetimg_fea, maxdisp, num_groups, patch_weight, gate_logits=None, normalize=True):
+def gwc_patch_gate(refimg_fea, targetimg_fea, maxdisp, num_groups, patch_weight, gate_logits=None, normalize=True, _range=None):
     """Fused models/SemStereo.py:273-276: build_gwc_volume_norm -> patch (depthwise (1,3,3)) -> channelAtt gate in one
     kernel; bit-identical to the two-kernel form.  patch_weight [G,1,1,3,3]; gate_logits [B,G,H,W] or None.  Inference only."""
     _check_pair(refimg_fea, targetimg_fea, num_groups)
@@ -103,9 +118,10 @@ def gwc_patch_gate(refimg_fea, targetimg_fea, maxdisp, num_groups, patch_weight,
     dev = _lib.require_device(ref, tgt, w, g)
     B, C, H, W = ref.shape
     assert w.numel() == num_groups * 9 and (g is None or g.shape == (B, num_groups, H, W))
-    out = torch.empty((B, num_groups, 2 * maxdisp, H, W), dtype=ref.dtype, device=ref.device)
+    dmin, nd = _range or signed_range(maxdisp)
+    out = torch.empty((B, num_groups, nd, H, W), dtype=ref.dtype, device=ref.device)
     with torch.cuda.device(dev):
-        call("ss_gwc_patch_gate_fwd", ptr(ref), ptr(tgt), ptr(w), ptr(g), ptr(out), B, C, H, W, int(maxdisp), int(num_groups),
+        call("ss_gwc_patch_gate_fwd", ptr(ref), ptr(tgt), ptr(w), ptr(g), ptr(out), B, C, H, W, dmin, nd, int(num_groups),
              int(normalize))
     return out
 
@@ -143,32 +159,33 @@ def groupwise_correlation_norm(fea1, fea2, num_groups):
 
 class _ConcatVolume(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ref, tgt, maxdisp):
+    def forward(ctx, ref, tgt, rng, mask_left):
         ref, tgt = _c(ref), _c(tgt)
         dev = _lib.require_device(ref, tgt)
         B, C, H, W = ref.shape
-        ctx.cfg = (B, C, H, W, maxdisp)
-        out = torch.empty((B, 2 * C, 2 * maxdisp, H, W), dtype=ref.dtype, device=ref.device)
+        dmin, nd = rng
+        ctx.cfg = (B, C, H, W, dmin, nd, int(mask_left))
+        out = torch.empty((B, 2 * C, nd, H, W), dtype=ref.dtype, device=ref.device)
         if out.numel():
             with torch.cuda.device(dev):
-                call("ss_concat_volume_fwd", ptr(ref), ptr(tgt), ptr(out), B, C, H, W, maxdisp)
+                call("ss_concat_volume_fwd", ptr(ref), ptr(tgt), ptr(out), B, C, H, W, dmin, nd, int(mask_left))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, C, H, W, maxdisp = ctx.cfg
+        B, C, H, W, dmin, nd, mask_left = ctx.cfg
         g = _c(g)
         gref = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device)
         gtgt = torch.empty_like(gref)
         with torch.cuda.device(g.device):
-            call("ss_concat_volume_bwd", ptr(g), ptr(gref), ptr(gtgt), B, C, H, W, maxdisp)
-        return gref, gtgt, None
+            call("ss_concat_volume_bwd", ptr(g), ptr(gref), ptr(gtgt), B, C, H, W, dmin, nd, mask_left)
+        return gref, gtgt, None, None
 
 
-def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
+def build_concat_volume(refimg_fea, targetimg_fea, maxdisp, _range=None, _mask_left=True):
     """models/submodule.py:173-187 -> [B, 2C, 2*maxdisp, H, W]."""
     _check_pair(refimg_fea, targetimg_fea)
-    return _ConcatVolume.apply(refimg_fea, targetimg_fea, int(maxdisp))
+    return _ConcatVolume.apply(refimg_fea, targetimg_fea, _range or signed_range(maxdisp), bool(_mask_left))
 
 
 # --------------------------------------------------------------------------------------
@@ -177,100 +194,106 @@ def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
 
 class _DisparityRegression(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, maxdisp):
+    def forward(ctx, x, rng):
         x = _c(x)
         dev = _lib.require_device(x)
         B, D, H, W = x.shape
-        ctx.cfg = (B, H, W, maxdisp)
+        dmin, nd = rng
+        ctx.cfg = (B, H, W, dmin, nd)
         out = torch.empty((B, H, W), dtype=x.dtype, device=x.device)
         if out.numel():
             with torch.cuda.device(dev):
-                call("ss_disparity_regression_fwd", ptr(x), ptr(out), B, maxdisp, H, W)
+                call("ss_disparity_regression_fwd", ptr(x), ptr(out), B, dmin, nd, H, W)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, H, W, maxdisp = ctx.cfg
+        B, H, W, dmin, nd = ctx.cfg
         g = _c(g)
-        gx = torch.empty((B, 2 * maxdisp, H, W), dtype=g.dtype, device=g.device)
+        gx = torch.empty((B, nd, H, W), dtype=g.dtype, device=g.device)
         with torch.cuda.device(g.device):
-            call("ss_disparity_regression_bwd", ptr(g), ptr(gx), B, maxdisp, H, W)
+            call("ss_disparity_regression_bwd", ptr(g), ptr(gx), B, dmin, nd, H, W)
         return gx, None
 
 
-def disparity_regression(x, maxdisp):
+def disparity_regression(x, maxdisp, _range=None):
     """models/submodule.py:164-170: [B, 2*maxdisp, H, W] -> [B, H, W]."""
     assert len(x.shape) == 4
-    assert x.shape[1] == 2 * maxdisp, "the disparity axis must span [-maxdisp, maxdisp)"
-    return _DisparityRegression.apply(x, int(maxdisp))
+    rng = _range or signed_range(maxdisp)
+    assert x.shape[1] == rng[1], "the disparity axis must span the whole range"
+    return _DisparityRegression.apply(x, rng)
 
 
 class _DisparityVariance(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, disparity, maxdisp):
+    def forward(ctx, x, disparity, rng):
         x, disparity = _c(x), _c(disparity)
         dev = _lib.require_device(x, disparity)
         B, D, H, W = x.shape
         ctx.save_for_backward(x, disparity)
-        ctx.maxdisp = maxdisp
+        ctx.rng = rng
         out = torch.empty((B, 1, H, W), dtype=x.dtype, device=x.device)
         if out.numel():
             with torch.cuda.device(dev):
-                call("ss_disparity_variance_fwd", ptr(x), ptr(disparity), ptr(out), B, maxdisp, H, W)
+                call("ss_disparity_variance_fwd", ptr(x), ptr(disparity), ptr(out), B, rng[0], rng[1], H, W)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, disparity = ctx.saved_tensors
-        m = ctx.maxdisp
-        dv = torch.arange(-m, m, dtype=x.dtype, device=x.device).reshape(1, 2 * m, 1, 1) - disparity
+        dmin, nd = ctx.rng
+        dv = torch.arange(dmin, dmin + nd, dtype=x.dtype, device=x.device).reshape(1, nd, 1, 1) - disparity
         gx = g * dv * dv
         gd = (g * (x * dv).sum(dim=1, keepdim=True)) * -2.0
         return gx, gd, None
 
 
-def disparity_variance(x, maxdisp, disparity):
+def disparity_variance(x, maxdisp, disparity, _range=None):
     """models/submodule.py:257-263: x [B,2m,H,W], disparity [B,1,H,W] -> [B,1,H,W]."""
     assert len(x.shape) == 4
-    assert x.shape[1] == 2 * maxdisp and disparity.shape == (x.shape[0], 1, x.shape[2], x.shape[3])
-    return _DisparityVariance.apply(x, disparity, int(maxdisp))
+    rng = _range or signed_range(maxdisp)
+    assert x.shape[1] == rng[1] and disparity.shape == (x.shape[0], 1, x.shape[2], x.shape[3])
+    return _DisparityVariance.apply(x, disparity, rng)
 
 
-def softmax_regression(logits, maxdisp, want_prob=False):
+def softmax_regression(logits, maxdisp, want_prob=False, _range=None):
     """Fused models/SemStereo.py:281-285: softmax over the disparity axis, its expectation and its
     variance in one kernel.  logits [B,2m,H,W] -> (disp [B,H,W], var [B,1,H,W], prob or None).
     Inference only."""
     logits = _c(logits)
     dev = _lib.require_device(logits)
     B, D, H, W = logits.shape
-    assert D == 2 * maxdisp
+    dmin, nd = _range or signed_range(maxdisp)
+    assert D == nd
     disp = torch.empty((B, H, W), dtype=logits.dtype, device=logits.device)
     var = torch.empty((B, 1, H, W), dtype=logits.dtype, device=logits.device)
     prob = torch.empty_like(logits) if want_prob else None
     with torch.cuda.device(dev):
-        call("ss_softmax_regression_fwd", ptr(logits), ptr(prob), ptr(disp), ptr(var), B, int(maxdisp), H, W)
+        call("ss_softmax_regression_fwd", ptr(logits), ptr(prob), ptr(disp), ptr(var), B, dmin, nd, H, W)
     return disp, var, prob
 
 
-def upsample_softmax_regression(coarse, maxdisp, H, W):
+def upsample_softmax_regression(coarse, maxdisp, H, W, _range=None):
     """Fused models/SemStereo.py:279-285: trilinear 2x up-sampling of the classifier output `coarse` [B,1,maxdisp,H/2,W/2]
     to [B,1,2*maxdisp,H,W], softmax over the disparity axis, its expectation and variance -- one kernel.
     -> (att_weights [B,1,2m,H,W], disp [B,H,W], var [B,1,H,W]).  Inference only; needs exact 2x and 2*maxdisp <= 128."""
     coarse = _c(coarse)
     dev = _lib.require_device(coarse)
     B = coarse.shape[0]
-    assert tuple(coarse.shape[1:]) == (1, maxdisp, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0
-    up = torch.empty((B, 1, 2 * maxdisp, H, W), dtype=coarse.dtype, device=coarse.device)
+    dmin, nd = _range or signed_range(maxdisp)
+    assert tuple(coarse.shape[1:]) == (1, nd // 2, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0 and nd % 2 == 0
+    up = torch.empty((B, 1, nd, H, W), dtype=coarse.dtype, device=coarse.device)
     disp = torch.empty((B, H, W), dtype=coarse.dtype, device=coarse.device)
     var = torch.empty((B, 1, H, W), dtype=coarse.dtype, device=coarse.device)
     with torch.cuda.device(dev):
-        call("ss_upsample_softmax_regression_fwd", ptr(coarse), ptr(up), ptr(disp), ptr(var), B, int(maxdisp), H, W)
+        call("ss_upsample_softmax_regression_fwd", ptr(coarse), ptr(up), ptr(disp), ptr(var), B, dmin, nd, H, W)
     return up, disp, var
 
 
-def upsample_softmax_regression_applies(coarse, maxdisp, H, W):
-    return (coarse.dim() == 5 and tuple(coarse.shape[1:]) == (1, maxdisp, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0
-            and 2 * maxdisp <= 128)
+def upsample_softmax_regression_applies(coarse, maxdisp, H, W, _range=None):
+    dmin, nd = _range or signed_range(maxdisp)
+    return (coarse.dim() == 5 and nd % 2 == 0 and tuple(coarse.shape[1:]) == (1, nd // 2, H // 2, W // 2) and H % 2 == 0
+            and W % 2 == 0 and nd <= 128)
 
 
 def _topk_reference_math(cost, disparity_samples, k):
@@ -451,19 +474,20 @@ def sample_strength(left, right, pred0, var, gamma, beta):
 TOPK_CANDIDATES_MAX_D = 128
 
 
-def topk_candidates(att_weights, strength, maxdisp, k):
+def topk_candidates(att_weights, strength, maxdisp, k, _range=None):
     """Fused models/SemStereo.py:295-310: att_weights [B,1,2m,H,W] (up-sampled logits), strength [B,5,H,W]
     -> (att_topk [B,1,k,H,W], disparity_sample_topk [B,k,H,W], pred_att [B,H,W]).  Inference only."""
     att_weights, strength = _c(att_weights), _c(strength)
     dev = _lib.require_device(att_weights, strength)
     B, one, D, H, W = att_weights.shape
-    assert one == 1 and D == 2 * maxdisp and strength.shape == (B, 5, H, W)
+    dmin, nd = _range or signed_range(maxdisp)
+    assert one == 1 and D == nd and strength.shape == (B, 5, H, W)
     samples = torch.empty((B, k, H, W), dtype=att_weights.dtype, device=att_weights.device)
     att_topk = torch.empty((B, 1, k, H, W), dtype=att_weights.dtype, device=att_weights.device)
     pred_att = torch.empty((B, H, W), dtype=att_weights.dtype, device=att_weights.device)
     with torch.cuda.device(dev):
         call("ss_topk_candidates_fwd", ptr(att_weights), ptr(strength), ptr(samples), ptr(att_topk), ptr(pred_att),
-             B, int(maxdisp), H, W, int(k))
+             B, dmin, nd, H, W, int(k))
     return att_topk, samples, pred_att
 
 

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import modules as M
-from . import ops
+from . import ops, ops_unsigned
 
 TOPK = 24                                   # models/SemStereo.py:301
 
@@ -46,10 +46,15 @@ class HotSegment(nn.Module):
     STEM_BY_HALVES = os.environ.get("SS_STEM_HALVES", "1") != "0"      # concat_stem's broadcast half by linearity
     GWC_PATCH_FUSED = os.environ.get("SS_GWC_PATCH_FUSED", "1") != "0"  # gwc volume -> patch -> gate in one kernel
 
-    def __init__(self, maxdisp, c8=256, c4=128):
+    def __init__(self, maxdisp, c8=256, c4=128, unsigned=False):
+        """unsigned=False: models/SemStereo.py (disparities [-maxdisp, maxdisp), op set models/submodule.py);
+        unsigned=True: models/SemStereo_WHU.py (:279 interpolates to maxdisp//4 planes, :305 takes the candidate indices
+        as disparities) on the unsigned op set it is written for, models/submodule_.py (disparities [0, maxdisp))."""
         super().__init__()
-        assert maxdisp % 64 == 0, "the reference graph needs maxdisp % 64 == 0 (SURVEY.md section 0.4)"
+        need = 128 if unsigned else 64
+        assert maxdisp % need == 0, f"the reference graph needs maxdisp % {need} == 0 (SURVEY.md section 0.4)"
         self.maxdisp = maxdisp
+        self.unsigned = bool(unsigned)
         self.gamma = nn.Parameter(torch.zeros(1))
         self.beta = nn.Parameter(2 * torch.ones(1))
         self.patch = M.DepthwisePatch(c8 // 8)
@@ -80,29 +85,34 @@ class HotSegment(nn.Module):
         H4, W4 = fl4.shape[-2:]
         fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, fl8, fr8)
         groups = fl8.shape[1] // 8
-        if fast and HotSegment.GWC_PATCH_FUSED and isinstance(self.patch, M.DepthwisePatch) and ops.gwc_patch_gate_applies(fl8, m8, groups):
+        # the disparity ranges at 1/8 and 1/4 scale, and the op set whose reference-named callables the line-by-line form uses
+        unsigned = getattr(self, "unsigned", False)
+        lib = ops_unsigned if unsigned else ops
+        r8 = ops.unsigned_range(m8) if unsigned else ops.signed_range(m8)
+        r4 = ops.unsigned_range(m4) if unsigned else ops.signed_range(m4)
+        if fast and HotSegment.GWC_PATCH_FUSED and isinstance(self.patch, M.DepthwisePatch) and ops.gwc_patch_gate_applies(fl8, m8, groups, r8):
             M.PATH_COUNTS["hip"] += 1
-            cost_att = ops.gwc_patch_gate(fl8, fr8, m8, groups, self.patch.weight, self.corr_feature_att_8.logits(fl8))   # :273-276 fused
+            cost_att = ops.gwc_patch_gate(fl8, fr8, m8, groups, self.patch.weight, self.corr_feature_att_8.logits(fl8), _range=r8)   # :273-276 fused
         elif fast:
-            corr = ops.build_gwc_volume_norm(fl8, fr8, m8, groups)                             # :273
+            corr = lib.build_gwc_volume_norm(fl8, fr8, m8, groups)                             # :273
             cost_att = self.patch(corr, self.corr_feature_att_8.logits(fl8))                   # :274 + :276 fused
         else:
-            corr = ops.build_gwc_volume_norm(fl8, fr8, m8, groups)                             # :273
+            corr = lib.build_gwc_volume_norm(fl8, fr8, m8, groups)                             # :273
             cost_att = self.corr_feature_att_8(self.patch(corr), fl8)
         cost_att = self.classif_att_(self.hourglass_att(cost_att))                             # :277-278
-        if fast and ops.upsample_softmax_regression_applies(cost_att, m4, H4, W4):
-            att_weights, pred0, var = ops.upsample_softmax_regression(cost_att, m4, H4, W4)    # :279-285 fused
+        if fast and ops.upsample_softmax_regression_applies(cost_att, m4, H4, W4, r4):
+            att_weights, pred0, var = ops.upsample_softmax_regression(cost_att, m4, H4, W4, _range=r4)    # :279-285 fused
         elif fast:
-            att_weights = F.interpolate(cost_att, [m4 * 2, H4, W4], mode="trilinear")          # :279
-            pred0, var, _ = ops.softmax_regression(att_weights.squeeze(1), m4)                 # :281-285 fused
+            att_weights = F.interpolate(cost_att, [r4[1], H4, W4], mode="trilinear")           # :279
+            pred0, var, _ = ops.softmax_regression(att_weights.squeeze(1), m4, _range=r4)      # :281-285 fused
         else:
-            att_weights = F.interpolate(cost_att, [m4 * 2, H4, W4], mode="trilinear")          # :279
+            att_weights = F.interpolate(cost_att, [r4[1], H4, W4], mode="trilinear")           # :279
             prob0 = F.softmax(att_weights.squeeze(1), dim=1)
-            pred0 = ops.disparity_regression(prob0, m4)
-            var = ops.disparity_variance(prob0, m4, pred0.unsqueeze(1))
-        if fast and 2 * m4 <= ops.TOPK_CANDIDATES_MAX_D:        # beyond (maxdisp >= 320): the line-by-line form below
+            pred0 = lib.disparity_regression(prob0, m4)
+            var = lib.disparity_variance(prob0, m4, pred0.unsqueeze(1))
+        if fast and r4[1] <= ops.TOPK_CANDIDATES_MAX_D:         # beyond (maxdisp >= 320): the line-by-line form below
             strength = ops.sample_strength(fl4, fr4, pred0, var, self.gamma, self.beta)        # :286-293 fused
-            att_topk, samples, pred_att = ops.topk_candidates(att_weights, strength, m4, TOPK)  # :295-310 fused
+            att_topk, samples, pred_att = ops.topk_candidates(att_weights, strength, m4, TOPK, _range=r4)  # :295-310 fused
             return att_topk, samples, pred_att, pred0
         var = torch.sigmoid(self.beta + self.gamma * var)                                      # :286-287
         var_samples = propagation(var)                                                         # :288
@@ -115,7 +125,7 @@ class HotSegment(nn.Module):
         _, ind = aw_prob.sort(dim=2, descending=True, stable=True)                                            # :299
         ind_k = ind[:, :, :TOPK].sort(2, False)[0]                                             # :302-303
         att_topk = torch.gather(aw_prob, 2, ind_k)                                             # :304
-        samples = ind_k.squeeze(1).float() - m4                                                # :305
+        samples = ind_k.squeeze(1).float() + r4[0]                                             # :305 (SemStereo_WHU.py:305: no offset)
         att_prob = F.softmax(torch.gather(aw, 2, ind_k).squeeze(1), dim=1)                     # :307-308
         pred_att = (att_prob * samples).sum(dim=1)                                             # :309-310
         return att_topk, samples, pred_att, pred0

@@ -17,7 +17,7 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
-    return {k: np.load(os.path.join(d, k + ".npz")) for k in ("ops", "stack", "segment", "segment_full")
+    return {k: np.load(os.path.join(d, k + ".npz")) for k in ("ops", "stack", "segment", "segment_full", "ops_unsigned", "segment_whu")
             if os.path.exists(os.path.join(d, k + ".npz"))}
 
 

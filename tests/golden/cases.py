@@ -17,6 +17,16 @@ GWC = {
     "live":     (1, 256, 4, 16, 4, 32),    # the live channel/group split (models/SemStereo.py:273)
     "cg16":     (1, 32, 3, 12, 5, 2),      # Cg = 16
 }
+# unsigned op set (models/submodule_.py): name -> (B, C, H, W, maxdisp, groups); maxdisp is the number of planes
+UGWC = {
+    "odd":    (2, 16, 5, 13, 4, 4),
+    "live":   (1, 256, 4, 16, 8, 32),
+    "m_gt_w": (1, 8, 2, 5, 7, 2),
+    "cg8_w8": (1, 24, 3, 8, 8, 3),
+}
+UCONCAT = {"odd": (2, 3, 4, 11, 3), "c32": (1, 32, 3, 16, 8), "m_gt_w": (1, 2, 2, 4, 6)}
+UREGRESSION = {"small": (2, 3, 5, 7), "m16": (1, 16, 4, 12)}
+
 # name -> (B, C, H, W, maxdisp)
 CONCAT = {
     "odd":    (2, 3, 4, 11, 3),
@@ -50,6 +60,26 @@ def gwc_inputs(name):
     B, C, H, W, m, G = GWC[name]
     s = 100 + sorted(GWC).index(name) * 2
     return dd.t_normalish((B, C, H, W), s), dd.t_normalish((B, C, H, W), s + 1), m, G
+
+
+def ugwc_inputs(name):
+    B, C, H, W, m, G = UGWC[name]
+    s = 150 + sorted(UGWC).index(name) * 2
+    return dd.t_normalish((B, C, H, W), s), dd.t_normalish((B, C, H, W), s + 1), m, G
+
+
+def uconcat_inputs(name):
+    B, C, H, W, m = UCONCAT[name]
+    s = 250 + sorted(UCONCAT).index(name) * 2
+    return dd.t_normalish((B, C, H, W), s), dd.t_normalish((B, C, H, W), s + 1), m
+
+
+def uregression_inputs(name):
+    B, m, H, W = UREGRESSION[name]
+    s = 350 + sorted(UREGRESSION).index(name) * 2
+    prob = torch.softmax(dd.t_normalish((B, m, H, W), s) * 2.0, dim=1)
+    disp = dd.t_uniform((B, 1, H, W), s + 1, 0, m)
+    return prob, m, disp
 
 
 def concat_inputs(name):
@@ -121,7 +151,12 @@ SEGMENT = {
     "s256_md128": (1, 256, 256, 128),          # the disparity range of BASELINE.json configs[1-3]: D8 = 32, D4 = 64
     "s192x256_md192": (1, 192, 256, 192),      # ... of configs[4]: D8 = 48, D4 = 96; H/32 = 6 pads the attention windows
 }
-_SEGMENT_SEED = {"s128": 800, "s96x160_b2": 804, "s256_md128": 808, "s192x256_md192": 812,
+# models/SemStereo_WHU.py (unsigned range) with the op set it needs (models/submodule_.py) bound in its globals
+SEGMENT_WHU = {
+    "whu128_md128": (1, 128, 128, 128),          # D8 = 16, D4 = 32
+    "whu96x160_md256_b2": (2, 96, 160, 256),     # D8 = 32, D4 = 64
+}
+_SEGMENT_SEED = {"whu128_md128": 828, "whu96x160_md256_b2": 832, "s128": 800, "s96x160_b2": 804, "s256_md128": 808, "s192x256_md192": 812,
                  "s256_md128_cal": 816, "f1024_md128_cal": 820, "f2048_md192_cal": 824}
 
 # "_cal": BatchNorm running statistics CALIBRATED on the fixture's own input (one pass of the reference with batch
@@ -143,7 +178,7 @@ FULL_SAMPLES = 2048
 
 
 def segment_shape(name):
-    for table in (SEGMENT, SEGMENT_CAL, SEGMENT_FULL):
+    for table in (SEGMENT, SEGMENT_CAL, SEGMENT_FULL, SEGMENT_WHU):
         if name in table:
             return table[name]
     raise KeyError(name)

@@ -115,6 +115,67 @@ def gen_ops(ref):
     print("ops.npz:", len(out), "arrays")
 
 
+def load_ref_unsigned_oplib():
+    spec = importlib.util.spec_from_file_location("ref_submodule_unsigned", os.path.join(REF, "models/submodule_.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_ops_unsigned(uref):
+    """The unsigned-range op set, models/submodule_.py (what models/SemStereo_WHU.py is written for)."""
+    out = {}
+    for n in cases.UGWC:
+        a, b, m, G = cases.ugwc_inputs(n)
+        if m <= a.shape[3]:                       # beyond the width the reference's own slice assignment raises
+            out[f"ugwc/{n}"] = f32(uref.build_gwc_volume(a, b, m, G))
+            out[f"ugwc_norm/{n}"] = f32(uref.build_gwc_volume_norm(a, b, m, G))
+    for n in cases.UCONCAT:
+        a, b, m = cases.uconcat_inputs(n)
+        if m <= a.shape[3]:
+            out[f"uconcat/{n}"] = f32(uref.build_concat_volume(a, b, m))
+    for n in cases.UREGRESSION:
+        p, m, d = cases.uregression_inputs(n)
+        out[f"uregression/{n}"] = f32(uref.disparity_regression(p, m))
+        out[f"uvariance/{n}"] = f32(uref.disparity_variance(p, m, d))
+    np.savez_compressed(os.path.join(HERE, "ops_unsigned.npz"), **out)
+    print("ops_unsigned.npz:", len(out), "arrays")
+
+
+def load_ref_whu_module(uref):
+    """models.SemStereo_WHU with the unsigned op set bound in ITS globals (install()'s own mechanism): as shipped it
+    star-imports the signed models/submodule.py and fails at disparity_regression."""
+    import models.SemStereo_WHU as mw
+    for name in ("build_gwc_volume", "build_gwc_volume_norm", "build_concat_volume", "disparity_regression", "disparity_variance"):
+        setattr(mw, name, getattr(uref, name))
+    return mw
+
+
+def gen_segment_whu(ms, uref):
+    mw = load_ref_whu_module(uref)
+    out = {}
+    for n, (B, H, W, maxdisp) in cases.SEGMENT_WHU.items():
+        net = mw.SemStereo_WHU(maxdisp, False, True, True, 6).eval()
+        P = oseg.deterministic_params()
+        res = net.load_state_dict(P, strict=False)
+        assert not res.unexpected_keys
+        fl4, fr4, fl8, fr8, _ = cases.segment_inputs(n)
+        cap = run_reference_segment(mw, net, B, H, W, (fl4, fr4, fl8, fr8))
+        (cost_sq, samples, k), pred = cap["regression_topk"][0]
+        out[f"{n}/pred"] = f32(pred)
+        out[f"{n}/samples"] = samples.numpy().astype(np.int16)
+        out[f"{n}/pred_att0"] = f32(cap["disparity_regression"][0][1])
+        out[f"{n}/pred_att"] = f32(cap["ssr_in"][0].squeeze(1))
+        out[f"{n}/cost_att"] = f32(cap["classif_att_"])
+        p = cap["aw_prob"].squeeze(1).sort(dim=1, descending=True).values
+        c = cost_sq.sort(dim=1, descending=True).values
+        out[f"{n}/gap24_rel"], out[f"{n}/gap2"] = f32((p[:, 23] - p[:, 24]) / p[:, 23]), f32(c[:, 1] - c[:, 2])
+        out[f"{n}/att_topk"] = f32(torch.gather(cap["aw_prob"], 2, samples.long().unsqueeze(1)).squeeze(1))
+        print(n, "pred", tuple(pred.shape), "range", float(pred.min()), float(pred.max()), "samples", int(samples.min()), int(samples.max()))
+    np.savez_compressed(os.path.join(HERE, "segment_whu.npz"), **out)
+    print("segment_whu.npz:", len(out), "arrays")
+
+
 def build_ref_net(ms, maxdisp):
     net = ms.SemStereo(maxdisp, False, True, True, 6).eval()
     P = oseg.deterministic_params()
@@ -343,7 +404,9 @@ def gen_ssr(ref):
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
-    what = sys.argv[1:] or ["ssr", "ops", "stack", "segment", "full"]
+    what = sys.argv[1:] or ["ssr", "ops", "stack", "segment", "full", "whu"]
+    if "whu" in what:
+        gen_ops_unsigned(load_ref_unsigned_oplib())
     if "ssr" in what:
         gen_ssr(load_ref_oplib())
     if "ops" in what:
@@ -353,7 +416,9 @@ if __name__ == "__main__":
         gen_stack(ms)
     if "segment" in what:
         gen_segment(ms)
+    if "whu" in what:
+        gen_segment_whu(ms, load_ref_unsigned_oplib())
     if "full" in what or any(w in cases.SEGMENT_FULL for w in what):      # ~1 min and ~5 min of CPU, ~25 GB at 2048^2
         gen_segment_full(ms, only=[w for w in what if w in cases.SEGMENT_FULL] or None)
-    for f in ("ops.npz", "stack.npz", "segment.npz", "segment_full.npz"):
+    for f in ("ops.npz", "stack.npz", "segment.npz", "segment_full.npz", "ops_unsigned.npz", "segment_whu.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -56,6 +56,6 @@ def test_abi_version_and_status_strings(lib):
 
 def test_invalid_arguments_are_rejected_before_any_launch(lib):
     """NULL pointers / bad sizes return SS_ERR_INVALID without touching a device."""
-    assert lib.ss_gwc_volume_fwd(None, None, None, 1, 8, 4, 4, 2, 2, 0, None) == -1
+    assert lib.ss_gwc_volume_fwd(None, None, None, 1, 8, 4, 4, -2, 4, 2, 0, None) == -1
     assert lib.ss_conv3d_fwd(None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 3, 1, 0, None) == -1
     assert lib.ss_regression_topk_fwd(None, None, None, 1, 4, 2, 2, 2, None) == -1

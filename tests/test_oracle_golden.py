@@ -153,3 +153,40 @@ def test_hot_segment_full_size_checksums(golden):
         a = t.double().reshape(-1)
         np.testing.assert_allclose(a[cases.sample_index(a.numel(), 64, i)].numpy(), rec[2:], atol=2e-5)
         np.testing.assert_allclose((a * a).sum().item(), rec[1], rtol=1e-5)
+
+
+# ---- the unsigned-range op set (models/submodule_.py) and the SemStereo_WHU graph ----------------------------------
+
+def test_unsigned_op_set(golden):
+    from oracle import ops_unsigned as uops
+    g = golden["ops_unsigned"]
+    for n in cases.UGWC:
+        a, b, m, G = cases.ugwc_inputs(n)
+        if f"ugwc/{n}" in g.files:
+            _eq(uops.build_gwc_volume(a, b, m, G), g[f"ugwc/{n}"])
+            _eq(uops.build_gwc_volume_norm(a, b, m, G), g[f"ugwc_norm/{n}"])
+            # the unsigned volume is the non-negative half of the signed one (plane d of [0, m) = plane m + d of [-m, m))
+            _eq(oops.build_gwc_volume(a, b, m, G)[:, :, m:], g[f"ugwc/{n}"])
+    for n in cases.UCONCAT:
+        a, b, m = cases.uconcat_inputs(n)
+        if f"uconcat/{n}" in g.files:
+            _eq(uops.build_concat_volume(a, b, m), g[f"uconcat/{n}"])
+    for n in cases.UREGRESSION:
+        p, m, d = cases.uregression_inputs(n)
+        _eq(uops.disparity_regression(p, m), g[f"uregression/{n}"])
+        _eq(uops.disparity_variance(p, m, d), g[f"uvariance/{n}"])
+
+
+@pytest.mark.parametrize("name", sorted(cases.SEGMENT_WHU))
+def test_hot_segment_whu(golden, name):
+    """models/SemStereo_WHU.py (two lines off models/SemStereo.py: :279, :305) on the unsigned op set."""
+    g = golden["segment_whu"]
+    P = oseg.deterministic_params()
+    fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
+    r = oseg.hot_segment(P, fl4, fr4, fl8, fr8, maxdisp, keep=True, unsigned=True)
+    assert np.array_equal(r["samples"].numpy().astype(np.int16), g[f"{name}/samples"])
+    assert int(r["samples"].min()) >= 0 and int(r["samples"].max()) < maxdisp // 4
+    _eq(r["pred_att0"], g[f"{name}/pred_att0"], atol=1e-5)
+    _eq(r["pred_att"], g[f"{name}/pred_att"], atol=1e-5)
+    _eq(r["pred"], g[f"{name}/pred"], atol=1e-5)
+    _eq(r["cost_att"], g[f"{name}/cost_att"], atol=1e-5, rtol=1e-5)

@@ -1333,3 +1333,60 @@ def test_hot_segment_training_step_runs_on_the_hip_stack(sa):
         worst = max(worst, float((g - ref).abs().max()) / (float(ref.abs().max()) + 1e-12))
     REPORT["segment_train/worst_relative_grad_diff"] = worst
     assert worst <= 5e-3, worst           # top-k picks and batch statistics amplify fp32 rounding; typical 1e-5
+
+
+# --------------------------------------------------------------------------------------
+# the unsigned-range op set (models/submodule_.py) and the SemStereo_WHU graph (VERDICT r1 missing #3)
+# --------------------------------------------------------------------------------------
+
+def test_unsigned_op_set_vs_reference_fixture(sa, golden):
+    from oracle import ops_unsigned as uops
+    U = sa.ops_unsigned
+    g = golden["ops_unsigned"]
+    for n in sorted(cases.UGWC):
+        a, b, m, G = cases.ugwc_inputs(n)
+        ref = g[f"ugwc/{n}"] if f"ugwc/{n}" in g.files else uops.build_gwc_volume(a, b, m, G)
+        refn = g[f"ugwc_norm/{n}"] if f"ugwc_norm/{n}" in g.files else uops.build_gwc_volume_norm(a, b, m, G)
+        check(f"ugwc/{n}", U.build_gwc_volume(dev(a), dev(b), m, G), ref, 1e-6)
+        check(f"ugwc_norm/{n}", U.build_gwc_volume_norm(dev(a), dev(b), m, G), refn, 2e-6)
+    for n in sorted(cases.UCONCAT):
+        a, b, m = cases.uconcat_inputs(n)
+        ref = g[f"uconcat/{n}"] if f"uconcat/{n}" in g.files else uops.build_concat_volume(a, b, m)
+        check(f"uconcat/{n}", U.build_concat_volume(dev(a), dev(b), m), ref, 0.0)
+    for n in sorted(cases.UREGRESSION):
+        p, m, d = cases.uregression_inputs(n)
+        check(f"uregression/{n}", U.disparity_regression(dev(p), m), g[f"uregression/{n}"], 2e-6)
+        check(f"uvariance/{n}", U.disparity_variance(dev(p), m, dev(d)), g[f"uvariance/{n}"], 2e-5, 1e-6)
+    # backward of the unsigned volume builders against the oracle's autograd
+    from oracle import detdata as dd
+    a, b = dd.t_normalish((2, 16, 5, 12), 871), dd.t_normalish((2, 16, 5, 12), 872)
+    seed = dd.t_normalish((2, 4, 8, 5, 12), 873)
+    gh = _grads(lambda p, q: U.build_gwc_volume_norm(p, q, 8, 4), [dev(a), dev(b)], lambda y: dev(seed))
+    go = _grads(lambda p, q: uops.build_gwc_volume_norm(p, q, 8, 4), [a, b], lambda y: seed)
+    for i, (x, r) in enumerate(zip(gh, go)):
+        check(f"bwd/ugwc_norm/{i}", x, r, 2e-5)
+    seed = dd.t_normalish((2, 32, 8, 5, 12), 874)
+    gh = _grads(lambda p, q: U.build_concat_volume(p, q, 8), [dev(a), dev(b)], lambda y: dev(seed))
+    go = _grads(lambda p, q: uops.build_concat_volume(p, q, 8), [a, b], lambda y: seed)
+    for i, (x, r) in enumerate(zip(gh, go)):
+        check(f"bwd/uconcat/{i}", x, r, 1e-5)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", sorted(cases.SEGMENT_WHU))
+def test_hot_segment_whu_vs_reference_fixture(sa, golden, name, fused):
+    """HotSegment(unsigned=True) = models/SemStereo_WHU.py:273-323 on the unsigned op set (fixture: the reference's own
+    SemStereo_WHU with models/submodule_.py's definitions bound in its globals), fused kernels and line-by-line form."""
+    B, H, W, maxdisp = cases.segment_shape(name)
+    seg = sa.HotSegment(maxdisp, unsigned=True)
+    P = oseg.deterministic_params()
+    seg.load_state_dict(P, strict=False)
+    seg = seg.cuda().eval()
+    seg.FUSED = fused
+    fl4, fr4, fl8, fr8, _ = cases.segment_inputs(name)
+    with torch.no_grad():
+        r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
+    g = golden["segment_whu"]
+    assert float(r["samples"].min()) >= 0 and float(r["samples"].max()) < maxdisp // 4
+    check(f"whu/{name}/{fused}/pred_att0", r["pred_att0"], g[f"{name}/pred_att0"], 1e-3)
+    _explained_deviation_check(f"whu/{name}/{fused}", r, g, name)
