@@ -79,7 +79,7 @@ def _group_normalise(x, groups):
     return (v / (torch.linalg.vector_norm(v, 2, dim=2, keepdim=True) + 1e-05)).reshape(B, C, H, W)
 
 
-def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None):
+def _build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None):
     """models/submodule.py:198-211 -> [B, G, 2*maxdisp, H, W] (signed disparity range)."""
     _check_pair(refimg_fea, targetimg_fea, num_groups)
     rng = _range or signed_range(maxdisp)
@@ -88,7 +88,7 @@ def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None
     return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), rng, int(num_groups), False)
 
 
-def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None):
+def _build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None):
     """models/submodule.py:224-238 (the live call, models/SemStereo.py:273)."""
     _check_pair(refimg_fea, targetimg_fea, num_groups)
     rng = _range or signed_range(maxdisp)
@@ -182,7 +182,7 @@ class _ConcatVolume(torch.autograd.Function):
         return gref, gtgt, None, None
 
 
-def build_concat_volume(refimg_fea, targetimg_fea, maxdisp, _range=None, _mask_left=True):
+def _build_concat_volume(refimg_fea, targetimg_fea, maxdisp, _range=None, _mask_left=True):
     """models/submodule.py:173-187 -> [B, 2C, 2*maxdisp, H, W]."""
     _check_pair(refimg_fea, targetimg_fea)
     return _ConcatVolume.apply(refimg_fea, targetimg_fea, _range or signed_range(maxdisp), bool(_mask_left))
@@ -216,7 +216,7 @@ class _DisparityRegression(torch.autograd.Function):
         return gx, None
 
 
-def disparity_regression(x, maxdisp, _range=None):
+def _disparity_regression(x, maxdisp, _range=None):
     """models/submodule.py:164-170: [B, 2*maxdisp, H, W] -> [B, H, W]."""
     assert len(x.shape) == 4
     rng = _range or signed_range(maxdisp)
@@ -248,7 +248,7 @@ class _DisparityVariance(torch.autograd.Function):
         return gx, gd, None
 
 
-def disparity_variance(x, maxdisp, disparity, _range=None):
+def _disparity_variance(x, maxdisp, disparity, _range=None):
     """models/submodule.py:257-263: x [B,2m,H,W], disparity [B,1,H,W] -> [B,1,H,W]."""
     assert len(x.shape) == 4
     rng = _range or signed_range(maxdisp)
@@ -501,6 +501,33 @@ def channel_gate(att_logits, cv):
     with torch.cuda.device(dev):
         call("ss_channel_gate_fwd", ptr(att_logits), ptr(cv), ptr(out), B, C, D, H, W)
     return out
+
+
+# ---- the reference's exact signatures (models/submodule.py: signed range); the `_name` forms above also take a range ----
+
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """models/submodule.py:198-211 -> [B, G, 2*maxdisp, H, W] (signed disparity range)."""
+    return _build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups)
+
+
+def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """models/submodule.py:224-238 (the live call, models/SemStereo.py:273)."""
+    return _build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups)
+
+
+def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
+    """models/submodule.py:173-187 -> [B, 2C, 2*maxdisp, H, W]."""
+    return _build_concat_volume(refimg_fea, targetimg_fea, maxdisp)
+
+
+def disparity_regression(x, maxdisp):
+    """models/submodule.py:164-170: [B, 2*maxdisp, H, W] -> [B, H, W]."""
+    return _disparity_regression(x, maxdisp)
+
+
+def disparity_variance(x, maxdisp, disparity):
+    """models/submodule.py:257-263: x [B,2m,H,W], disparity [B,1,H,W] -> [B,1,H,W]."""
+    return _disparity_variance(x, maxdisp, disparity)
 
 
 #: names the reference model module resolves by bare global (SURVEY.md section 8b)

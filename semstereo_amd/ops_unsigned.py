@@ -14,28 +14,28 @@ from .ops import (SpatialTransformer_grid, groupwise_correlation, groupwise_corr
 
 def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
     """models/submodule_.py:188-198 -> [B, G, maxdisp, H, W]."""
-    return ops.build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=unsigned_range(maxdisp))
+    return ops._build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=unsigned_range(maxdisp))
 
 
 def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups):
     """models/submodule_.py:211-221 -> [B, G, maxdisp, H, W]."""
-    return ops.build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=unsigned_range(maxdisp))
+    return ops._build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=unsigned_range(maxdisp))
 
 
 def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
     """models/submodule_.py:166-177 -> [B, 2C, maxdisp, H, W]; the left half is copied UNMASKED, only the shifted right
     half is zero where its partner column leaves the image."""
-    return ops.build_concat_volume(refimg_fea, targetimg_fea, maxdisp, _range=unsigned_range(maxdisp), _mask_left=False)
+    return ops._build_concat_volume(refimg_fea, targetimg_fea, maxdisp, _range=unsigned_range(maxdisp), _mask_left=False)
 
 
 def disparity_regression(x, maxdisp):
     """models/submodule_.py:159-163: [B, maxdisp, H, W] -> [B, H, W], disparity values 0 .. maxdisp-1."""
-    return ops.disparity_regression(x, maxdisp, _range=unsigned_range(maxdisp))
+    return ops._disparity_regression(x, maxdisp, _range=unsigned_range(maxdisp))
 
 
 def disparity_variance(x, maxdisp, disparity):
     """models/submodule_.py:239-245."""
-    return ops.disparity_variance(x, maxdisp, disparity, _range=unsigned_range(maxdisp))
+    return ops._disparity_variance(x, maxdisp, disparity, _range=unsigned_range(maxdisp))
 
 
 #: names models/SemStereo_WHU.py resolves by bare global
