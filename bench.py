@@ -185,6 +185,8 @@ def main():
                     "fp32 oracle's time) that tells kernel error from the reference algorithm's own conditioning")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the oracle run")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (one launch per step instead "
+                    "of ~45 from Python); the per-kernel HIP-event timers are off in this mode")
     ap.add_argument("--dry-launch", action="store_true", help="CPU rehearsal of the N-rank control flow over gloo "
                     "(launcher, rendezvous, barriers, metric reduction, teardown) with a stand-in step; measures nothing")
     args = ap.parse_args()
@@ -249,6 +251,22 @@ def main():
             return seg(*feats)
     if dry:
         step = dry_step_factory(device)
+    graphed = False
+    if args.graph and not dry:
+        # capture one step (both streams of the segment join the capture through their event waits) and replay it
+        args.no_kernel_timers = True
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = step()
+        eager_step = step
+
+        def step():                                                  # noqa: F811
+            graph.replay()
+            return static_out
+        graphed = True
 
     def timed_run(nsteps, nwarm, kernel_timers=False):
         """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks.
@@ -335,6 +353,7 @@ def main():
                    "pairs_per_gpu_per_step": B, "parallelism": f"pairs sharded over {world} rank(s), no collective in the forward",
                    "weights": "random init at unit gain (see init_unit_gain), BatchNorm eval",
                    "conv_engine": engine, "conv_engine_note": engine_note},
+        "hip_graph": graphed,
         "pairs_per_s_by_conv_engine": by_engine,
         "pairs_per_s_reference_forward_untouched": unfused_rate,
     }

@@ -25,14 +25,14 @@
 #include "common.h"
 #include "split_f16.h"
 
-#ifdef SS_TIMING     // phase timestamps of every workgroup (tools/wg_phases.py); not part of the product build
-__device__ unsigned long long ss_dbg_t[8 * 16384];
-extern "C" int ss_debug_read(unsigned long long* dst, int n) {
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ss_dbg_t), (size_t)n * 8) == hipSuccess ? 0 : -1;
-}
-#define SS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384 && blockIdx.y == 0 && blockIdx.z == 0) ss_dbg_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
+// Phase stamps of a workgroup: no-ops here.  tools/conv_timing.hip defines SS_STAMP / SS_STAMP_STEPS_* before including this
+// file to build the instrumented library tools/wg_phases.py reads (tools/build_timing.sh); the product build has no
+// instrumentation in it.
+#ifndef SS_STAMP
 #define SS_STAMP(k) do {} while (0)
+#define SS_STAMP_STEPS_BEGIN() do {} while (0)
+#define SS_STAMP_STEPS_END() do {} while (0)
+#define SS_STAMP_FINISH() do {} while (0)
 #endif
 
 namespace {
@@ -41,18 +41,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
 constexpr int KSTEPS = 14;        // ceil(27 taps / 2): the 3-D kernels (BCfg::KSTEPS is the general form)
-#ifndef SS_IN_STEPS
-#define SS_IN_STEPS 10            // K-steps over which the next chunk's input loads are issued
-#endif
-#ifndef SS_IN_AUX
-#define SS_IN_AUX 0               // cache policy bits of the activation loads (buffer_load aux: 1 = sc0, 2 = nt)
-#endif
-#ifndef SS_ROW_PAIR
-#define SS_ROW_PAIR 1             // rows whose MFMAs alternate; 2 measured 1 % slower: the other wave of the SIMD already fills the gaps
-#endif
-#ifndef SS_A_AHEAD
-#define SS_A_AHEAD 2              // K-steps between the load of a weight fragment and its MFMAs
-#endif
+// measured-best settings (each was swept on the bench shapes)
+constexpr int SS_IN_STEPS = 10;   // K-steps over which the next chunk's input loads are issued
+constexpr int SS_IN_AUX = 0;      // cache policy bits of the activation loads (buffer_load aux: 1 = sc0, 2 = nt)
+constexpr int SS_ROW_PAIR = 1;    // rows whose MFMAs alternate; 2 measured 1 % slower: the other wave of the SIMD already fills the gaps
+constexpr int SS_A_AHEAD = 2;     // K-steps between the load of a weight fragment and its MFMAs
+constexpr int SS_F16_WGS = 2;     // workgroups per CU the fp16 form is compiled for (3 = 168 VGPRs: spills, +29 %)
+constexpr int SS_EPI_GROUP = 8;   // fragment rows whose side inputs (gate, residual) are fetched together in the epilogue
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {       // finite inputs
     unsigned u = __float_as_uint(x);
@@ -100,11 +95,7 @@ struct BCfg {
 };
 
 constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
-#ifdef SS_NO_WLDS      // A/B builds (tools)
-    return false;
-#else
     return NTERMS == 19 && S == 1 && NT == 1 && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
-#endif
 }
 
 // GATED: the channelAtt gate is fused into the epilogue (only concat_stem has one, so its launches also carry
@@ -112,9 +103,6 @@ constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
 // MT: 32-channel output tiles per wave (the activation fragments of a row then feed MT x 6 MFMAs: used by the stride-2
 // layers, whose staging is 8x dearer per MFMA and whose 2-4 output tiles would otherwise each stage the same input)
 template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
-#ifndef SS_F16_WGS
-#define SS_F16_WGS 2              // workgroups per CU the fp16 form is compiled for
-#endif
 __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
@@ -151,11 +139,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // relu bit 0: ReLU; bit 1: `residual` is added BEFORE the affine: a partial sum of the same convolution computed
     // elsewhere (stem_left.hip).  It joins the accumulator in the epilogue, fetched together with the gate (as initial
     // accumulators its 64 loads per lane were 14 k cycles of every workgroup's prologue: tools/wg_phases.py).
-#ifdef SS_ABL_RES
-    const bool res_pre = false;
-#else
     const bool res_pre = (relu & 2) != 0 && residual != nullptr;
-#endif
     // f16 form: float[Cout] of 2^-(weight scale of the channel), stored behind the packed terms
     const float* wunscale = reinterpret_cast<const float*>(
         reinterpret_cast<const char*>(wsplit) + (size_t)((Cin + 7) / 8) * C::KSTEPS * ((NTERMS == F16X3 ? 2 : 3) * 2 * Cout * 16));
@@ -278,12 +262,8 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     }
     SS_STAMP(1);
 
-#ifdef SS_TIMING
-    long long t_steps = 0;
-#endif
     for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
         // ---- split + transpose: registers -> [term][position][8 ch] ----
-        // (SS_ABL_*: timing ablations built by tools/ablate_conv.sh only -- results are wrong with them)
         if constexpr (WLDS) {         // this chunk's weights: wave w issues the (K-step, term) pairs i = w, w + 4, ...; lane -> (half, channel)
 #pragma unroll
             for (int k = 0; k < (KSTEPS * 2 + 3) / 4; ++k) {
@@ -292,7 +272,6 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                     lds_dma16(wres, &lds[WL + i * 64], wlane[0], (g0 + i / 2) * wstep + (i & 1) * 2 * Cout * 16);
             }
         }
-#ifndef SS_ABL_SPLIT
         float in_scale = 1.f;
         if (F16) {
             const uint4 wm = lds[ZSLOT + 1];
@@ -324,17 +303,12 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             lds[1 * C::CS + p] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
             if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
         }
-#endif
         if (WLDS) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the LDS-DMA weight loads have landed
-#ifndef SS_ABL_BAR1
         __syncthreads();
-#endif
         const bool more = ci0 + 8 < Cin;
         nlive_next = min(8, Cin - ci0 - 8);
         const unsigned nomore = more ? 0u : 0x80000000u;
-#ifdef SS_TIMING
-        const long long tk0 = __builtin_readcyclecounter();
-#endif
+        SS_STAMP_STEPS_BEGIN();
 
         // B fragments are read one row GROUP ahead of their MFMAs.  With RP = 2 the MFMAs of two rows
         // alternate so that no two consecutive ones share an accumulator (SS_ROW_PAIR; no gain measured).
@@ -362,7 +336,6 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             // wait-count pass cannot tell how many loads are younger than the one it waits for and falls back to
             // vmcnt(0/1) -- every K-step then waited for the input loads it had just issued (seen in the ISA).  Past the
             // end, the last fragment is requested again and the input loads get an offset beyond the buffer (no access).
-#ifndef SS_ABL_A
             if (!WLDS) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -372,12 +345,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
                 for (int c = 0; c < NC; ++c) aq[(s + 1) % AR][0][c] = lds[WL + ((s + 1) * 2 + c) * 64 + lane];
             }
-#endif
-#ifndef SS_ABL_IN
 #pragma unroll
             for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q)
                 rin[q] = load_in_masked(min(ci0 + 8, Cin - 1) + min(q / C::NPOS, max(nlive_next, 1) - 1), q % C::NPOS, nomore);
-#endif
             uint4 a[MT][NC];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -387,13 +357,8 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             for (int i0 = 0; i0 < NT; i0 += RP) {
 #pragma unroll
                 for (int r = 0; r < RP; ++r) {
-#ifndef SS_ABL_B
                     if (i0 + RP < NT) read_b(bnxt[r], s, i0 + RP + r);
                     else if (s + 1 < KSTEPS) read_b(bnxt[r], s + 1, r);
-#else
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) bnxt[r][c] = bcur[r][c];
-#endif
                 }
                 // cross terms (a term, b term), smallest first; rows of the group alternate
                 constexpr int NP = (NTERMS == 6) ? 6 : 3;
@@ -404,10 +369,6 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int r = 0; r < RP; ++r) {
-#ifdef SS_ABL_MFMA      // one cheap VALU op per MFMA that keeps both operands live
-                            acc[mt * NT + i0 + r][p] += __uint_as_float(a[mt][pa[p]].x ^ bcur[r][pb[p]].y);
-                            continue;
-#endif
                             if (F16)
                                 acc[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                     __builtin_bit_cast(f16x8, a[mt][pa[p]]), __builtin_bit_cast(f16x8, bcur[r][pb[p]]),
@@ -421,13 +382,11 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                 for (int r = 0; r < RP; ++r)
 #pragma unroll
                     for (int c = 0; c < NC; ++c) bcur[r][c] = bnxt[r][c];
-#ifndef SS_NO_SGB
                 // pin the software pipeline: the next group's fragment reads are issued BEFORE this
                 // group's MFMAs (the scheduler otherwise sinks them next to their use and every row
                 // starts with an exposed LDS latency)
                 __builtin_amdgcn_sched_group_barrier(0x100, NC * RP, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NP * RP * MT, 0);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);     // keep each step's loads inside the step
         }
@@ -448,15 +407,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                     for (int c = 0; c < NC; ++c) aq[k][mt][c] = tq[k][mt][c];
         }
         nlive = nlive_next;
-#ifdef SS_TIMING
-        t_steps += (long long)__builtin_readcyclecounter() - tk0;
-#endif
-#ifndef SS_ABL_MAX
+        SS_STAMP_STEPS_END();
         if (F16 && more) publish_max(0.f);
-#endif                        // of the chunk staged next (its loads were issued >= 4 K-steps ago)
-#ifndef SS_ABL_BAR2
         __syncthreads();
-#endif
     }
 
     SS_STAMP(2);
@@ -475,9 +428,6 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const float floor_v = (relu & 1) ? 0.f : -__builtin_inff();
     // the side inputs (affine, gate, residual) of a group of EG fragment rows are fetched first so that their latencies
     // overlap instead of chaining; every group costs one exposed round trip (load -> store -> the next group's loads)
-#ifndef SS_EPI_GROUP
-#define SS_EPI_GROUP 8
-#endif
     constexpr int EG = SS_EPI_GROUP;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -526,23 +476,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                 if (res_epi) v = ss::add_rn(v, rv[q][i]);
                 v = fmaxf(v, floor_v);
                 if (GATED) v = ss::mul_rn(gv[q][i], v);     // channelAtt gate, broadcast over D
-#ifdef SS_ABL_STORE
-                if (v == 123456.f)
-#endif
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)(cok ? vout[i] : 0x80000000u),
                                                       cb * (int)ochan_b, 0);
             }
         }
     }
     SS_STAMP(3);
-#ifdef SS_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 16384 && blockIdx.y == 0 && blockIdx.z == 0) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        ss_dbg_t[blockIdx.x * 8 + 4] = hw;
-        ss_dbg_t[blockIdx.x * 8 + 5] = (unsigned long long)t_steps;
-    }
-#endif
+    SS_STAMP_FINISH();
 }
 
 // [Cout,Cin,3,3,3] fp32 -> [ceil(Cin/8)][14 steps][3 terms][2 halves][Cout][8] bf16 (zero padded)

@@ -17,15 +17,6 @@
 #include "common.h"
 #include "split_f16.h"
 
-#ifdef SS_TIMING     // phase timestamps of every workgroup (development builds only)
-__device__ unsigned long long ss_dbgd_t[8 * 8192];
-extern "C" int ss_debug_read_d(unsigned long long* dst, int n) {
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ss_dbgd_t), (size_t)n * 8) == hipSuccess ? 0 : -1;
-}
-#define SS_DSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0 && blockIdx.z == 0) ss_dbgd_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define SS_DSTAMP(k) do {} while (0)
-#endif
 
 namespace {
 
@@ -228,8 +219,6 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
 
 
     const bool skip_first = HAS_SKIP && ((blockIdx.x ^ blockIdx.y) & 1);
-    SS_DSTAMP(0);
-#ifndef SS_ABL_D_SKIP
     if (HAS_SKIP && skip_first) {
         skip_phase();
         if (F16) {      // the main loop's accumulators carry the channel's weight scale (a power of two: exact)
@@ -242,7 +231,6 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             }
         }
     }
-#endif
     // fp16 form: block-floating scale of the staged chunk (see conv3d_bf16s.hip)
     int e_cur = E_ONE, e_run = E_MIN;
     auto publish_max = [&](float m) {
@@ -263,12 +251,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         publish_max(m0);
         __syncthreads();
     }
-#ifdef SS_ABL_D_MAIN
-    const int nchunks_run = 0;
-#else
     const int nchunks_run = nchunks;
-#endif
-    SS_DSTAMP(1);
     for (int ck = 0, g0 = 0; ck < nchunks_run; ++ck, g0 += KST) {
         const int ci0 = ck * 16;
         // ---- split + transpose: registers -> [term][half][position] ----
@@ -384,7 +367,6 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         if (F16 && more) publish_max(0.f);                        // of the chunk staged next
         __syncthreads();
     }
-    SS_DSTAMP(2);
     if (F16) {          // back to plain values: 2^-(activation scale) x the channel's 2^-(weight scale), exact
         const float au = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
 #pragma unroll
@@ -395,11 +377,8 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         }
     }
 
-#ifndef SS_ABL_D_SKIP
     if (HAS_SKIP && !skip_first) skip_phase();
-#endif
 
-    SS_DSTAMP(3);
     // ---- epilogue: each lane owns the 2x2x2 output cube of its input position.  Buffer stores: a 32-bit per-lane offset
     // per (plane, row) pair of the cube (positions outside the volume parked beyond the buffer: the store is dropped) and
     // a scalar offset per channel -- no 64-bit per-lane arithmetic, no branches ----
@@ -423,17 +402,10 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         for (int pdh = 0; pdh < 4; ++pdh) {
             const float v0 = fmaxf(ss::add_rn(acc[pdh * 2 + 0][r], sh), floor_v);
             const float v1 = fmaxf(ss::add_rn(acc[pdh * 2 + 1][r], sh), floor_v);
-#ifdef SS_ABL_D_STORE
-            if (v0 == 123456.f)
-#endif
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ss_u32x2, make_float2(v0, v1)), ores,
                                                   (int)(cok ? vo[pdh] : 0x80000000u), cb * (int)ochan_b, 0);
         }
     }
-    SS_DSTAMP(4);
-#ifdef SS_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0 && blockIdx.z == 0) ss_dbgd_t[blockIdx.x * 8 + 5] = skip_first;
-#endif
 }
 
 // wpack [Cin][27][Cout] fp32 (ss_pack_conv3d_weights, transposed form, BN scale folded by the caller) ->

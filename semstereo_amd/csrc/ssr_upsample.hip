@@ -54,33 +54,9 @@ __device__ __forceinline__ float upsampled(const float* __restrict__ low, int h,
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void ssr_upsample_kernel(const float* __restrict__ depth_low, const float* __restrict__ weights,
-                                                            const float* __restrict__ label, const float* __restrict__ prm,
-                                                            float* __restrict__ out, int h, int w, long long total) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int H = 4 * h, W = 4 * w;
-    const long long plane = (long long)H * W;
-    const int X = (int)(i % W), Y = (int)((i / W) % H);
-    const long long b = i / plane;
-    const long long pix = (long long)Y * W + X;
-    const float* low = depth_low + b * h * w;
-
-    // 3x3 neighbourhood of BN0(up), zero outside the image
-    float nb[9], centre = 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int yy = Y + ky - 1, xx = X + kx - 1;
-            float v = 0.f;
-            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                const float u = upsampled(low, h, w, yy, xx);
-                if (ky == 1 && kx == 1) centre = u;
-                v = ss::add_rn(ss::mul_rn(u, prm[P_BN0]), prm[P_BN0 + 1]);
-            }
-            nb[ky * 3 + kx] = v;
-        }
+// one pixel: everything after the 3x3 neighbourhood `nb` of BN0(up) and the raw centre value are known
+__device__ __forceinline__ float ssr_pixel(const float (&nb)[9], float centre, const float (&labv)[NCLS], const float (&wt)[NCLS],
+                                           const float* __restrict__ prm) {
     float depth[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) {
@@ -91,16 +67,12 @@ __global__ __launch_bounds__(256) void ssr_upsample_kernel(const float* __restri
         depth[c] = ss::add_rn(ss::mul_rn(a, prm[P_BNA + c]), prm[P_BNA + NCLS + c]);
     }
     // class probabilities and the two gated 1x1 stages
-    float lab[NCLS], wt[NCLS], mx = -INFINITY;
+    float lab[NCLS], mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) {
-        lab[c] = label[(b * NCLS + c) * plane + pix];
-        wt[c] = weights[(b * NCLS + c) * plane + pix];
-        mx = fmaxf(mx, lab[c]);
-    }
+    for (int c = 0; c < NCLS; ++c) mx = fmaxf(mx, labv[c]);
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) { lab[c] = expf(lab[c] - mx); sum = ss::add_rn(sum, lab[c]); }
+    for (int c = 0; c < NCLS; ++c) { lab[c] = expf(labv[c] - mx); sum = ss::add_rn(sum, lab[c]); }
     float z[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) z[c] = ss::mul_rn(lab[c] / sum, wt[c]);
@@ -125,7 +97,108 @@ __global__ __launch_bounds__(256) void ssr_upsample_kernel(const float* __restri
         const float p2 = sigmoidf(ss::add_rn(ss::mul_rn(a, prm[P_BN2 + o]), prm[P_BN2 + NCLS + o]));
         res = fmaf(prm[P_W3 + o], ss::mul_rn(depth[o], p2), res);
     }
-    out[i] = ss::add_rn(centre, ss::add_rn(res, prm[P_B3]));
+    return ss::add_rn(centre, ss::add_rn(res, prm[P_B3]));
+}
+
+// Any size: one thread per output pixel, the 9 taps of the 3x3 conv re-interpolated from the 1/4-scale map.
+__global__ __launch_bounds__(256) void ssr_upsample_kernel(const float* __restrict__ depth_low, const float* __restrict__ weights,
+                                                            const float* __restrict__ label, const float* __restrict__ prm,
+                                                            float* __restrict__ out, int h, int w, long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int H = 4 * h, W = 4 * w;
+    const long long plane = (long long)H * W;
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const long long b = i / plane;
+    const long long pix = (long long)Y * W + X;
+    const float* low = depth_low + b * h * w;
+    float nb[9], centre = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = Y + ky - 1, xx = X + kx - 1;
+            float v = 0.f;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                const float u = upsampled(low, h, w, yy, xx);
+                if (ky == 1 && kx == 1) centre = u;
+                v = ss::add_rn(ss::mul_rn(u, prm[P_BN0]), prm[P_BN0 + 1]);
+            }
+            nb[ky * 3 + kx] = v;
+        }
+    float lab[NCLS], wt[NCLS];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+        lab[c] = label[(b * NCLS + c) * plane + pix];
+        wt[c] = weights[(b * NCLS + c) * plane + pix];
+    }
+    out[i] = ssr_pixel(nb, centre, lab, wt, prm);
+}
+
+// W % 4 == 0 (always: W = 4 w): a workgroup owns 8 rows x 128 columns.  The up-sampled disparity of the tile and its one-pixel
+// halo is interpolated ONCE into LDS (raw, and through the first BatchNorm with the conv's zero padding applied) -- the
+// per-pixel form above re-interpolates each value nine times and was bound by that arithmetic, not by HBM -- and every
+// thread then finishes 4 consecutive pixels with 16-byte loads of the class logits / guidance weights and a 16-byte store.
+constexpr int SST_H = 8, SST_W = 128, SSP = SST_W + 8;          // LDS pitch: halo column at index 3, tile from index 4
+
+__global__ __launch_bounds__(256) void ssr_upsample_tiled(const float* __restrict__ depth_low, const float* __restrict__ weights,
+                                                           const float* __restrict__ label, const float* __restrict__ prm,
+                                                           float* __restrict__ out, int h, int w) {
+    __shared__ __attribute__((aligned(16))) float raw[(SST_H + 2) * SSP];
+    __shared__ __attribute__((aligned(16))) float bn[(SST_H + 2) * SSP];
+    const int H = 4 * h, W = 4 * w;
+    const int X0 = blockIdx.x * SST_W, Y0 = blockIdx.y * SST_H;
+    const long long b = blockIdx.z;
+    const long long plane = (long long)H * W;
+    const float* low = depth_low + b * h * w;
+    const float s0 = prm[P_BN0], t0 = prm[P_BN0 + 1];
+    for (int q = threadIdx.x; q < (SST_H + 2) * (SST_W + 2); q += 256) {
+        const int r = q / (SST_W + 2), c = q - r * (SST_W + 2);
+        const int yy = Y0 - 1 + r, xx = X0 - 1 + c;
+        float u = 0.f, v = 0.f;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+            u = upsampled(low, h, w, yy, xx);
+            v = ss::add_rn(ss::mul_rn(u, s0), t0);
+        }
+        raw[r * SSP + 3 + c] = u;
+        bn[r * SSP + 3 + c] = v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int X = X0 + tx * 4, Y = Y0 + ty;
+    if (X >= W || Y >= H) return;
+    const long long pix = (long long)Y * W + X;
+    float4 lv[NCLS], wv[NCLS];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+        lv[c] = *reinterpret_cast<const float4*>(label + (b * NCLS + c) * plane + pix);
+        wv[c] = *reinterpret_cast<const float4*>(weights + (b * NCLS + c) * plane + pix);
+    }
+    float win[3][6];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const float* p = &bn[(ty + ky) * SSP + 4 + tx * 4];
+        const float4 m = *reinterpret_cast<const float4*>(p);
+        win[ky][0] = p[-1]; win[ky][1] = m.x; win[ky][2] = m.y; win[ky][3] = m.z; win[ky][4] = m.w; win[ky][5] = p[4];
+    }
+    const float4 cen = *reinterpret_cast<const float4*>(&raw[(ty + 1) * SSP + 4 + tx * 4]);
+    const float cv[4] = {cen.x, cen.y, cen.z, cen.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float nb[9], lab[NCLS], wt[NCLS];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) nb[ky * 3 + kx] = win[ky][j + kx];
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) {
+            lab[c] = j == 0 ? lv[c].x : (j == 1 ? lv[c].y : (j == 2 ? lv[c].z : lv[c].w));
+            wt[c] = j == 0 ? wv[c].x : (j == 1 ? wv[c].y : (j == 2 ? wv[c].z : wv[c].w));
+        }
+        o[j] = ssr_pixel(nb, cv[j], lab, wt, prm);
+    }
+    *reinterpret_cast<float4*>(out + b * plane + pix) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 }  // namespace
@@ -136,6 +209,12 @@ extern "C" int ss_ssr_upsample_fwd(const float* depth_low, const float* weights,
     SS_REQUIRE(depth_low && weights && pred_label && params && out);
     SS_REQUIRE(B > 0 && h > 0 && w > 0);
     if (num_classes != NCLS) return SS_ERR_UNSUPPORTED;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(weights) | reinterpret_cast<uintptr_t>(pred_label) | reinterpret_cast<uintptr_t>(out);
+    if ((bits & 15) == 0 && B <= 65535 && ss::ceil_div(4 * h, SST_H) <= 65535) {
+        const dim3 grid(ss::ceil_div(4 * w, SST_W), ss::ceil_div(4 * h, SST_H), B);
+        hipLaunchKernelGGL(ssr_upsample_tiled, grid, dim3(256), 0, ss::as_stream(stream), depth_low, weights, pred_label, params, out, h, w);
+        return ss::check_launch();
+    }
     const long long total = (long long)B * 16 * h * w;
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;

@@ -53,3 +53,21 @@ def test_hip_kernel_matches_reference_fixture(ssr_golden, name):
     assert sa.modules.PATH_COUNTS["torch"] == before["torch"] and sa.modules.PATH_COUNTS["hip"] > before["hip"]
     err = float((y.cpu() - torch.as_tensor(ssr_golden[f"ssr/{name}"])).abs().max())
     assert err <= 2e-5, err          # disparities up to +-12 px: ~1e-6 relative
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 37, 70), (1, 64, 64)])
+def test_hip_kernel_on_several_tiles_matches_the_oracle(shape):
+    """Sizes that span several 8 x 128 tiles of the tiled kernel (seams, ragged edges) against the CPU oracle."""
+    import semstereo_amd as sa
+    from oracle import detdata as dd
+    mod, P = _twin(sa)
+    mod = mod.cuda()
+    B, h, w = shape
+    d = dd.t_uniform((B, 1, h, w), 950, -12.0, 12.0)
+    wt = dd.t_normalish((B, 6, 4 * h, 4 * w), 951)
+    lab = dd.t_normalish((B, 6, 4 * h, 4 * w), 952) * 2.0
+    with torch.no_grad():
+        ref = ossr.ssr_upsample(ossr.deterministic_ssr_params(), d, wt, lab)
+        y = mod(d.cuda(), wt.cuda(), lab.cuda())
+    assert float((y.cpu() - ref).abs().max()) <= 2e-5

@@ -1,0 +1,17 @@
+// Instrumented build of the tiled conv kernel for tools/wg_phases.py: cycle-counter stamps at the phase boundaries of every
+// workgroup (prologue / K loop / epilogue, and the K-steps alone), read back through ss_debug_read.  NOT part of the product
+// library: tools/build_timing.sh compiles this file INSTEAD of semstereo_amd/csrc/conv3d_bf16s.hip into tools/_build/lib_timing.so.
+#include <hip/hip_runtime.h>
+
+__device__ unsigned long long ss_dbg_t[8 * 16384];
+__device__ long long ss_dbg_steps_scratch;
+extern "C" int ss_debug_read(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ss_dbg_t), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#define SS_STAMP_ON (threadIdx.x == 0 && blockIdx.x < 16384 && blockIdx.y == 0 && blockIdx.z == 0)
+#define SS_STAMP(k) do { if (SS_STAMP_ON) ss_dbg_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define SS_STAMP_STEPS_BEGIN() const long long ss_tk0 = __builtin_readcyclecounter()
+#define SS_STAMP_STEPS_END() do { if (SS_STAMP_ON) ss_dbg_t[blockIdx.x * 8 + 5] += (unsigned long long)(__builtin_readcyclecounter() - ss_tk0); } while (0)
+#define SS_STAMP_FINISH() do { if (SS_STAMP_ON) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); ss_dbg_t[blockIdx.x * 8 + 4] = hw; } } while (0)
+
+#include "../semstereo_amd/csrc/conv3d_bf16s.hip"

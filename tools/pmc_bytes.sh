@@ -1,0 +1,41 @@
+#!/bin/bash
+# HBM bytes of ONE kernel from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
+# passes (they do not fit one pass), no tracing domain besides the kernel dispatches, FETCH_SIZE doubled (gfx950 tallies a
+# wide coalesced read at half its bytes), WRITE_SIZE as is.  usage (GPU box): tools/pmc_bytes.sh <kernel> [batch] -> gpurun_out/pmc_<kernel>_b<batch>.md
+set -u
+k=$1; b=${2:-1}
+root=$(pwd); out=$root/gpurun_out; mkdir -p $out
+export TMPDIR=/tmp; cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $out/pmc_tmp_$c
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_tmp_$c -o run -- python3 $root/tools/run_kernel.py $k $b 5 > $out/pmc_tmp_$c.log 2>&1
+done
+cd $root
+python3 - "$k" "$b" <<'PY' > $out/pmc_${k}_b${b}.md
+import csv, glob, sys, collections
+k, b = sys.argv[1], sys.argv[2]
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(f"gpurun_out/pmc_tmp_{c}/**/*counter_collection.csv", recursive=True)
+    per = collections.defaultdict(list)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == c:
+                per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    res[c] = per
+line = open("gpurun_out/pmc_tmp_FETCH_SIZE.log").read().strip().splitlines()[-1]
+print(f"# PMC bytes of `{k}` at batch {b} (tools/pmc_bytes.sh, rocprofv3 --pmc, one counter per pass)\n")
+print(line + "\n")
+print("| kernel | dispatches | FETCH_SIZE mean (KB) | x2 (gfx950) = read MB | WRITE_SIZE mean (KB) = written MB | total MB |")
+print("|---|---|---|---|---|---|")
+for name in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
+    f, w = res["FETCH_SIZE"].get(name, []), res["WRITE_SIZE"].get(name, [])
+    if not f and not w:
+        continue
+    # the runner's warm-up dispatches are identical to the timed ones: average everything
+    fm = sum(f) / len(f) if f else 0.0
+    wm = sum(w) / len(w) if w else 0.0
+    print(f"| `{name[:90]}` | {max(len(f), len(w))} | {fm:.1f} | {2 * fm * 1024 / 1e6:.1f} | {wm:.1f} = {wm * 1024 / 1e6:.1f} | {(2 * fm + wm) * 1024 / 1e6:.1f} |")
+PY
+rm -rf $out/pmc_tmp_*
+cat $out/pmc_${k}_b${b}.md

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
+PMC passes see nothing else, and prints its time and algorithmic-byte rate.
+usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att warp ssr ssr2048 strength topk
+                                                               catt8 catt4 upsoft stem_left"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import semstereo_amd as sa  # noqa: E402
+
+name = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+dev = torch.device("cuda")
+M, O = sa.modules, sa.ops
+R = lambda *s: torch.randn(*s, device=dev)                                  # noqa: E731
+
+if name in ("gwc", "gwc_fused", "patch"):
+    fl, fr, gl = R(B, 256, 128, 128), R(B, 256, 128, 128), R(B, 32, 128, 128)
+    patch = M.DepthwisePatch(32).to(dev).eval()
+    vol = O.build_gwc_volume_norm(fl, fr, 16, 32)
+    fn = {"gwc": lambda: O.build_gwc_volume_norm(fl, fr, 16, 32),
+          "gwc_fused": lambda: O.gwc_patch_gate(fl, fr, 16, 32, patch.weight, gl),
+          "patch": lambda: patch(vol, gl)}[name]
+    nbytes = {"gwc": 4.0 * B * (2 * 256 + 32 * 32) * 128 * 128, "gwc_fused": 4.0 * B * (2 * 256 + 32 + 32 * 32) * 128 * 128,
+              "patch": 4.0 * B * (2 * 32 * 32 + 32) * 128 * 128}[name]
+elif name in ("head", "head_att"):
+    D, H = (24, 256) if name == "head" else (32, 128)
+    x = torch.relu(R(B, 32, D, H, H))
+    ws = M.pack_head_weight_bf16s(R(1, 32, 3, 3, 3))
+    fn = lambda: M.conv3d_head_bf16s_hip(x, ws, None, None, False, 6)          # noqa: E731
+    nbytes = 4.0 * B * 33 * D * H * H
+elif name == "warp":
+    cr, smp = R(B, 32, 256, 256), torch.randint(-32, 32, (B, 24, 256, 256), device=dev).float().sort(dim=1).values
+    att = torch.rand(B, 24, 256, 256, device=dev)
+    fn = lambda: O.concat_volume_sampled(None, cr, smp, att)                   # noqa: E731
+    nbytes = 4.0 * B * (32 + 24 + 24 + 32 * 24) * 256 * 256
+elif name in ("ssr", "ssr2048"):
+    Hf = 1024 if name == "ssr" else 2048
+    ssr = M.SSR_upsample(6).to(dev).eval()
+    d, w, l = R(B, 1, Hf // 4, Hf // 4), R(B, 6, Hf, Hf), R(B, 6, Hf, Hf)
+    fn = lambda: ssr(d, w, l)                                                  # noqa: E731
+    nbytes = 4.0 * B * (13 + 1.0 / 16) * Hf * Hf
+elif name == "strength":
+    fl, fr, p0, var = R(B, 128, 256, 256), R(B, 128, 256, 256), R(B, 256, 256) * 8, torch.rand(B, 1, 256, 256, device=dev)
+    g, b = torch.full((1,), 0.25, device=dev), torch.full((1,), 2.0, device=dev)
+    fn = lambda: O.sample_strength(fl, fr, p0, var, g, b)                      # noqa: E731
+    nbytes = 4.0 * B * (2 * 128 + 2 + 5) * 256 * 256
+elif name == "topk":
+    aw, st = R(B, 1, 64, 256, 256), torch.softmax(R(B, 5, 256, 256), dim=1)
+    fn = lambda: O.topk_candidates(aw, st, 32, 24)                             # noqa: E731
+    nbytes = 4.0 * B * (64 + 5 + 24 + 24 + 1) * 256 * 256
+elif name in ("catt8", "catt4"):
+    c, h = (256, 128) if name == "catt8" else (128, 256)
+    mod = M.channelAtt(32, c).to(dev).eval()
+    im = R(B, c, h, h)
+    fn = lambda: mod.logits(im)                                                # noqa: E731
+    nbytes = 4.0 * B * (c + 32) * h * h
+elif name == "upsoft":
+    coarse = R(B, 1, 32, 128, 128)
+    fn = lambda: O.upsample_softmax_regression(coarse, 32, 256, 256)           # noqa: E731
+    nbytes = 4.0 * B * (32 * 128 * 128 + 66 * 256 * 256)
+elif name == "stem_left":
+    stem = M.BasicConv(64, 32, is_3d=True, kernel_size=3, stride=1, padding=1).to(dev).eval()
+    cl, att = R(B, 32, 256, 256), torch.rand(B, 1, 24, 256, 256, device=dev)
+    fn = lambda: M.stem_broadcast_half(stem, cl, att)                          # noqa: E731
+    nbytes = 4.0 * B * (32 + 24 + 32 * 24) * 256 * 256
+else:
+    sys.exit(__doc__)
+
+with torch.no_grad():
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    while (time.time() - t0) * 1e3 < float(os.environ.get("SS_WARM_MS", "300")):     # loaded clocks
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print(f"{name} B={B}: {ms * 1e3:.1f} us/launch, {nbytes / 1e6:.1f} MB algorithmic, {nbytes / ms / 1e6:.0f} GB/s = "
+      f"{100 * nbytes / ms / 1e6 / 8000:.1f} % of 8 TB/s")

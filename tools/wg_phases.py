@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase times of the dominant conv from a library built with -DSS_TIMING (tools/ablate_conv.sh builds
-tools/_build/lib_timing.so): prologue (launch -> first chunk staged), K loop, epilogue, and how many workgroups are
+"""Per-workgroup phase times of the dominant conv from the instrumented library tools/build_timing.sh builds
+(tools/_build/lib_timing.so = the product library with tools/conv_timing.hip in place of conv3d_bf16s.hip): prologue (launch -> first chunk staged), K loop, epilogue, and how many workgroups are
 resident over time.  usage: SS_TOOL_LIB=tools/_build/lib_timing.so python tools/wg_phases.py [engine]"""
 import ctypes
 import os
