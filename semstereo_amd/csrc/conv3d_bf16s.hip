@@ -47,7 +47,6 @@ constexpr int SS_IN_AUX = 0;      // cache policy bits of the activation loads (
 constexpr int SS_ROW_PAIR = 1;    // rows whose MFMAs alternate; 2 measured 1 % slower: the other wave of the SIMD already fills the gaps
 constexpr int SS_A_AHEAD = 2;     // K-steps between the load of a weight fragment and its MFMAs
 constexpr int SS_F16_WGS = 2;     // workgroups per CU the fp16 form is compiled for (3 = 168 VGPRs: spills, +29 %)
-constexpr int SS_EPI_GROUP = 8;   // fragment rows whose side inputs (gate, residual) are fetched together in the epilogue
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {       // finite inputs
     unsigned u = __float_as_uint(x);
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
                                                         float* __restrict__ out,
                                                         int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
-                                                        int tiles_w, int tiles_h, int relu) {
+                                                        int tiles_w, int tiles_h, int ntiles, int relu) {
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
     constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed weights
@@ -126,16 +125,21 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SS_STAMP(0);
     const int l31 = lane & 31, half = lane >> 5;
-    int t = blockIdx.x;
-    const int tw = t % tiles_w; t /= tiles_w;
-    const int th = t % tiles_h; t /= tiles_h;
-    const int ow0 = tw * 32, oh0 = th * TH, od0 = t * TD;
+    // PERSISTENT workgroups: a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its (channel tile, batch
+    // element).  While the LAST chunk of a tile is multiplied, the prefetch registers -- idle there until now -- fetch the
+    // FIRST chunk of the next tile, so only the very first tile of a workgroup pays the exposed round trip to HBM that used
+    // to open every workgroup's life (12 k of ~100 k cycles, tools/wg_phases.py); the epilogue's stores then drain under the
+    // next tile's first K-steps.
     const int co0 = blockIdx.y * 32 * MT;
     const int b = blockIdx.z;
-    const int iw0 = ow0 * S - 1, ih0 = oh0 * S - 1, id0 = od0 * S - KD / 2;
     const int dzw = (wave * NT) / TH, hy0 = (wave * NT) % TH;
     const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + l31 * S;     // slot of this lane's first row, tap (0,0,0)
-
+    auto tile_origin = [&](int tile, int& ow0, int& oh0, int& od0) {
+        int t = tile;
+        const int tw = t % tiles_w; t /= tiles_w;
+        const int th = t % tiles_h; t /= tiles_h;
+        ow0 = tw * 32; oh0 = th * TH; od0 = t * TD;
+    };
     // relu bit 0: ReLU; bit 1: `residual` is added BEFORE the affine: a partial sum of the same convolution computed
     // elsewhere (stem_left.hip).  It joins the accumulator in the epilogue, fetched together with the gate (as initial
     // accumulators its 64 loads per lane were 14 k cycles of every workgroup's prologue: tools/wg_phases.py).
@@ -151,7 +155,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const unsigned ochan_b = (unsigned)((size_t)Do * out_plane * 4), gchan_b = (unsigned)(out_plane * 4);
     const int obytes = (int)min((long long)Cout * (long long)ochan_b, 0x7fffffffLL);
     unsigned vout[NT], vgate[NT];
-    {
+    auto set_outputs = [&](int tile) {
+        int ow0, oh0, od0;
+        tile_origin(tile, ow0, oh0, od0);
         const int ow_ = ow0 + l31, od_ = od0 + dzw;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -160,33 +166,35 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             vout[i] = ok ? (unsigned)((((size_t)od_ * Ho + oh_) * Wo + ow_) * 4) + 4u * half * ochan_b : 0x80000000u;
             vgate[i] = ok ? (unsigned)(((size_t)oh_ * Wo + ow_) * 4) + 4u * half * gchan_b : 0x80000000u;
         }
-    }
+    };
     // this lane's channel of fragment register r of output tile mt: cbase(mt, r) + 4 * half
     auto cbase = [&](int mt, int r) { return co0 + mt * 32 + (r & 3) + 8 * (r >> 2); };
     f32x16 acc[MT * NT];                  // index mt * NT + row
-#pragma unroll
-    for (int i = 0; i < MT * NT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const size_t in_plane = (size_t)H * W, chan = (size_t)D * in_plane;
     const float* inb = in + (size_t)b * Cin * chan;
 
-    // staging plan: this thread owns positions p = tid + 256*i of the halo tile, all 8 channels
-    unsigned poff[C::NPOS];
+    // staging plan of a tile: this thread owns positions p = tid + 256*i of the halo tile, all 8 channels
+    auto make_poff = [&](int tile, unsigned (&po)[C::NPOS]) {
+        int ow0, oh0, od0;
+        tile_origin(tile, ow0, oh0, od0);
+        const int iw0 = ow0 * S - 1, ih0 = oh0 * S - 1, id0 = od0 * S - KD / 2;
 #pragma unroll
-    for (int i = 0; i < C::NPOS; ++i) {
-        const int p = tid + 256 * i;
-        const int wx = p % C::IW;
-        int r = p / C::IW;
-        const int hy = r % C::IH;
-        const int dz = r / C::IH;
-        const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz;
-        const bool ok = (p < C::CS) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        // halo positions outside the volume get an offset beyond the buffer's num_records: the buffer
-        // load returns 0 for them, no select needed
-        poff[i] = ok ? (unsigned)(((size_t)gd * in_plane + (size_t)gh * W + gw) * 4) : 0x80000000u;
-    }
+        for (int i = 0; i < C::NPOS; ++i) {
+            const int p = tid + 256 * i;
+            const int wx = p % C::IW;
+            int r = p / C::IW;
+            const int hy = r % C::IH;
+            const int dz = r / C::IH;
+            const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz;
+            const bool ok = (p < C::CS) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            // halo positions outside the volume get an offset beyond the buffer's num_records: the buffer
+            // load returns 0 for them, no select needed
+            po[i] = ok ? (unsigned)(((size_t)gd * in_plane + (size_t)gh * W + gw) * 4) : 0x80000000u;
+        }
+    };
+    unsigned poff[C::NPOS];
+    make_poff(blockIdx.x, poff);
     // input prefetch registers, flattened q = c * NPOS + i, loaded in KSTEPS slices spread over the
     // K-steps of the previous chunk so that a wait for a weight fragment never drains them all
     constexpr int NQ = 8 * C::NPOS;
@@ -226,9 +234,6 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     auto load_in = [&](int ch, int i) {                                       // channel ch (absolute), position slot i
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, SS_IN_AUX));
     };
-    auto load_in_masked = [&](int ch, int i, unsigned mask) {                 // mask 0x80000000: beyond the buffer, reads 0
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(poff[i] | mask), ch * chan_b, SS_IN_AUX));
-    };
     const int G = ((Cin + 7) / 8) * KSTEPS;
     // Ring of weight fragments, AP steps ahead: vmcnt retires in order, so a wait for a fragment also
     // waits for every input (HBM) load issued before it -- the distance must cover HBM latency, not L2's.
@@ -262,6 +267,14 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     }
     SS_STAMP(1);
 
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool has_next = tile + (int)gridDim.x < ntiles;
+#pragma unroll
+    for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    e_cur = E_ONE; e_run = E_MIN;
+    nlive = min(8, Cin);
     for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
         // ---- split + transpose: registers -> [term][position][8 ch] ----
         if constexpr (WLDS) {         // this chunk's weights: wave w issues the (K-step, term) pairs i = w, w + 4, ...; lane -> (half, channel)
@@ -305,9 +318,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         }
         if (WLDS) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the LDS-DMA weight loads have landed
         __syncthreads();
-        const bool more = ci0 + 8 < Cin;
-        nlive_next = min(8, Cin - ci0 - 8);
-        const unsigned nomore = more ? 0u : 0x80000000u;
+        const bool more = ci0 + 8 < Cin;                       // another chunk of THIS tile follows
+        // what the K-steps prefetch: the next chunk of this tile, or (last chunk) the first chunk of the workgroup's next tile
+        // (this tile's own offsets are not needed past this point: its last chunk is already staged)
+        if (!more) make_poff(tile + (int)gridDim.x, poff);                  // pure index arithmetic under a wave-uniform branch
+        nlive_next = more ? min(8, Cin - ci0 - 8) : min(8, Cin);
+        const int ch_next = more ? ci0 + 8 : 0;
+        const unsigned nomore = (more || has_next) ? 0u : 0x80000000u;
         SS_STAMP_STEPS_BEGIN();
 
         // B fragments are read one row GROUP ahead of their MFMAs.  With RP = 2 the MFMAs of two rows
@@ -340,14 +357,18 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) aq[(s + AP) % AR][mt][c] = load_a(min(g0 + s + AP, G - 1), c, mt);
+                    for (int c = 0; c < NC; ++c) {              // (past the tile's last step: steps 0, 1, .. of the next tile)
+                        const int gw_ = g0 + s + AP;
+                        aq[(s + AP) % AR][mt][c] = load_a(gw_ < G ? gw_ : gw_ - G, c, mt);
+                    }
             } else if (s + 1 < KSTEPS) {                       // next step's fragments from the LDS copy
 #pragma unroll
                 for (int c = 0; c < NC; ++c) aq[(s + 1) % AR][0][c] = lds[WL + ((s + 1) * 2 + c) * 64 + lane];
             }
 #pragma unroll
             for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q)
-                rin[q] = load_in_masked(min(ci0 + 8, Cin - 1) + min(q / C::NPOS, max(nlive_next, 1) - 1), q % C::NPOS, nomore);
+                rin[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                       ires, (int)(poff[q % C::NPOS] | nomore), (ch_next + min(q / C::NPOS, max(nlive_next, 1) - 1)) * chan_b, SS_IN_AUX));
             uint4 a[MT][NC];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -408,11 +429,12 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         }
         nlive = nlive_next;
         SS_STAMP_STEPS_END();
-        if (F16 && more) publish_max(0.f);
+        if (F16 && (more || has_next)) publish_max(0.f);       // of the chunk staged next (its loads were issued >= 4 K-steps ago)
         __syncthreads();
     }
 
     SS_STAMP(2);
+    set_outputs(tile);                 // (output addressing is derived here, not kept live through the K loop)
     // ---- epilogue: 32x32 D layout (col = lane & 31 = output column, row = channel, see cbase) ----
     // f16 form: 2^-(activation scale); the per-channel 2^-(weight scale) is stored behind the packed weights
     const float acc_unscale = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
@@ -428,7 +450,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const float floor_v = (relu & 1) ? 0.f : -__builtin_inff();
     // the side inputs (affine, gate, residual) of a group of EG fragment rows are fetched first so that their latencies
     // overlap instead of chaining; every group costs one exposed round trip (load -> store -> the next group's loads)
-    constexpr int EG = SS_EPI_GROUP;
+    // (the next tile's first chunk occupies the prefetch registers during the epilogue: with both a gate and a residual to
+    // fetch, groups of 4 rows keep the kernel out of scratch)
+    constexpr int EG = (GATED || NT * MT >= 4) ? 4 : 8;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -482,6 +506,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         }
     }
     SS_STAMP(3);
+    }       // tiles of this workgroup (the next one's first chunk is already in the prefetch registers)
     SS_STAMP_FINISH();
 }
 
@@ -557,12 +582,17 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
     if (C::LDS_BYTES > 64 * 1024) {
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
-    dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32 * MT), B);
+    // persistent workgroups: as many as the chip holds at once (2 per CU), each walking an equal share of the tiles
+    const int groups = ss::ceil_div(Cout, 32 * MT) * B;
+    const long long cap = std::max<long long>(1, (2 * 256) / groups);
+    const long long rounds = ss::ceil_div_ll(nt, cap);
+    const long long gx = ss::ceil_div_ll(nt, rounds);
+    dim3 grid((unsigned)gx, ss::ceil_div(Cout, 32 * MT), B);
     // (Workgroups of equal duration that all start together stay in lock-step -- every CU stages, multiplies and stores at
     // the same time.  Starting the first round's workgroups spread over 0.5-1.5 estimated lifetimes, in 2-16 groups, was
     // measured: no gain, -0 .. -8 %.)
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
-                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, relu);
+                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, (int)nt, relu);
     return ss::check_launch();
 }
 
