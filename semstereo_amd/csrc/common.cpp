@@ -72,6 +72,21 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
     g_lds_set[key] = bytes;
     return SS_OK;
 }
+
+int resident_workgroups(const void* kernel, int block, int lds_bytes) {
+    static std::unordered_map<unsigned long long, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(kernel) * 64ull + (unsigned)dev;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, (size_t)lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    (void)hipGetLastError();
+    return cache[key] = per_cu * cus;
+}
 }  // namespace ss
 
 extern "C" int ss_reload_tuning(void) {

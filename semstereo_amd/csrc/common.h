@@ -39,6 +39,10 @@ const Tuning& tuning();
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch.
 int ensure_dynamic_lds(const void* kernel, int bytes);
+// Workgroups of `kernel` (block size, dynamic LDS bytes) the hardware keeps resident per CU, and the CU count of the
+// current device (hipOccupancyMaxActiveBlocksPerMultiprocessor / hipDeviceGetAttribute, asked once and cached): the grid
+// size of the persistent kernels.
+int resident_workgroups(const void* kernel, int block, int lds_bytes);
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -582,9 +582,10 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
     if (C::LDS_BYTES > 64 * 1024) {
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
-    // persistent workgroups: as many as the chip holds at once (2 per CU), each walking an equal share of the tiles
+    // persistent workgroups: as many as the chip holds at once (2 - 4 per CU depending on the tile), each walking an equal
+    // share of the tiles
     const int groups = ss::ceil_div(Cout, 32 * MT) * B;
-    const long long cap = std::max<long long>(1, (2 * 256) / groups);
+    const long long cap = std::max<long long>(1, ss::resident_workgroups(reinterpret_cast<const void*>(kern), 256, (int)C::LDS_BYTES) / groups);
     const long long rounds = ss::ceil_div_ll(nt, cap);
     const long long gx = ss::ceil_div_ll(nt, rounds);
     dim3 grid((unsigned)gx, ss::ceil_div(Cout, 32 * MT), B);
