@@ -461,6 +461,29 @@ def main():
                 "frac": nb8 / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msf, "algorithmic_bytes_per_launch": nb8,
                 "traffic": None, "replaces_ms": None}
         del a8, b8, gl8
+        # ... and alone at the bench batch: inside the step it shares the chip with the matching branch's 2-D convolutions
+        # on the second stream (roofline_cost_volume above is that concurrent figure)
+        gB = torch.Generator(device=device).manual_seed(8)
+        aB, bB = torch.randn(B, 256, H8, W8, generator=gB, device=device), torch.randn(B, 256, H8, W8, generator=gB, device=device)
+        glB = torch.randn(B, 32, H8, W8, generator=gB, device=device)
+        if fused_gwc and semstereo_amd.ops.gwc_patch_gate_applies(aB, maxdisp // 8, 32):
+            run = lambda: semstereo_amd.ops.gwc_patch_gate(aB, bB, maxdisp // 8, 32, seg.patch.weight, glB)     # noqa: E731
+            for _ in range(5):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            msa = e0.elapsed_time(e1) / 20
+            res["roofline_cost_volume_alone"] = {
+                "kernel": res["roofline_cost_volume"]["kernel"] + ", launched alone", "bound": "hbm",
+                "achieved": nbytes / (msa * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": nbytes / (msa * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msa, "algorithmic_bytes_per_launch": nbytes,
+                "traffic": None,
+                "note": "the two kernels it replaces (volume, then patch + gate) move 2.35x these bytes: 100.7 + 136.3 MB per pair"}
+        del aB, bB, glB
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and EPE: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the
         # same workload: about 10-30 s of CPU work.  ATen's CPU kernels stop scaling (the slice
