@@ -4,10 +4,10 @@
 Attribute names equal the reference model's (patch, corr_feature_att_8, hourglass_att,
 classif_att_, gamma, beta, concat_feature, concat_stem, concat_feature_att_4, hourglass, classif),
 so the matching slice of a reference checkpoint loads with `load_reference_state_dict`.
-In inference the volume builders, the whole 3-D stack and the regressions are HIP kernels, with
-the fusions SURVEY.md section 8(f) asks for (patch+gate, softmax+regression+variance,
-warp+correlation, warp+concat+gate); the remaining glue (trilinear upsampling, softmax, sort /
-top-24 / gather, the 5-tap propagation) is PyTorch-on-GPU as in the reference.
+In inference every line of that segment runs in hand-written HIP kernels, with the fusions SURVEY.md
+section 8(f) asks for (volume+patch+gate, up-sampling+softmax+regression+variance, the 5-candidate probe,
+the top-24 selection, warp+concat+gate, stem by halves + gate); with autograd on (training) the same
+graph runs line by line on the reference-named ops (HIP forward / backward) and the module twins.
 """
 import os
 

@@ -28,8 +28,9 @@ def _worker(rank, world, port, n_pairs, ret):
     with torch.no_grad():
         lin.weight.normal_()
     sd.broadcast_module(lin, src=0)
-    torch.manual_seed(100)
-    ref_w = torch.nn.Linear(4, 4).weight.detach().clone().normal_()
+    ref_w = torch.empty(4, 4)
+    torch.manual_seed(100)                      # rank 0's draw, reproduced on every rank
+    ref_w.normal_()
     # the full batch is defined by closed form on every rank; each rank computes its shard only
     g = torch.Generator().manual_seed(7)
     prob = torch.softmax(torch.randn(n_pairs, 8, 5, 6, generator=g), dim=1)
@@ -38,7 +39,7 @@ def _worker(rank, world, port, n_pairs, ret):
     full = sd.gather_batch(local, n_pairs)
     pairs, err, pix, tmax = sd.reduce_metrics(mine.shape[0], float(rank + 1), local.numel(), 0.5 + rank, "cpu")
     ok = torch.allclose(full, oops.disparity_regression(prob, 4)) and full.shape[0] == n_pairs
-    ret[rank] = (ok, pairs, err, pix, tmax, torch.equal(lin.weight.detach(), lin.weight.detach()),
+    ret[rank] = (ok, pairs, err, pix, tmax, torch.equal(lin.weight.detach(), ref_w),       # every rank holds rank 0's weights
                  float(lin.weight.detach().sum()))
     dist.barrier()
     dist.destroy_process_group()
@@ -58,4 +59,5 @@ def test_two_ranks_shard_gather_reduce_even_and_ragged():
         assert all(v[0] for v in ret.values())
         assert ret[0][1] == n_pairs and ret[1][1] == n_pairs            # SUM of pairs
         assert ret[0][2] == 3.0 and ret[0][4] == 1.5                    # SUM of errors, MAX of time
-        assert abs(ret[0][6] - ret[1][6]) < 1e-6                        # broadcast made weights equal
+        assert ret[0][5] and ret[1][5]                                  # both ranks hold exactly rank 0's weights
+        assert abs(ret[0][6] - ret[1][6]) < 1e-6

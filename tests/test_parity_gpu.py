@@ -411,7 +411,7 @@ def test_conv3d_fused_channel_gate(sa, engine):
 def test_attention_block_forms_agree(sa, shape):
     """attention_block (models/submodule_other.py:790-837) in both HIP forms -- the fused one-kernel-per-window
     form and the three-launch form (projection, per-(window, 4 heads) attention, projection) -- against the
-    PyTorch composition of the same module, including H/W padding (both, one, none)."""
+    oracle's restatement of the block, including H/W padding (both, one, none)."""
     from oracle import detdata as dd
     block, D, H, W = shape
     mod = sa.modules.attention_block(128, 16, block).cuda().eval()
@@ -427,11 +427,16 @@ def test_attention_block_forms_agree(sa, shape):
             for form in ("split", "fused"):
                 sa.modules.ATTENTION_FORM = form
                 outs[form] = mod(x)
-            ref = mod._forward_torch(x)
     finally:
         sa.modules.ATTENTION_FORM = old
+    # the reference: the ORACLE's restatement of the block (oracle/stack.py, pinned to the reference's fixtures attn_pad /
+    # attn_pad_w), not the module's own PyTorch path
+    P = {"ab." + k: v.detach().cpu() for k, v in mod.state_dict().items()}
+    ref = ostack.attention_block(P, "ab", x.cpu(), block)
     for form in outs:
-        check(f"attention_{form}/{shape}", outs[form], ref.cpu(), 2e-5)
+        check(f"attention_{form}/{shape}", outs[form], ref, 2e-5)
+    with torch.no_grad():
+        check(f"attention_torch_path/{shape}", mod._forward_torch(x), ref, 2e-5)       # the training path agrees too
 
 
 @pytest.mark.parametrize("nterms", [6, 3])
