@@ -484,6 +484,34 @@ def main():
                 "traffic": None,
                 "note": "the two kernels it replaces (volume, then patch + gate) move 2.35x these bytes: 100.7 + 136.3 MB per pair"}
         del aB, bB, glB
+    # the semantic-guided refinement head that follows the segment in the model (SSR_upsample, models/submodule.py:412-431;
+    # BASELINE.json configs[4] names it): one launch per pair at full resolution, outside the timed segment
+    try:
+        ssr = M.SSR_upsample(6).to(device).eval()
+        gs = torch.Generator(device=device).manual_seed(9)
+        d_low = torch.randn(B, 1, H4, W4, generator=gs, device=device) * 8
+        wts, lab = torch.randn(B, 6, H, W, generator=gs, device=device), torch.randn(B, 6, H, W, generator=gs, device=device)
+        prm = ssr._params()
+        out_ssr = torch.empty(B, H, W, device=device)
+        lib = semstereo_amd._lib
+        run = lambda: lib.call("ss_ssr_upsample_fwd", lib.ptr(d_low), lib.ptr(wts), lib.ptr(lab), lib.ptr(prm), lib.ptr(out_ssr), B, H4, W4, 6)   # noqa: E731
+        for _ in range(5):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        mss = e0.elapsed_time(e1) / 20
+        nbs = 4.0 * B * (13 * H * W + H4 * W4)
+        res["roofline_ssr_upsample"] = {"kernel": "ssr_upsample_tiled (SSR_upsample: 4x bilinear + 6-class gated residual, one launch)",
+                                        "bound": "hbm", "achieved": nbs / (mss * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": nbs / (mss * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": mss,
+                                        "algorithmic_bytes_per_launch": nbs, "traffic": None}
+        del d_low, wts, lab, out_ssr
+    except Exception as e:       # noqa: BLE001  (never let the side measurement take the line down)
+        res["roofline_ssr_upsample"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and EPE: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the
         # same workload: about 10-30 s of CPU work.  ATen's CPU kernels stop scaling (the slice

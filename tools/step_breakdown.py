@@ -3,13 +3,13 @@
 
 The rocpd database also holds the warm-up (MIOpen's find phase runs every candidate solver there) and
 bench.py's micro-runs; this tool cuts the window between two launches of the marker kernel that runs
-exactly once per step (the B=1 cost-volume kernel) and reports time per step inside it.
+exactly once per step (the final top-2 soft-argmax) and reports time per step inside it.
 usage: step_breakdown.py <results.db> [marker-substring] [skip-first-n]"""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-marker = sys.argv[2] if len(sys.argv) > 2 else "gwc_volume_v4<8, true, false>"
+marker = sys.argv[2] if len(sys.argv) > 2 else "topk_regress_kernel<2>"     # runs exactly once per step, in no micro-run
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 marks = [s for n, s, e in rows if marker in n]
