@@ -60,3 +60,23 @@ def test_parent_makes_no_gpu_call_before_spawning():
     launcher = src[src.index("def launch_ranks"):src.index("def dry_step_factory")]
     launcher = launcher[launcher.index('"""', launcher.index('"""') + 3):]          # code only, not the docstring
     assert "torch.cuda" not in launcher and "os.exec" not in launcher and "execv" not in launcher
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_through_the_real_step():
+    """On the GPU box: `python bench.py --gpus 2` with SS_DIST_BACKEND=gloo (RCCL refuses two ranks on one device): the
+    self-launched ranks run the REAL hot-segment step on cuda:0, meet at the barriers, reduce the metrics and rank 0 prints
+    one line with n_gpus = 2 and twice the pairs of a single rank.  (The rate of such a run means nothing.)"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "1", "--no-cpu-baseline",
+                        "--no-other-engines", "--height", "256", "--width", "256", "--maxdisp", "64"],
+                       env=_env(SS_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    res = lines[0]
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
+    assert abs(res["value"] * res["ms_per_step"] * 1e-3 - 2.0) < 1e-6          # pairs/s x s/step = 2 pairs per step over both ranks
+    assert "roofline" in res
