@@ -23,7 +23,22 @@ for n, s, e in rows:
         a[0] += 1
         a[1] += (e - s) / 1e3
 busy = sum(a[1] for a in agg.values())
-print(f"{nsteps} steps, wall {(t1 - t0) / 1e6 / nsteps:.3f} ms/step, kernels busy {busy / 1e3 / nsteps:.3f} ms/step")
+# time with NO kernel running at all inside the window (dispatch gaps between dependent kernels, host stalls)
+iv = sorted((s_, e_) for n_, s_, e_ in rows if t0 <= s_ < t1)
+covered, cur_s, cur_e = 0, None, None
+for s_, e_ in iv:
+    if cur_e is None or s_ > cur_e:
+        if cur_e is not None:
+            covered += cur_e - cur_s
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+if cur_e is not None:
+    covered += cur_e - cur_s
+idle_us = ((t1 - t0) - covered) / 1e3 / nsteps
+ngaps = len(iv) / nsteps
+print(f"{nsteps} steps, wall {(t1 - t0) / 1e6 / nsteps:.3f} ms/step, kernels busy {busy / 1e3 / nsteps:.3f} ms/step, "
+      f"no kernel running {idle_us:.1f} us/step over {ngaps:.0f} launches")
 print(f"{'us/step':>9} {'calls':>6} {'avg us':>8}  kernel")
 for n, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{us / nsteps:9.1f} {c / nsteps:6.1f} {us / c:8.1f}  {n[:120]}")
