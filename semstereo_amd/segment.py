@@ -200,3 +200,30 @@ def run_segment(owner, fl4, fr4, fl8, fr8, matching=True):
             t.record_stream(cur)
     pred = HotSegment.matching_branch(owner, fl4, fr4, att_topk, samples, prelude) if matching else None
     return dict(pred=pred, pred_att=pred_att, samples=samples, att_topk=att_topk, pred_att0=pred0)
+
+
+class GraphedSegment:
+    """The hot segment captured ONCE into a HIP graph and replayed: one graph launch per call instead of ~40 kernel launches
+    from Python (both streams of the segment join the capture through their event waits).  Shapes are fixed at capture;
+    inputs are copied into the captured buffers, outputs are the captured buffers (overwritten by the next call --
+    clone what must outlive it).  Inference only.  On the bench shape the step is GPU-bound (a no-kernel-running gap of 42 us
+    per step shrinks to 18 us: +0.8 %); the form matters for small images and for callers with a slow host thread."""
+
+    def __init__(self, segment, fl4, fr4, fl8, fr8, warmup=3):
+        assert fl4.is_cuda and not segment.training
+        self.segment = segment
+        self.inputs = [t.detach().clone().contiguous() for t in (fl4, fr4, fl8, fr8)]
+        with torch.no_grad():
+            for _ in range(warmup):                     # packs weights, sizes the persistent grids, allocates the side stream
+                segment(*self.inputs)
+            torch.cuda.synchronize(fl4.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.outputs = segment(*self.inputs)
+
+    def __call__(self, fl4, fr4, fl8, fr8):
+        for dst, src in zip(self.inputs, (fl4, fr4, fl8, fr8)):
+            assert dst.shape == src.shape, "GraphedSegment replays the shapes it was captured with"
+            dst.copy_(src)
+        self.graph.replay()
+        return self.outputs

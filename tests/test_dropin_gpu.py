@@ -116,3 +116,27 @@ def test_data_parallel_replicas_run_their_own_forward_in_two_threads(sa):
         err = (got - want).abs()
         assert float(err.median()) <= 1e-4 and float((err <= 4e-3).float().mean()) >= 0.995, (float(err.median()), float(err.max()))
     sa.restore_forward(net)
+
+
+def test_graphed_segment_replays_the_eager_result(sa):
+    """GraphedSegment: the step captured into a HIP graph (both streams) gives bit-identical outputs to the eager call, also
+    for new inputs copied into the captured buffers."""
+    from golden import cases
+    from oracle import hot_segment as oseg
+    fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs("s128")
+    seg = sa.HotSegment(maxdisp)
+    seg.load_state_dict(oseg.deterministic_params(), strict=False)
+    seg = seg.cuda().eval()
+    ins = [t.cuda() for t in (fl4, fr4, fl8, fr8)]
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in seg(*ins).items()}
+    g = sa.GraphedSegment(seg, *ins)
+    got = g(*ins)
+    for k in ("pred", "pred_att", "samples", "att_topk"):
+        assert torch.equal(got[k], want[k]), k
+    ins2 = [torch.roll(t, shifts=3, dims=-1).contiguous() for t in ins]
+    with torch.no_grad():
+        want2 = {k: v.clone() for k, v in seg(*ins2).items()}
+    got2 = g(*ins2)
+    for k in ("pred", "pred_att", "samples"):
+        assert torch.equal(got2[k], want2[k]), k
