@@ -14,5 +14,6 @@ db=$(find $out/prof_$tag -name "*.db" | head -1)
 stats=$(find $out/prof_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$stats" ] && cp $stats $out/${tag}_kernel_stats.csv
 [ -n "$db" ] && python3 tools/step_breakdown.py $db "${SS_MARKER:-topk_regress_kernel<2>}" > $out/${tag}_step_breakdown.txt 2>&1
+[ -n "$db" ] && python3 tools/step_timeline.py $db "${SS_MARKER:-topk_regress_kernel<2>}" > $out/${tag}_step_timeline.txt 2>&1
 ls -R $out/prof_$tag | head -20 >> $out/${tag}_prof.err; rm -rf $out/prof_$tag
 head -40 $out/${tag}_step_breakdown.txt

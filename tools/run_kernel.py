@@ -2,7 +2,7 @@
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
 usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att warp ssr ssr2048 strength topk
-                                                               catt8 catt4 upsoft stem_left"""
+                                                               catt8 catt4 upsoft stem_left conv_s1 conv_s2 deconv"""
 import os
 import sys
 import time
@@ -69,6 +69,20 @@ elif name == "stem_left":
     cl, att = R(B, 32, 256, 256), torch.rand(B, 1, 24, 256, 256, device=dev)
     fn = lambda: M.stem_broadcast_half(stem, cl, att)                          # noqa: E731
     nbytes = 4.0 * B * (32 + 24 + 32 * 24) * 256 * 256
+elif name in ("conv_s2", "conv_s1", "deconv"):
+    if name == "deconv":            # hourglass2.conv6: 64 -> 32 to [24,256,256] with the 1x1x1 skip projection of a 32-channel volume
+        hg = M.hourglass2(32).to(dev).eval()
+        c5, x0 = torch.relu(R(B, 64, 12, 128, 128)), torch.relu(R(B, 32, 24, 256, 256))
+        fn = lambda: hg._up("u6", hg.conv6, hg.redir1, c5, x0)               # noqa: E731
+        nbytes = 4.0 * B * (64 * 12 * 128 * 128 + 2 * 32 * 24 * 256 * 256)
+    else:
+        stride = 2 if name == "conv_s2" else 1
+        cout = 64 if stride == 2 else 32
+        x = torch.relu(R(B, 32, 24, 256, 256))
+        ws = M.pack_conv_weight_bf16s(R(cout, 32, 3, 3, 3) * 0.03, 19)
+        sc, sh = torch.rand(cout, device=dev) + 0.5, R(cout) * 0.1
+        fn = lambda: M.conv3d_bf16s_hip(x, ws, cout, sc, sh, True, 19, stride=stride)       # noqa: E731
+        nbytes = 4.0 * B * (32 * 24 * 256 * 256 + cout * (24 // stride) * (256 // stride) ** 2)
 else:
     sys.exit(__doc__)
 
