@@ -145,3 +145,23 @@ def test_install_into_the_real_reference_module(ref_module):
     finally:
         sa.uninstall(ref_module, prev)
     assert ref_module.build_gwc_volume_norm is orig
+
+
+def test_install_unsigned_op_set_into_the_reference_whu_module(ref_module):
+    """models/SemStereo_WHU.py star-imports the SIGNED op library and cannot run as shipped; `install(module, unsigned=True)`
+    binds the unsigned op set it is written for (models/submodule_.py's definitions) in ITS globals."""
+    import importlib
+    import semstereo_amd as sa
+    mw = importlib.import_module("models.SemStereo_WHU")
+    net = mw.SemStereo_WHU(128, False, True, True, 6).eval()
+    with pytest.raises(RuntimeError), torch.no_grad():                     # as shipped: size mismatch in disparity_regression
+        net(torch.randn(1, 3, 128, 128), torch.randn(1, 3, 128, 128))
+    prev = sa.install(mw, unsigned=True)
+    try:
+        for name in sa.ops.REFERENCE_NAMES:
+            assert getattr(mw, name) is getattr(sa.ops_unsigned, name)
+        assert mw.disparity_regression is not sa.ops.disparity_regression
+        with pytest.raises(sa._lib.SemStereoHipError), torch.no_grad():    # the HIP ops are reached (CPU tensors: a loud error)
+            net(torch.randn(1, 3, 128, 128), torch.randn(1, 3, 128, 128))
+    finally:
+        sa.uninstall(mw, prev)
