@@ -458,7 +458,9 @@ def main():
                 "kernel": "gwc_patch_gate_v4<8,true,stream>, batch 8: volume + patch + gate in one launch", "bound": "hbm",
                 "achieved": nb8 / (msf * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": nb8 / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msf, "algorithmic_bytes_per_launch": nb8,
-                "traffic": None, "replaces_ms": None}
+                "traffic": 910.5e6,
+                "traffic_note": "HBM bytes per launch from PMC passes of tools/pmc_bytes.sh gwc_fused 8 (profiles/r02_c_pmc_gwc_fused_b8.md): "
+                                "2 x FETCH_SIZE (373.7 MB: the 8-rows-for-6 halo re-reads) + WRITE_SIZE (536.9 MB)"}
         del a8, b8, gl8
         # ... and alone at the bench batch: inside the step it shares the chip with the matching branch's 2-D convolutions
         # on the second stream (roofline_cost_volume above is that concurrent figure)
