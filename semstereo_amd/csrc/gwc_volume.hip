@@ -459,18 +459,24 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
         // ---- depthwise 3x3 + gate from LDS: thread (ty, tx) owns disparity d0 + ty, 4 columns, ALL 6 output rows: the 8
         // computed rows slide through registers (one 16-byte + two 4-byte LDS reads per row instead of nine 16-byte reads
         // per output quad: this phase was bound by LDS bandwidth) ----
-        if (x0 < W) {
+        {
             float win[3][6];                                    // rows yo - 1, yo, yo + 1 of the current output row
 #pragma unroll
             for (int rr = 0; rr < FRC; ++rr) {
                 const float* vp = &vt[(ty * FRC + rr) * FVP + 4 + tx * 4];
                 const float4 M = *reinterpret_cast<const float4*>(vp);
-                const float l = vp[-1], rgt = vp[4];
+                // the two neighbouring columns come from the neighbouring LANES (a +-1 wave shift of M.w / M.x); only the first
+                // and last lane of a row read the seam columns from LDS.  (As two 4-byte LDS reads per lane at a 16-byte
+                // stride they were 8-way bank conflicts: 43 % of the kernel's LDS time, tools/pmc_sq.sh.)
+                float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, M.w), 0x138, 0xf, 0xf, false));   // lane n <- n - 1
+                float rgt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, M.x), 0x130, 0xf, 0xf, false)); // lane n <- n + 1
+                if (tx == 0) l = vp[-1];
+                if (tx == 31) rgt = vp[4];
                 const int slot = rr % 3;
                 win[slot][0] = l; win[slot][1] = M.x; win[slot][2] = M.y; win[slot][3] = M.z; win[slot][4] = M.w; win[slot][5] = rgt;
                 if (rr < 2) continue;
                 const int orow = rr - 2, yo = y0 + 1 + orow;      // output row whose window is complete
-                if (yo >= H) continue;
+                if (yo >= H || x0 >= W) continue;
                 float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
