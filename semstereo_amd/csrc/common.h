@@ -72,6 +72,17 @@ __device__ __forceinline__ float exp_fast(float x) {
     return __fmaf_rn(p, e * 0.693147180559945f, p);
 }
 
+// 16-byte LDS read that stays ONE ds_read_b128.  Through a plain float4 the optimiser splits the load into scalars,
+// drops unused lanes and re-merges the rest as 4- and 8-byte reads (gwc_patch_gate_v4: 56 LDS instructions per channel
+// block instead of 24, and at a 16-byte lane stride those are bank conflicts -- 47 -> 37 us, tools/pmc_sq.sh).
+// `p` must point into LDS and be 16-byte aligned.
+typedef float lds_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_read16(const float* p, float* dst) {
+    typedef const volatile lds_v4f __attribute__((address_space(3))) * ptr_t;
+    const lds_v4f q = *(ptr_t)(p);
+    dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+}
+
 }  // namespace ss
 
 // attention_tail.hip: wave-split softmax+regression+variance; returns non-zero if D is out of its range

@@ -48,9 +48,8 @@ __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict
     const float* tgtg = tgt + ((size_t)b * C + (size_t)g * CG) * plane;
 
     // ---- stage the (normalised) right-image tile, zero-extended by m columns per side ----
-    const int LQ = LW / 4;
-    for (int q = tid; q < RT * LQ; q += 32 * RT) {
-        const int row = q / LQ, qi = q - row * LQ;
+    // (the 128 central columns: one aligned quad per thread; then the m / 4 halo quads per side and row)
+    auto stage_right = [&](int row, int qi) {
         const int col0 = xt0 - m + qi * 4;
         const int y = y0 + row;
         float4 v[CG];
@@ -82,6 +81,12 @@ __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict
 #pragma unroll
         for (int c = 0; c < CG; ++c)
             *reinterpret_cast<float4*>(&lds[(c * RT + row) * LW + qi * 4]) = v[c];
+    };
+    const int HQ = m / 4;
+    stage_right(tid >> 5, HQ + (tid & 31));
+    for (int q = tid; q < RT * 2 * HQ; q += 32 * RT) {
+        const int row = q / (2 * HQ), k = q - row * 2 * HQ;
+        stage_right(row, k < HQ ? k : k + XT / 4);
     }
 
     // ---- this thread's 4 left-image pixels, all CG channels, in registers ----
@@ -135,9 +140,9 @@ __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict
         for (int c = 0; c < CG; ++c) {
             const float* lp = &lds[(c * RT + ty) * LW + base];
             float w[12];
-            *reinterpret_cast<float4*>(&w[0]) = *reinterpret_cast<const float4*>(lp);
-            *reinterpret_cast<float4*>(&w[4]) = *reinterpret_cast<const float4*>(lp + 4);
-            *reinterpret_cast<float4*>(&w[8]) = *reinterpret_cast<const float4*>(lp + 8);
+            ss::lds_read16(lp, &w[0]);
+            ss::lds_read16(lp + 4, &w[4]);
+            ss::lds_read16(lp + 8, &w[8]);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -343,9 +348,10 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
     const float* refg = ref + ((size_t)b * C + (size_t)g * CG) * plane;
     const float* tgtg = tgt + ((size_t)b * C + (size_t)g * CG) * plane;
 
-    const int LQ = LW / 4;
-    for (int q = tid; q < FRC * LQ; q += 32 * FRC) {
-        const int row = q / LQ, qi = q - row * LQ;
+    // The tile's 128 central columns are one aligned quad per thread (as the left image below); the (m + 4) / 4 halo quads per
+    // side and row follow in a second pass of (m + 4) / 2 * FRC threads.  (As one loop over all FRC * LW / 4 quads the first two
+    // waves normalised two quads each -- the second mostly out-of-image zeros -- while the others waited at the barrier.)
+    auto stage_right = [&](int row, int qi) {
         const int col0 = xt0 - m - 4 + qi * 4;
         const int y = y0 + row;
         float4 v[CG];
@@ -360,6 +366,12 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
         }
 #pragma unroll
         for (int c = 0; c < CG; ++c) *reinterpret_cast<float4*>(&tn[(c * FRC + row) * LW + qi * 4]) = v[c];
+    };
+    const int HQ = (m + 4) / 4;                                 // halo quads per side
+    stage_right(tid >> 5, HQ + (tid & 31));
+    for (int q = tid; q < FRC * 2 * HQ; q += 32 * FRC) {
+        const int row = q / (2 * HQ), k = q - row * 2 * HQ;
+        stage_right(row, k < HQ ? k : k + XT / 4);
     }
     if (tid < 2 * FRC) {                                        // the left image at x = xt0 - 1 and x = xt0 + 128
         // (normalised as the aligned quad that holds the column, through the same code as every other pixel: a scalar
@@ -427,9 +439,9 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
         for (int c = 0; c < CG; ++c) {
             const float* lp = &tn[(c * FRC + ty) * LW + base];
             float w[12];
-            *reinterpret_cast<float4*>(&w[0]) = *reinterpret_cast<const float4*>(lp);
-            *reinterpret_cast<float4*>(&w[4]) = *reinterpret_cast<const float4*>(lp + 4);
-            *reinterpret_cast<float4*>(&w[8]) = *reinterpret_cast<const float4*>(lp + 8);
+            ss::lds_read16(lp, &w[0]);
+            ss::lds_read16(lp + 4, &w[4]);
+            ss::lds_read16(lp + 8, &w[8]);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -464,7 +476,9 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
 #pragma unroll
             for (int rr = 0; rr < FRC; ++rr) {
                 const float* vp = &vt[(ty * FRC + rr) * FVP + 4 + tx * 4];
-                const float4 M = *reinterpret_cast<const float4*>(vp);
+                float mq[4];
+                ss::lds_read16(vp, mq);
+                const float4 M = make_float4(mq[0], mq[1], mq[2], mq[3]);
                 // the two neighbouring columns come from the neighbouring LANES (a +-1 wave shift of M.w / M.x); only the first
                 // and last lane of a row read the seam columns from LDS.  (As two 4-byte LDS reads per lane at a 16-byte
                 // stride they were 8-way bank conflicts: 43 % of the kernel's LDS time, tools/pmc_sq.sh.)
