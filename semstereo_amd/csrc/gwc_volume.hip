@@ -16,6 +16,7 @@
 // All global traffic is 16 B per lane, coalesced along W.
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -471,40 +472,50 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
         // ---- depthwise 3x3 + gate from LDS: thread (ty, tx) owns disparity d0 + ty, 4 columns, ALL 6 output rows: the 8
         // computed rows slide through registers (one 16-byte + two 4-byte LDS reads per row instead of nine 16-byte reads
         // per output quad: this phase was bound by LDS bandwidth) ----
-        {
-            float win[3][6];                                    // rows yo - 1, yo, yo + 1 of the current output row
+        // Two copies: tiles whose 8 computed rows and 128 columns all lie inside the image (all but the first and last row of
+        // tiles) run without a single bounds test; the border tiles take the checked form.
+        auto stencil = [&](auto checked) {
+            constexpr bool CHECK = decltype(checked)::value;
+            // a row of the window as aligned register PAIRS, in both phases: wa[k] = (x[2k], x[2k+1]), ws[k] = (x[2k+1], x[2k+2]) with
+            // x[0..5] = columns x0 - 1 .. x0 + 4
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 wa[3][3], ws[3][2];                              // [slot][pair]
 #pragma unroll
             for (int rr = 0; rr < FRC; ++rr) {
-                const float* vp = &vt[(ty * FRC + rr) * FVP + 4 + tx * 4];
+                const float* vrow = &vt[(ty * FRC + rr) * FVP];
                 float mq[4];
-                ss::lds_read16(vp, mq);
-                const float4 M = make_float4(mq[0], mq[1], mq[2], mq[3]);
-                // the two neighbouring columns come from the neighbouring LANES (a +-1 wave shift of M.w / M.x); only the first
-                // and last lane of a row read the seam columns from LDS.  (As two 4-byte LDS reads per lane at a 16-byte
-                // stride they were 8-way bank conflicts: 43 % of the kernel's LDS time, tools/pmc_sq.sh.)
-                float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, M.w), 0x138, 0xf, 0xf, false));   // lane n <- n - 1
-                float rgt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, M.x), 0x130, 0xf, 0xf, false)); // lane n <- n + 1
-                if (tx == 0) l = vp[-1];
-                if (tx == 31) rgt = vp[4];
+                ss::lds_read16(vrow + 4 + tx * 4, mq);
+                // the two neighbouring columns come from the neighbouring LANES (a +-1 wave shift of M.w / M.x); the first and
+                // last lane of a row take the seam columns, which every lane of the row reads from the same LDS address (a
+                // broadcast, no branch).  (As two 4-byte LDS reads per lane at a 16-byte stride they were 8-way bank
+                // conflicts: 43 % of the kernel's LDS time, tools/pmc_sq.sh.)
+                const float sl_ = vrow[3], sr_ = vrow[4 + XT];
+                float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mq[3]), 0x138, 0xf, 0xf, false));   // lane n <- n - 1
+                float rgt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mq[0]), 0x130, 0xf, 0xf, false)); // lane n <- n + 1
+                l = (tx == 0) ? sl_ : l;
+                rgt = (tx == 31) ? sr_ : rgt;
                 const int slot = rr % 3;
-                win[slot][0] = l; win[slot][1] = M.x; win[slot][2] = M.y; win[slot][3] = M.z; win[slot][4] = M.w; win[slot][5] = rgt;
+                wa[slot][0] = f2{l, mq[0]}; wa[slot][1] = f2{mq[1], mq[2]}; wa[slot][2] = f2{mq[3], rgt};
+                ws[slot][0] = f2{mq[0], mq[1]}; ws[slot][1] = f2{mq[2], mq[3]};
                 if (rr < 2) continue;
                 const int orow = rr - 2, yo = y0 + 1 + orow;      // output row whose window is complete
-                if (yo >= H || x0 >= W) continue;
-                float o[4] = {0.f, 0.f, 0.f, 0.f};
+                if (CHECK && (yo >= H || x0 >= W)) continue;
+                f2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    if ((unsigned)(yo + ky - 1) >= (unsigned)H) continue;        // (as depthwise_patch_v4: the row is skipped)
-                    const float* x = win[(orow + ky) % 3];
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = fmaf(wv[ky * 3 + kx], x[j + kx], o[j]);
+                    if (CHECK && (unsigned)(yo + ky - 1) >= (unsigned)H) continue;        // (as depthwise_patch_v4: the row is skipped)
+                    const int sl = (orow + ky) % 3;
+                    const f2 w0 = {wv[ky * 3], wv[ky * 3]}, w1 = {wv[ky * 3 + 1], wv[ky * 3 + 1]}, w2 = {wv[ky * 3 + 2], wv[ky * 3 + 2]};
+                    o01 = __builtin_elementwise_fma(w0, wa[sl][0], o01); o23 = __builtin_elementwise_fma(w0, wa[sl][1], o23);
+                    o01 = __builtin_elementwise_fma(w1, ws[sl][0], o01); o23 = __builtin_elementwise_fma(w1, ws[sl][1], o23);
+                    o01 = __builtin_elementwise_fma(w2, wa[sl][1], o01); o23 = __builtin_elementwise_fma(w2, wa[sl][2], o23);
                 }
+                float o[4] = {o01.x, o01.y, o23.x, o23.y};
                 if (gateg) {
-                    const float4 sg = *reinterpret_cast<const float4*>(&sgt[orow * XT + tx * 4]);
-                    o[0] = ss::mul_rn(sg.x, o[0]); o[1] = ss::mul_rn(sg.y, o[1]);
-                    o[2] = ss::mul_rn(sg.z, o[2]); o[3] = ss::mul_rn(sg.w, o[3]);
+                    float sg[4];
+                    ss::lds_read16(&sgt[orow * XT + tx * 4], sg);
+                    o[0] = ss::mul_rn(sg[0], o[0]); o[1] = ss::mul_rn(sg[1], o[1]);
+                    o[2] = ss::mul_rn(sg[2], o[2]); o[3] = ss::mul_rn(sg[3], o[3]);
                 }
                 float* op = outg + (size_t)(d0 + ty) * plane + (size_t)yo * W + x0;
                 if (STREAM) {
@@ -515,7 +526,9 @@ __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __res
                     *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
-        }
+        };
+        if (y0 >= 0 && y0 + FRC <= H && xt0 + XT <= W) stencil(std::false_type{});
+        else stencil(std::true_type{});
         __syncthreads();
     }
 }
