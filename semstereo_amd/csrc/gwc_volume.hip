@@ -27,6 +27,44 @@ constexpr float kEps = 1e-05f;
 
 constexpr int RT = 4;     // rows per workgroup tile (measured against 8: never slower, +5 % at B=8)
 
+// x / (||x||_2 + 1e-5) over the CG channels of 4 pixels (models/submodule.py:200-205).  The CG quotients of a pixel share
+// their divisor: ONE IEEE reciprocal r = RN(1/s) per pixel, then per channel q = v * r (faithful), e = v - s * q (exact, one
+// fma), q' = RN(q + e * r) -- Markstein's correction step, which returns the correctly rounded v / s (what the plain
+// division computes with ~10 instructions per quotient instead of 3) unless the significand of s is all ones or
+// |v| < 2^-100 s (then it may differ in the last bit).  Pixels whose divisor is not finite take the plain division.
+template <int CG>
+__device__ __forceinline__ void l2_normalise4(float4 (&v)[CG]) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        s.x = ss::add_rn(s.x, ss::mul_rn(v[c].x, v[c].x));
+        s.y = ss::add_rn(s.y, ss::mul_rn(v[c].y, v[c].y));
+        s.z = ss::add_rn(s.z, ss::mul_rn(v[c].z, v[c].z));
+        s.w = ss::add_rn(s.w, ss::mul_rn(v[c].w, v[c].w));
+    }
+    s.x = sqrtf(s.x) + kEps; s.y = sqrtf(s.y) + kEps;
+    s.z = sqrtf(s.z) + kEps; s.w = sqrtf(s.w) + kEps;
+    const float big = 3.0e38f;
+    if (s.x < big && s.y < big && s.z < big && s.w < big) {              // (NaN compares false)
+        const float4 r = make_float4(1.0f / s.x, 1.0f / s.y, 1.0f / s.z, 1.0f / s.w);
+        auto quot = [](float a, float d, float rd) {
+            const float q = ss::mul_rn(a, rd);
+            return __fmaf_rn(__fmaf_rn(-d, q, a), rd, q);
+        };
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            v[c].x = quot(v[c].x, s.x, r.x); v[c].y = quot(v[c].y, s.y, r.y);
+            v[c].z = quot(v[c].z, s.z, r.z); v[c].w = quot(v[c].w, s.w, r.w);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            v[c].x = v[c].x / s.x; v[c].y = v[c].y / s.y;
+            v[c].z = v[c].z / s.z; v[c].w = v[c].w / s.w;
+        }
+    }
+}
+
 // STREAM: write the volume with nontemporal stores.  Kernel alone: -10 % time at every size; but a
 // volume that fits the 256 MB infinity cache is re-read from there by the next kernel of the path,
 // and streaming it past the cache costs the consumer more than it saves here (measured on the live
@@ -58,23 +96,7 @@ __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict
             const float* p = tgtg + (size_t)y * W + col0;
 #pragma unroll
             for (int c = 0; c < CG; ++c) v[c] = *reinterpret_cast<const float4*>(p + c * plane);
-            if (NORM) {
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int c = 0; c < CG; ++c) {
-                    s.x = ss::add_rn(s.x, ss::mul_rn(v[c].x, v[c].x));
-                    s.y = ss::add_rn(s.y, ss::mul_rn(v[c].y, v[c].y));
-                    s.z = ss::add_rn(s.z, ss::mul_rn(v[c].z, v[c].z));
-                    s.w = ss::add_rn(s.w, ss::mul_rn(v[c].w, v[c].w));
-                }
-                s.x = sqrtf(s.x) + kEps; s.y = sqrtf(s.y) + kEps;
-                s.z = sqrtf(s.z) + kEps; s.w = sqrtf(s.w) + kEps;
-#pragma unroll
-                for (int c = 0; c < CG; ++c) {
-                    v[c].x = v[c].x / s.x; v[c].y = v[c].y / s.y;
-                    v[c].z = v[c].z / s.z; v[c].w = v[c].w / s.w;
-                }
-            }
+            if (NORM) l2_normalise4<CG>(v);
         } else {
 #pragma unroll
             for (int c = 0; c < CG; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -101,23 +123,7 @@ __global__ __launch_bounds__(32 * RT) void gwc_volume_v4(const float* __restrict
         float4 v[CG];
 #pragma unroll
         for (int c = 0; c < CG; ++c) v[c] = *reinterpret_cast<const float4*>(p + c * plane);
-        if (NORM) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < CG; ++c) {
-                s.x = ss::add_rn(s.x, ss::mul_rn(v[c].x, v[c].x));
-                s.y = ss::add_rn(s.y, ss::mul_rn(v[c].y, v[c].y));
-                s.z = ss::add_rn(s.z, ss::mul_rn(v[c].z, v[c].z));
-                s.w = ss::add_rn(s.w, ss::mul_rn(v[c].w, v[c].w));
-            }
-            s.x = sqrtf(s.x) + kEps; s.y = sqrtf(s.y) + kEps;
-            s.z = sqrtf(s.z) + kEps; s.w = sqrtf(s.w) + kEps;
-#pragma unroll
-            for (int c = 0; c < CG; ++c) {
-                v[c].x = v[c].x / s.x; v[c].y = v[c].y / s.y;
-                v[c].z = v[c].z / s.z; v[c].w = v[c].w / s.w;
-            }
-        }
+        if (NORM) l2_normalise4<CG>(v);
 #pragma unroll
         for (int c = 0; c < CG; ++c) { r[c][0] = v[c].x; r[c][1] = v[c].y; r[c][2] = v[c].z; r[c][3] = v[c].w; }
     } else {
@@ -310,24 +316,6 @@ __global__ void gwc_volume_bwd_kernel(const float* __restrict__ gout, const floa
 // two-kernel form.
 constexpr int FRO = 6, FRC = FRO + 2, FVP = XT + 8;
 
-template <int CG>
-__device__ __forceinline__ void l2_normalise4(float4 (&v)[CG]) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < CG; ++c) {
-        s.x = ss::add_rn(s.x, ss::mul_rn(v[c].x, v[c].x));
-        s.y = ss::add_rn(s.y, ss::mul_rn(v[c].y, v[c].y));
-        s.z = ss::add_rn(s.z, ss::mul_rn(v[c].z, v[c].z));
-        s.w = ss::add_rn(s.w, ss::mul_rn(v[c].w, v[c].w));
-    }
-    s.x = sqrtf(s.x) + kEps; s.y = sqrtf(s.y) + kEps;
-    s.z = sqrtf(s.z) + kEps; s.w = sqrtf(s.w) + kEps;
-#pragma unroll
-    for (int c = 0; c < CG; ++c) {
-        v[c].x = v[c].x / s.x; v[c].y = v[c].y / s.y;
-        v[c].z = v[c].z / s.z; v[c].w = v[c].w / s.w;
-    }
-}
 
 template <int CG, bool NORM, bool STREAM>
 __global__ __launch_bounds__(32 * FRC) void gwc_patch_gate_v4(const float* __restrict__ ref, const float* __restrict__ tgt,
