@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (7): bumped on any signature change or new entry point the Python binding requires. */
+/* ABI version (8): bumped on any signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
  * measurement aids) are read from the environment ONCE per process; call this after changing
@@ -261,6 +261,17 @@ int ss_conv3d_head_bf16s_fwd(const float* in, const void* wsplit, const float* s
                              float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
                              ss_stream_t stream);
 int ss_pack_conv3d_head_weights_bf16s(const float* w, void* wsplit, int Cin, ss_stream_t stream);
+/* The two layers of a classifier (nn.Sequential(convbn_3d(32,32,3,1,1), ReLU, Conv3d(32,1,3,p1)), models/SemStereo.py:228-234)
+ * hand their intermediate over CHANNELS-LAST, [B][D][H][W][C]: it is private to the Sequential, and with a position's
+ * channels contiguous the first layer stores 16 bytes per lane and instruction and the head loads 16 (the head spends half
+ * of its time issuing 4-byte loads otherwise).  ss_conv3d_bf16s_cl_fwd = ss_conv3d_bf16s_fwd (stride 1, no residual, no
+ * gate, Cout % 8 == 0) with that output layout; ss_conv3d_head_bf16s_cl_fwd = ss_conv3d_head_bf16s_fwd reading it
+ * (Cin = 32, `in` 16-byte aligned).  Same arithmetic, same results as the plain-layout pair. */
+int ss_conv3d_bf16s_cl_fwd(const float* in, const void* wsplit, const float* scale, const float* shift, float* out,
+                           int B, int Cin, int D, int H, int W, int Cout, int relu, int nterms, ss_stream_t stream);
+int ss_conv3d_head_bf16s_cl_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
+                                ss_stream_t stream);
 /* 1x1x1 Conv3d / per-position Linear (+ per-channel affine: bias; ReLU) on the split-bf16 engine:
  * qkv_3d and final1x1 of attention_block (models/submodule_other.py:804, 835).
  *   out [B,Cout,npos] = relu?(scale * (W in) + shift), in [B,Cin,npos], npos = D*H*W, W [Cout,Cin];

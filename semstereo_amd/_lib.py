@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -51,6 +51,8 @@ _SIGNATURES = {
     "ss_pack_conv2d_weights_bf16s": [_P, _P, _I, _I, _P],
     "ss_pack_conv2d_weights_f16s": [_P, _P, _I, _I, _P],
     "ss_conv3d_head_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_conv3d_head_bf16s_cl_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_conv3d_bf16s_cl_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_head_weights_bf16s": [_P, _P, _I, _P],
     "ss_conv3d_pointwise_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_longlong, _I, _I, _P],
     "ss_pack_pointwise_weights_bf16s": [_P, _P, _I, _I, _P],

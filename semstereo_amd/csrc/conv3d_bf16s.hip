@@ -101,6 +101,8 @@ constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
 // their own kernel symbol in a profile: conv3d_bf16s<..., true>)
 // MT: 32-channel output tiles per wave (the activation fragments of a row then feed MT x 6 MFMAs: used by the stride-2
 // layers, whose staging is 8x dearer per MFMA and whose 2-4 output tiles would otherwise each stage the same input)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
 __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
@@ -144,6 +146,11 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // elsewhere (stem_left.hip).  It joins the accumulator in the epilogue, fetched together with the gate (as initial
     // accumulators its 64 loads per lane were 14 k cycles of every workgroup's prologue: tools/wg_phases.py).
     const bool res_pre = (relu & 2) != 0 && residual != nullptr;
+    // bit 2: CHANNELS-LAST output [Do][Ho][Wo][Cout] (the hand-off to the 32 -> 1 head of the same classifier, conv3d_head.hip,
+    // which wants 8 consecutive channels of a position per lane): a lane's 4 consecutive channels of a fragment register
+    // group go out as one 16-byte store instead of four 4-byte ones.  Plain stride-1 form only, Cout % 8 == 0.
+    constexpr bool CAN_CL = !GATED && MT == 1 && S == 1 && KD == 3;
+    const bool out_cl = CAN_CL && (relu & 4) != 0;
     // f16 form: float[Cout] of 2^-(weight scale of the channel), stored behind the packed terms
     const float* wunscale = reinterpret_cast<const float*>(
         reinterpret_cast<const char*>(wsplit) + (size_t)((Cin + 7) / 8) * C::KSTEPS * ((NTERMS == F16X3 ? 2 : 3) * 2 * Cout * 16));
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             const int oh_ = oh0 + hy0 + i;
             const bool ok = ow_ < Wo && od_ < Do && oh_ < Ho;
             vout[i] = ok ? (unsigned)((((size_t)od_ * Ho + oh_) * Wo + ow_) * 4) + 4u * half * ochan_b : 0x80000000u;
+            if (CAN_CL && out_cl) vout[i] = ok ? (unsigned)((((size_t)od_ * Ho + oh_) * Wo + ow_) * Cout * 4) + 16u * half : 0x80000000u;
             vgate[i] = ok ? (unsigned)(((size_t)oh_ * Wo + ow_) * 4) + 4u * half * gchan_b : 0x80000000u;
         }
     };
@@ -487,11 +495,10 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
                 for (int i = 0; i < NT; ++i) rv[q][i] = 0.f;
         }
+        float vv[EG][NT];
 #pragma unroll
         for (int q = 0; q < EG; ++q) {
             const int r = r0 + q;
-            const int cb = cbase(mt, r);
-            const bool cok = cb + 4 * half < Cout;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 float a0 = F16 ? acc[mt * NT + i][r] * un[q] : acc[mt * NT + i][r];
@@ -500,8 +507,29 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                 if (res_epi) v = ss::add_rn(v, rv[q][i]);
                 v = fmaxf(v, floor_v);
                 if (GATED) v = ss::mul_rn(gv[q][i], v);     // channelAtt gate, broadcast over D
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)(cok ? vout[i] : 0x80000000u),
-                                                      cb * (int)ochan_b, 0);
+                vv[q][i] = v;
+            }
+        }
+        if (CAN_CL && out_cl) {
+#pragma unroll
+            for (int g4 = 0; g4 < EG; g4 += 4) {
+                const int cb = cbase(mt, r0 + g4);           // channels cb + 4 * half .. + 3 sit in registers r0 + g4 .. + 3
+                const bool cok = cb + 4 * half < Cout;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(u32x4_t, make_float4(vv[g4][i], vv[g4 + 1][i], vv[g4 + 2][i], vv[g4 + 3][i])), ores,
+                        (int)(cok ? vout[i] : 0x80000000u), cb * 4, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EG; ++q) {
+                const int cb = cbase(mt, r0 + q);
+                const bool cok = cb + 4 * half < Cout;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[q][i]), ores,
+                                                          (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, 0);
             }
         }
     }
@@ -636,6 +664,13 @@ extern "C" int ss_conv3d_bf16s_partial_fwd(const float* in, const void* wsplit, 
                                            int H, int W, int Cout, int relu, int nterms, ss_stream_t stream) {
     SS_REQUIRE(partial != nullptr);
     return conv3d_bf16s_impl(in, wsplit, scale, shift, partial, gate, out, B, Cin, D, H, W, Cout, 1, (relu ? 1 : 0) | 2, nterms,
+                             stream);
+}
+
+extern "C" int ss_conv3d_bf16s_cl_fwd(const float* in, const void* wsplit, const float* scale, const float* shift, float* out,
+                                      int B, int Cin, int D, int H, int W, int Cout, int relu, int nterms, ss_stream_t stream) {
+    SS_REQUIRE(Cout > 0 && Cout % 8 == 0);
+    return conv3d_bf16s_impl(in, wsplit, scale, shift, nullptr, nullptr, out, B, Cin, D, H, W, Cout, 1, (relu ? 1 : 0) | 4, nterms,
                              stream);
 }
 

@@ -54,7 +54,11 @@ __host__ __device__ inline int head_row_tap(int i) {
     return reg < 12 ? (5 + reg / 3) * 3 + reg % 3 : -1;
 }
 
-template <int TD, int TH, int KS, int NTERMS>     // KS = Cin / 16
+// CL: the input is CHANNELS-LAST [D][H][W][Cin] (written so by ss_conv3d_bf16s_cl_fwd, the first layer of the same classifier):
+// a lane's 8 channels of a position are 32 consecutive bytes, two 16-byte loads instead of eight 4-byte ones -- the plain
+// layout keeps the CU's address path busy for 16 cycles per 4-byte wave load, 40 us of this kernel's 78 with as many again
+// for the matrix work (tools/_build ablations).
+template <int TD, int TH, int KS, int NTERMS, bool CL = false>     // KS = Cin / 16
 __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              float* __restrict__ out, int D, int H, int W, int tiles_w,
@@ -83,78 +87,75 @@ __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restr
     const int gw = w0 - 1 + l31;
     const bool col_ok = (unsigned)gw < (unsigned)W;
     // lane part of the offset: this lane's 8-channel block and column (beyond the buffer when outside the row)
-    const unsigned lane_off = col_ok ? (unsigned)((size_t)(8 * half) * chan * 4 + (size_t)gw * 4) : 0x80000000u;
+    const unsigned lane_off = !col_ok ? 0x80000000u
+                              : CL ? (unsigned)((size_t)gw * Cin * 4 + 32 * half) : (unsigned)((size_t)(8 * half) * chan * 4 + (size_t)gw * 4);
 
-    // This wave's input rows r = wave + 4*i, in groups of GR: the loads of a whole group (GR x KS x 8 per lane)
-    // are in flight while the previous group is multiplied -- one row ahead does not cover HBM latency with
-    // only two waves per SIMD.
-    constexpr int NRW = NR / 4, GR = (KS <= 2) ? 5 : 2, NG = (NRW + GR - 1) / GR;
+    // This wave's input rows r = wave + 4*i, a ring of PD rows ahead of the one being multiplied: the loads of row i + PD are
+    // issued right before row i's arithmetic and the scheduler is fenced per row, so every wave keeps PD * KS * 8 loads per
+    // lane in flight THROUGH its arithmetic.  (Loaded in groups of 5 rows the compiler hoisted all of a wave's loads to the top
+    // of the kernel: the workgroups of a round, started together, first all waited for memory and then all multiplied -- with
+    // the loads or the MFMAs removed the kernel took 40 us either way, with both 78.)
+    constexpr int NRW = NR / 4, PD = (KS <= 2) ? 3 : 2;
     static_assert(NR % 4 == 0, "rows split evenly over the 4 waves");
-    auto row_valid = [&](int r) {
+    auto load_row = [&](float (&x)[KS][8], int i) {
+        const int r = wave + 4 * i;
+        // rows outside the volume are requested beyond the buffer (no access, zeros) instead of skipped: a load under a
+        // branch makes the compiler's wait-count pass fall back to vmcnt(0) at the merge, i.e. drain the whole prefetch
         const int gd = d0 - 1 + r / IH, gh = h0 - 1 + r % IH;
-        return (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
-    };
-    auto load_group = [&](float (&xg)[GR][KS][8], int gi) {
+        const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && col_ok;
+        const unsigned off = ok ? lane_off + (unsigned)(((size_t)gd * H + gh) * W * 4 * (CL ? Cin : 1)) : 0x80000000u;
 #pragma unroll
-        for (int k = 0; k < GR; ++k) {
-            const int i = gi * GR + k;
-            if (i >= NRW) continue;
-            const int r = wave + 4 * i;
-            // rows outside the volume are requested beyond the buffer (no access, zeros) instead of skipped: a load under a
-            // branch makes the compiler's wait-count pass fall back to vmcnt(0) at the merge, i.e. drain the whole prefetch
-            const int gd = d0 - 1 + r / IH, gh = h0 - 1 + r % IH;
-            const unsigned off = (row_valid(r) && col_ok) ? lane_off + (unsigned)(((size_t)gd * H + gh) * W * 4) : 0x80000000u;
+        for (int ks = 0; ks < KS; ++ks) {
+            if (CL) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+                for (int j4 = 0; j4 < 2; ++j4) {
+                    const float4 q = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ires, (int)off, ks * 64 + j4 * 16, 0));
+                    x[ks][4 * j4] = q.x; x[ks][4 * j4 + 1] = q.y; x[ks][4 * j4 + 2] = q.z; x[ks][4 * j4 + 3] = q.w;
+                }
+            } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    xg[k][ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)off, (ks * 16 + j) * chan_b, 0));
-        }
-    };
-    auto process_group = [&](float (&xg)[GR][KS][8], int gi) {
-#pragma unroll
-        for (int k = 0; k < GR; ++k) {
-            const int i = gi * GR + k;
-            if (i >= NRW) continue;
-            const int r = wave + 4 * i;
-            f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-            {                                            // (rows outside the volume were read as zeros)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    unsigned bh[4], bm[4], bl[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) split3_pk(xg[k][ks][2 * j], xg[k][ks][2 * j + 1], bh[j], bm[j], bl[j]);
-                    const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
-                    const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
-                    if (NTERMS == 6) {
-                        const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], m8, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], l8, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][NC - 1], h8, acc, 0, 0, 0);
-                    }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], m8, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], h8, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], h8, acc, 0, 0, 0);
-                }
-            }
-            // kw = 0 comes from the column to the left, kw = 2 from the column to the right
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const float sv = ss::add_rn(ss::add_rn(from_lane_below(acc[3 * q]), acc[3 * q + 1]), from_lane_above(acc[3 * q + 2]));
-                if (half == 0 || q < 4) S[((half ? 5 + q : q) * NR + r) * 32 + l31] = sv;
+                    x[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)off, (ks * 16 + j) * chan_b, 0));
             }
         }
     };
-    float xa[GR][KS][8], xb[GR][KS][8];
-    load_group(xa, 0);
+    auto process_row = [&](float (&x)[KS][8], int i) {
+        const int r = wave + 4 * i;
+        f32x16 acc;
 #pragma unroll
-    for (int gi = 0; gi < NG; gi += 2) {
-        if (gi + 1 < NG) load_group(xb, gi + 1);
-        process_group(xa, gi);
-        if (gi + 2 < NG) load_group(xa, gi + 2);
-        if (gi + 1 < NG) process_group(xb, gi + 1);
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {                   // (rows outside the volume were read as zeros)
+            unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split3_pk(x[ks][2 * j], x[ks][2 * j + 1], bh[j], bm[j], bl[j]);
+            const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+            if (NTERMS == 6) {
+                const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], m8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], l8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][NC - 1], h8, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], m8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], h8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], h8, acc, 0, 0, 0);
+        }
+        // kw = 0 comes from the column to the left, kw = 2 from the column to the right
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const float sv = ss::add_rn(ss::add_rn(from_lane_below(acc[3 * q]), acc[3 * q + 1]), from_lane_above(acc[3 * q + 2]));
+            if (half == 0 || q < 4) S[((half ? 5 + q : q) * NR + r) * 32 + l31] = sv;
+        }
+    };
+    float xr[PD + 1][KS][8];
+#pragma unroll
+    for (int k = 0; k < PD && k < NRW; ++k) load_row(xr[k], k);
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        if (i + PD < NRW) load_row(xr[(i + PD) % (PD + 1)], i + PD);
+        process_row(xr[i % (PD + 1)], i);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
 
@@ -193,13 +194,13 @@ __global__ void pack_head_weights_kernel(const float* __restrict__ w, unsigned s
     wsplit[i] = (unsigned short)((term == 0 ? h : (term == 1 ? m : l)) & 0xffffu);
 }
 
-template <int TD, int TH, int KS, int NTERMS>
+template <int TD, int TH, int KS, int NTERMS, bool CL>
 int launch_head(const float* in, const void* wsplit, const float* scale, const float* shift, float* out, int B, int D,
                 int H, int W, int relu, hipStream_t st) {
     const int tiles_w = ss::ceil_div(W, TWO), tiles_h = ss::ceil_div(H, TH), tiles_d = ss::ceil_div(D, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = conv3d_head_bf16s<TD, TH, KS, NTERMS>;
+    auto kern = conv3d_head_bf16s<TD, TH, KS, NTERMS, CL>;
     const size_t lds = (size_t)9 * (TD + 2) * (TH + 2) * 32 * sizeof(float);
     if (lds > 64 * 1024) {
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
@@ -209,14 +210,14 @@ int launch_head(const float* in, const void* wsplit, const float* scale, const f
     return ss::check_launch();
 }
 
-template <int KS, int NTERMS>
+template <int KS, int NTERMS, bool CL = false>
 int launch_head_tile(const float* in, const void* wsplit, const float* scale, const float* shift, float* out, int B, int D,
                      int H, int W, int relu, hipStream_t st) {
     // 4 planes x 8 rows per workgroup unless that leaves the chip short of workgroups (small volumes)
     const long long big = (long long)ss::ceil_div(W, TWO) * ss::ceil_div(H, 8) * ss::ceil_div(D, 4) * B;
     if (big >= 1024 && D >= 4)
-        return launch_head<4, 8, KS, NTERMS>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
-    return launch_head<2, 8, KS, NTERMS>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
+        return launch_head<4, 8, KS, NTERMS, CL>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
+    return launch_head<2, 8, KS, NTERMS, CL>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
 }
 
 }  // namespace
@@ -412,5 +413,19 @@ extern "C" int ss_conv3d_pointwise_bf16s_fwd(const float* in, const void* wsplit
     SS_PW(4)
     SS_PW(8)
 #undef SS_PW
+    return SS_ERR_UNSUPPORTED;
+}
+
+extern "C" int ss_conv3d_head_bf16s_cl_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                           float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
+                                           ss_stream_t stream) {
+    SS_REQUIRE(in && wsplit && out);
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE(((reinterpret_cast<uintptr_t>(wsplit) | reinterpret_cast<uintptr_t>(in)) & 15) == 0);
+    if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipStream_t st = ss::as_stream(stream);
+    if (Cin == 32)
+        return nterms == 6 ? launch_head_tile<2, 6, true>(in, wsplit, scale, shift, out, B, D, H, W, relu, st)
+                           : launch_head_tile<2, 3, true>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
     return SS_ERR_UNSUPPORTED;
 }

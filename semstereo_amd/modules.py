@@ -245,6 +245,20 @@ def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None,
     return out
 
 
+def classifier_cl_hip(x, ws0, scale0, shift0, nterms0, ws2, nterms2):
+    """nn.Sequential(convbn_3d(C,C,3,1,1), ReLU, Conv3d(C,1,3,p1)) (models/SemStereo.py:228-234) as two launches whose
+    intermediate is channels-last [B,D,H,W,C] (private to the pair: 16-byte stores in the first, 16-byte loads in the head)."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, scale0, shift0)
+    B, C, D, H, W = x.shape
+    mid = torch.empty((B, D, H, W, C), dtype=x.dtype, device=x.device)
+    out = torch.empty((B, 1, D, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(dev):
+        call("ss_conv3d_bf16s_cl_fwd", ptr(x), ptr(ws0), ptr(scale0), ptr(shift0), ptr(mid), B, C, D, H, W, C, 1, int(nterms0))
+        call("ss_conv3d_head_bf16s_cl_fwd", ptr(mid), ptr(ws2), None, None, ptr(out), B, C, D, H, W, 0, int(nterms2))
+    return out
+
+
 def pack_conv2d_weight_bf16s(w, nterms=6):
     """[Cout,Cin,3,3] fp32 -> split fragments for ss_conv2d_bf16s_fwd (three bf16 terms, or two scaled fp16 terms: nterms 19)."""
     w = w.detach().float().contiguous()
@@ -404,6 +418,7 @@ def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
 # (main_us3d.py:186-222 back-propagates through the whole stack; BatchNorm with batch statistics and ReLU stay PyTorch)
 # --------------------------------------------------------------------------------------
 
+CLASSIFIER_CL = os.environ.get("SS_CLASSIFIER_CL", "1") != "0"    # 0: plain-layout intermediate inside the classifiers (two generic launches)
 TRAIN_HIP = os.environ.get("SS_TRAIN_HIP", "1") != "0"      # 0: the stock PyTorch layers whenever autograd / batch statistics are needed
 
 
@@ -856,8 +871,19 @@ class Classifier(nn.Sequential):
     def forward(self, x):
         if _inference(self, x):
             PATH_COUNTS["hip"] += 1
-            y = run_convbn(self, "h0", self[0][0], self[0][1], x, relu=True)
-            return run_convbn(self, "h2", self[2], None, y, relu=False)
+            c0, bn0, c2 = self[0][0], self[0][1], self[2]
+            if (CLASSIFIER_CL and CONV_ENGINE != "f32" and c0.in_channels == c0.out_channels == c2.in_channels == 32
+                    and _conv_geometry(c0) == (3, 1) and _conv_geometry(c2) == (3, 1) and c2.out_channels == 1):
+                nt0, nt2 = _tiled_nterms(), _aux_nterms()
+
+                def build():
+                    sc, sh = fold_bn(bn0)
+                    return pack_conv_weight_bf16s(c0.weight, nt0), sc, sh, pack_head_weight_bf16s(c2.weight)
+                srcs = [c0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, c2.weight]
+                ws0, sc, sh, ws2 = _cache(self).get("cl/%d/%d" % (nt0, nt2), srcs, build)
+                return classifier_cl_hip(x, ws0, sc, sh, nt0, ws2, nt2)
+            y = run_convbn(self, "h0", c0, bn0, x, relu=True)
+            return run_convbn(self, "h2", c2, None, y, relu=False)
         PATH_COUNTS["torch"] += 1
         return super().forward(x)
 

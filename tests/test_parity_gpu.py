@@ -542,6 +542,28 @@ def test_conv3d_head_split_bf16(sa, case, nterms):
     refn = F.conv3d(x.double(), w.double(), None, 1, 1)
     assert float((yn.double().cpu() - refn).abs().max()) <= (4e-6 if nterms == 6 else 4e-5)
 
+@pytest.mark.parametrize("shape", [(2, 5, 9, 37), (1, 8, 24, 64), (1, 4, 70, 95), (1, 1, 1, 1), (1, 24, 64, 96)])
+def test_classifier_channels_last_handoff_is_bit_identical(sa, shape, monkeypatch):
+    """`classif` / `classif_att_` (models/SemStereo.py:228-234): the pair of launches that hands its intermediate over
+    channels-last computes exactly what the plain-layout pair computes (same arithmetic, another address pattern), on every
+    tile shape of the first layer (4x4x32, 2x8x32, 1x8x32, 1x4x32) and of the head, ragged widths included."""
+    from oracle import detdata as dd
+    B, D, H, W = shape
+    m = sa.modules.Classifier(32).cuda().eval()
+    with torch.no_grad():
+        for i, p in enumerate(m.parameters()):
+            p.copy_(dev(dd.t_uniform(tuple(p.shape), 900 + i, -1, 1) * (0.05 if p.dim() > 1 else 1.0)))
+        m[0][1].running_mean.copy_(dev(dd.t_uniform((32,), 910, -0.1, 0.1)))
+        m[0][1].running_var.copy_(dev(dd.t_uniform((32,), 911, 0.6, 1.4)))
+    x = dev(dd.t_normalish((B, 32, D, H, W), 912))
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(sa.modules, "CLASSIFIER_CL", flag)
+        with torch.no_grad():
+            outs.append(m(x))
+    assert outs[0].shape == (B, 1, D, H, W)
+    assert torch.equal(outs[0], outs[1])
+
 
 @pytest.mark.parametrize("nterms", [6, 19])
 @pytest.mark.parametrize("case", [(64, 128, 4, 7, 40), (32, 64, 6, 10, 34), (20, 40, 3, 5, 9), (64, 128, 16, 64, 64)])

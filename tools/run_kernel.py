@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
-usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att warp ssr ssr2048 strength topk
+usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain warp ssr ssr2048 strength topk
                                                                catt8 catt4 upsoft stem_left conv_s1 conv_s2 deconv"""
 import os
 import sys
@@ -11,6 +11,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import semstereo_amd as sa  # noqa: E402
+
+if os.environ.get("SS_TOOL_LIB"):          # experimental builds of the library (tools/_build)
+    sa._lib.LIB_PATH = os.path.abspath(os.environ["SS_TOOL_LIB"])
 
 name = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -34,6 +37,12 @@ elif name in ("head", "head_att"):
     ws = M.pack_head_weight_bf16s(R(1, 32, 3, 3, 3))
     fn = lambda: M.conv3d_head_bf16s_hip(x, ws, None, None, False, 6)          # noqa: E731
     nbytes = 4.0 * B * 33 * D * H * H
+elif name in ("classif", "classif_plain"):                # the whole classifier: conv 32->32 + BN + ReLU, then the 32->1 head
+    M.CLASSIFIER_CL = name == "classif"
+    cl = M.Classifier(32).to(dev).eval()
+    x = torch.relu(R(B, 32, 24, 256, 256))
+    fn = lambda: cl(x)                                                         # noqa: E731
+    nbytes = 4.0 * B * (32 + 32 + 32 + 1) * 24 * 256 * 256
 elif name == "warp":
     cr, smp = R(B, 32, 256, 256), torch.randint(-32, 32, (B, 24, 256, 256), device=dev).float().sort(dim=1).values
     att = torch.rand(B, 24, 256, 256, device=dev)
