@@ -116,6 +116,27 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
 
+def steady_ms(run, iters=20, warm_ms=200.0):
+    """Mean launch time of `run` between two HIP events on the current stream, after `warm_ms` of back-to-back launches of the
+    same kernel (the clock the chip holds under THIS kernel's load, not the one the previous micro-run left behind: the
+    issue-bound kernels read up to 10 % slower right after a memory-bound one)."""
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    while (time.time() - t0) * 1e3 < warm_ms:
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this file and relay
     rank 0's stdout (the JSON line).  The parent has made no GPU/HIP call (nothing before this point touches
@@ -403,15 +424,7 @@ def main():
         g8 = torch.Generator(device=device).manual_seed(7)
         a8 = torch.randn(8, 256, H8, W8, generator=g8, device=device)
         b8 = torch.randn(8, 256, H8, W8, generator=g8, device=device)
-        for _ in range(3):
-            semstereo_amd.ops.build_gwc_volume_norm(a8, b8, maxdisp // 8, 32)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            semstereo_amd.ops.build_gwc_volume_norm(a8, b8, maxdisp // 8, 32)
-        e1.record()
-        torch.cuda.synchronize()
-        ms8 = e0.elapsed_time(e1) / 20
+        ms8 = steady_ms(lambda: semstereo_amd.ops.build_gwc_volume_norm(a8, b8, maxdisp // 8, 32))
         nb8 = 8 * nbytes / B
         res["roofline_cost_volume_b8"] = {"kernel": "gwc_volume_v4<8,true,stream>, batch 8 (BASELINE.json configs[2])", "bound": "hbm",
                                           "achieved": nb8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -445,15 +458,7 @@ def main():
         gl8 = torch.randn(8, 32, H8, W8, generator=g8, device=device)
         if semstereo_amd.ops.gwc_patch_gate_applies(a8, maxdisp // 8, 32):
             run = lambda: semstereo_amd.ops.gwc_patch_gate(a8, b8, maxdisp // 8, 32, seg.patch.weight, gl8)     # noqa: E731
-            for _ in range(3):
-                run()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                run()
-            e1.record()
-            torch.cuda.synchronize()
-            msf = e0.elapsed_time(e1) / 20
+            msf = steady_ms(run)
             res["roofline_cost_volume_fused_b8"] = {
                 "kernel": "gwc_patch_gate_v4<8,true,stream>, batch 8: volume + patch + gate in one launch", "bound": "hbm",
                 "achieved": nb8 / (msf * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -469,15 +474,7 @@ def main():
         glB = torch.randn(B, 32, H8, W8, generator=gB, device=device)
         if fused_gwc and semstereo_amd.ops.gwc_patch_gate_applies(aB, maxdisp // 8, 32):
             run = lambda: semstereo_amd.ops.gwc_patch_gate(aB, bB, maxdisp // 8, 32, seg.patch.weight, glB)     # noqa: E731
-            for _ in range(5):
-                run()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                run()
-            e1.record()
-            torch.cuda.synchronize()
-            msa = e0.elapsed_time(e1) / 20
+            msa = steady_ms(run)
             res["roofline_cost_volume_alone"] = {
                 "kernel": res["roofline_cost_volume"]["kernel"] + ", launched alone", "bound": "hbm",
                 "achieved": nbytes / (msa * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -496,15 +493,7 @@ def main():
         out_ssr = torch.empty(B, H, W, device=device)
         lib = semstereo_amd._lib
         run = lambda: lib.call("ss_ssr_upsample_fwd", lib.ptr(d_low), lib.ptr(wts), lib.ptr(lab), lib.ptr(prm), lib.ptr(out_ssr), B, H4, W4, 6)   # noqa: E731
-        for _ in range(5):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        mss = e0.elapsed_time(e1) / 20
+        mss = steady_ms(run)
         nbs = 4.0 * B * (13 * H * W + H4 * W4)
         res["roofline_ssr_upsample"] = {"kernel": "ssr_upsample_tiled (SSR_upsample: 4x bilinear + 6-class gated residual, one launch)",
                                         "bound": "hbm", "achieved": nbs / (mss * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
