@@ -78,6 +78,14 @@ elif name == "stem_left":
     cl, att = R(B, 32, 256, 256), torch.rand(B, 1, 24, 256, 256, device=dev)
     fn = lambda: M.stem_broadcast_half(stem, cl, att)                          # noqa: E731
     nbytes = 4.0 * B * (32 + 24 + 32 * 24) * 256 * 256
+elif name == "conv_s1_cl":       # the stride-1 32 -> 32 conv with channels-last output (16-byte stores)
+    x = torch.relu(R(B, 32, 24, 256, 256))
+    ws = M.pack_conv_weight_bf16s(R(32, 32, 3, 3, 3) * 0.03, 19)
+    sc, sh = torch.rand(32, device=dev) + 0.5, R(32) * 0.1
+    mid = torch.empty(B, 24, 256, 256, 32, device=dev)
+    lib = sa._lib
+    fn = lambda: lib.call("ss_conv3d_bf16s_cl_fwd", lib.ptr(x), lib.ptr(ws), lib.ptr(sc), lib.ptr(sh), lib.ptr(mid), B, 32, 24, 256, 256, 32, 1, 19)   # noqa: E731
+    nbytes = 4.0 * B * 2 * 32 * 24 * 256 * 256
 elif name in ("conv_s2", "conv_s1", "deconv"):
     if name == "deconv":            # hourglass2.conv6: 64 -> 32 to [24,256,256] with the 1x1x1 skip projection of a 32-channel volume
         hg = M.hourglass2(32).to(dev).eval()
