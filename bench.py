@@ -502,6 +502,26 @@ def main():
         del d_low, wts, lab, out_ssr
     except Exception as e:       # noqa: BLE001  (never let the side measurement take the line down)
         res["roofline_ssr_upsample"] = {"error": repr(e)}
+    # the 32 -> 1 head of `classif` (models/SemStereo.py:228-234) reading its classifier's channels-last intermediate: the
+    # bandwidth kernel VERDICT r1 #6 named (268 MB in 83 us then), alone at the bench batch
+    try:
+        xcl = torch.relu(torch.randn(B, 24, H4, W4, 32, generator=torch.Generator(device=device).manual_seed(10), device=device))
+        wsh = M.pack_head_weight_bf16s(torch.randn(1, 32, 3, 3, 3, device=device) * 0.03)
+        outh = torch.empty(B, 1, xcl.shape[1], H4, W4, device=device)
+        lib = semstereo_amd._lib
+        runh = lambda: lib.call("ss_conv3d_head_bf16s_cl_fwd", lib.ptr(xcl), lib.ptr(wsh), None, None, lib.ptr(outh), B, 32, xcl.shape[1], H4, W4, 0, 6)   # noqa: E731
+        msh = steady_ms(runh)
+        nbh = 4.0 * B * 33 * xcl.shape[1] * H4 * W4
+        res["roofline_classifier_head"] = {
+            "kernel": "conv3d_head_bf16s<4,8,2,6,CL> (classif.2: Conv3d(32,1,3) over [B,32,24,H/4,W/4], channels-last input), launched alone",
+            "bound": "hbm", "achieved": nbh / (msh * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbh / (msh * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msh, "algorithmic_bytes_per_launch": nbh,
+            "traffic": 291.6e6 * B if (H, W, maxdisp) == (1024, 1024, 128) else None,
+            "traffic_note": "HBM bytes per pair from PMC passes of tools/pmc_bytes.sh head_cl 1 (profiles/r02_e_pmc_head_cl_b1.md): "
+                            "2 x FETCH_SIZE (284.1 MB: the 6x10-rows-for-4x8 halo re-reads that miss L2) + WRITE_SIZE (7.5 MB)"}
+        del xcl, outh
+    except Exception as e:       # noqa: BLE001
+        res["roofline_classifier_head"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and EPE: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the
         # same workload: about 10-30 s of CPU work.  ATen's CPU kernels stop scaling (the slice

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
-usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain warp ssr ssr2048 strength topk
+usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl warp ssr ssr2048 strength topk
                                                                catt8 catt4 upsoft stem_left conv_s1 conv_s2 deconv"""
 import os
 import sys
@@ -78,6 +78,13 @@ elif name == "stem_left":
     cl, att = R(B, 32, 256, 256), torch.rand(B, 1, 24, 256, 256, device=dev)
     fn = lambda: M.stem_broadcast_half(stem, cl, att)                          # noqa: E731
     nbytes = 4.0 * B * (32 + 24 + 32 * 24) * 256 * 256
+elif name == "head_cl":          # classif.2 reading the channels-last intermediate of its classifier
+    xcl = torch.relu(R(B, 24, 256, 256, 32))
+    ws = M.pack_head_weight_bf16s(R(1, 32, 3, 3, 3))
+    outh = torch.empty(B, 1, 24, 256, 256, device=dev)
+    lib = sa._lib
+    fn = lambda: lib.call("ss_conv3d_head_bf16s_cl_fwd", lib.ptr(xcl), lib.ptr(ws), None, None, lib.ptr(outh), B, 32, 24, 256, 256, 0, 6)   # noqa: E731
+    nbytes = 4.0 * B * 33 * 24 * 256 * 256
 elif name == "conv_s1_cl":       # the stride-1 32 -> 32 conv with channels-last output (16-byte stores)
     x = torch.relu(R(B, 32, 24, 256, 256))
     ws = M.pack_conv_weight_bf16s(R(32, 32, 3, 3, 3) * 0.03, 19)
