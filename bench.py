@@ -155,6 +155,15 @@ def launch_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
 
+    def end_ranks(signum, _frame):                               # the launcher is being ended: do not leave ranks behind on the GPUs
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        sys.exit(128 + signum)
+    import signal
+    signal.signal(signal.SIGTERM, end_ranks)
+    signal.signal(signal.SIGINT, end_ranks)
+
     def relay():
         for line in procs[0].stdout:
             sys.stdout.write(line)
