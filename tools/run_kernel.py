@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
-usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl warp ssr ssr2048 strength topk
+usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low warp ssr ssr2048 strength topk
                                                                catt8 catt4 upsoft stem_left conv_s1 conv_s2 deconv"""
 import os
 import sys
@@ -78,6 +78,13 @@ elif name == "stem_left":
     cl, att = R(B, 32, 256, 256), torch.rand(B, 1, 24, 256, 256, device=dev)
     fn = lambda: M.stem_broadcast_half(stem, cl, att)                          # noqa: E731
     nbytes = 4.0 * B * (32 + 24 + 32 * 24) * 256 * 256
+elif name in ("conv_mid", "conv_low"):   # hourglass2.conv2: 64 -> 64 at [12,128,128]; conv4: 128 -> 128 at [6,64,64]
+    c, d, hw = (64, 12, 128) if name == "conv_mid" else (128, 6, 64)
+    x = torch.relu(R(B, c, d, hw, hw))
+    ws = M.pack_conv_weight_bf16s(R(c, c, 3, 3, 3) * 0.03, 19)
+    sc, sh = torch.rand(c, device=dev) + 0.5, R(c) * 0.1
+    fn = lambda: M.conv3d_bf16s_hip(x, ws, c, sc, sh, True, 19)               # noqa: E731
+    nbytes = 4.0 * B * 2 * c * d * hw * hw
 elif name == "head_cl":          # classif.2 reading the channels-last intermediate of its classifier
     xcl = torch.relu(R(B, 24, 256, 256, 32))
     ws = M.pack_head_weight_bf16s(R(1, 32, 3, 3, 3))
