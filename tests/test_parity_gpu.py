@@ -1277,6 +1277,8 @@ def test_conv3d_training_forward_dgrad_wgrad_in_hip(sa, case):
     """VERDICT r1 missing #2: Conv3d(k3,p1) through the HIP autograd function -- forward, data gradient (the same engine on
     flipped weights / the transposed-conv kernels) and weight gradient (conv3d_wgrad.hip) -- against autograd of
     F.conv3d in float64."""
+    if sa.modules.CONV_ENGINE == "bf16x3":
+        pytest.skip("SS_CONV_ENGINE=bf16x3: this bound is for the fp32-accurate engines")
     import torch.nn.functional as F
     from oracle import detdata as dd
     B, Cin, Cout, D, H, W, stride = case
@@ -1306,6 +1308,8 @@ def test_conv3d_training_forward_dgrad_wgrad_in_hip(sa, case):
 @pytest.mark.parametrize("case", [(1, 64, 32, 3, 6, 18), (2, 128, 64, 2, 4, 8), (1, 48, 40, 2, 5, 33)])
 def test_deconv3d_training_forward_dgrad_wgrad_in_hip(sa, case):
     """ConvTranspose3d(k3,s2,p1,op1) of the hourglasses (models/SemStereo.py:124-130) through the HIP autograd function."""
+    if sa.modules.CONV_ENGINE == "bf16x3":
+        pytest.skip("SS_CONV_ENGINE=bf16x3: this bound is for the fp32-accurate engines")
     import torch.nn.functional as F
     from oracle import detdata as dd
     B, Cin, Cout, D, H, W = case
@@ -1336,6 +1340,8 @@ def test_hot_segment_training_step_runs_on_the_hip_stack(sa):
     """A training-mode pass of the hot segment (BatchNorm with batch statistics, autograd on: main_us3d.py:186-222): every
     3x3x3 convolution and transposed convolution runs the HIP autograd functions, every parameter receives a finite
     gradient, and the gradients agree with the same pass on the stock PyTorch layers (SS_TRAIN_HIP=0)."""
+    if sa.modules.CONV_ENGINE == "bf16x3":
+        pytest.skip("SS_CONV_ENGINE=bf16x3: this bound is for the fp32-accurate engines")
     name = "s128"
     fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
     grads = {}
