@@ -1203,6 +1203,7 @@ def test_upsample_softmax_regression_kernel(sa, shape):
     (1, 64, 7, 260, 24, 8, True),         # maxdisp 192's range; a ragged third column tile
     (1, 32, 5, 64, 8, 8, False),          # narrower than a tile; 4 channels per group; no gate
     (1, 64, 1, 128, 16, 8, True),         # a single row
+    (1, 64, 26, 384, 16, 8, True),        # three column tiles (the middle one has real halo columns on both sides), several interior row tiles
 ])
 def test_gwc_patch_gate_fused_is_bit_identical_to_the_two_kernels(sa, shape):
     """models/SemStereo.py:273-276 in one kernel (ss_gwc_patch_gate_fwd) against build_gwc_volume_norm followed by the
