@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -268,6 +269,8 @@ __global__ __launch_bounds__(256) void window_attention_core(const float* __rest
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
     const float* qb = qkv_in + (size_t)b * 3 * C * vol;
 
+    __shared__ unsigned vmax_w[4];
+    float vm = 0.f;                                           // |max| of this thread's share of the V rows (64-95)
     if (bw == 4 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv_in) & 15) == 0)) {
         constexpr int NQ = 96 * (A::TP / 4) / 256;           // quads per thread (9 or 6)
         static_assert(96 * (A::TP / 4) % 256 == 0, "whole batches");
@@ -282,7 +285,9 @@ __global__ __launch_bounds__(256) void window_attention_core(const float* __rest
             const float4 q = *reinterpret_cast<const float4*>(qb + (size_t)f * vol + (size_t)gd * plane +
                                                               (size_t)min(gh, H - 1) * W + min(gw, W - 4));
             const float bf = bqkv[f];
-            *reinterpret_cast<float4*>(&qkv[e * 4]) = ok ? q : make_float4(bf, bf, bf, bf);
+            const float4 v4 = ok ? q : make_float4(bf, bf, bf, bf);
+            *reinterpret_cast<float4*>(&qkv[e * 4]) = v4;
+            if (row >= 64) vm = fmaxf(vm, fmaxf(fmaxf(fabsf(v4.x), fabsf(v4.y)), fmaxf(fabsf(v4.z), fabsf(v4.w))));
         }
     } else {
         for (int e = tid; e < 96 * A::TP; e += 256) {
@@ -290,8 +295,14 @@ __global__ __launch_bounds__(256) void window_attention_core(const float* __rest
             const int f = (row >> 5) * C + g * 32 + (row & 31);
             const int iw = t % bw, ih = (t / bw) % bh, id = t / (bw * bh);
             const int gw = ww * bw + iw, gh = wh * bh + ih, gd = wd * bd + id;
-            qkv[e] = (gh < H && gw < W) ? qb[(size_t)f * vol + (size_t)gd * plane + (size_t)gh * W + gw] : bqkv[f];
+            const float v1 = (gh < H && gw < W) ? qb[(size_t)f * vol + (size_t)gd * plane + (size_t)gh * W + gw] : bqkv[f];
+            qkv[e] = v1;
+            if (row >= 64) vm = fmaxf(vm, fabsf(v1));
         }
+    }
+    {
+        const unsigned wm = wave_max_bits(__float_as_uint(vm));
+        if (lane == 0) vmax_w[wave] = wm;
     }
     for (int t = tid; t < A::TP; t += 256) {
         const int iw = t % bw, ih = (t / bw) % bh;
@@ -300,6 +311,31 @@ __global__ __launch_bounds__(256) void window_attention_core(const float* __rest
     __syncthreads();
 
     const float scale = 0.35355339059327379f;    // 8 ** -0.5
+    // block exponent of V (see the P V product below): max -> [2^14, 2^15); a non-finite V makes the scale non-finite
+    const int e_v = max((int)(max(max(vmax_w[0], vmax_w[1]), max(vmax_w[2], vmax_w[3])) >> 23), E_MIN);
+    const float v_scale = __uint_as_float((unsigned)(127 + E_ONE - e_v) << 23);
+    const float pv_unscale = __uint_as_float((unsigned)(127 - E_ONE + e_v) << 23) * (1.0f / 16384.0f);
+    // V -> two scaled fp16 terms, IN PLACE and in the order the P V product reads it: the 16 tokens of a K-step (64 bytes of a
+    // V row) become [half 0: hi, lo][half 1: hi, lo], 8 fp16 each, lane half h holding tokens {4 h .. +3, 8 + 4 h .. +3} of
+    // the step.  Once per workgroup instead of once per (head, query tile) unit.
+    for (int wk = tid; wk < 32 * (A::TP / 16); wk += 256) {
+        float* base = qkv + (64 + wk / (A::TP / 16)) * A::TP + (wk % (A::TP / 16)) * 16;
+        float f[16];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) ss::lds_read16(base + 4 * k4, &f[4 * k4]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t0 = (j < 2) ? 4 * h + 2 * j : 8 + 4 * h + 2 * (j - 2);
+                split2_pk_f16(f[t0] * v_scale, f[t0 + 1] * v_scale, hi[j], lo[j]);
+            }
+            *reinterpret_cast<uint4*>(base + 8 * h) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(base + 8 * h + 4) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    }
+    __syncthreads();
     float* yb = y + (size_t)b * C * vol;
     // one unit = (head hh, tile of 32 queries); see the fused kernel's phase 2 for the operand layout
     for (int u = wave; u < HG * A::NTL; u += 4) {
@@ -338,14 +374,34 @@ __global__ __launch_bounds__(256) void window_attention_core(const float* __rest
         f32x16 ot;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-        const float* vrow = qkv + (64 + hh * HD + (l31 & 7)) * A::TP + 4 * half;     // V[dim = lane][...]
+        // P V on the fp16 matrix core, fp32-accurate: both operands as two fp16 terms, three products (hi*hi, hi*lo, lo*hi;
+        // split_f16.h) -- K = 16 keys per instruction instead of the exact-fp32 MFMA's 2 (this product was 80 % of the kernel's
+        // matrix time).  P is scaled by 2^14 (p <= 1), V by the power of two that brings the head group's |max| into
+        // [2^14, 2^15); both are undone on the accumulator.  A 16-key step = registers 8 s .. 8 s + 7 of the logits tile: keys
+        // {4 half .. +3, 8 + 4 half .. +3} of the step, and V is read in that order.
+        const float* vrow = qkv + (64 + hh * HD + (l31 & 7)) * A::TP + 8 * half;     // split V[dim = lane & 7] (rows 8-31 of the tile are not stored)
+        const float ps = rsum * 16384.0f;
 #pragma unroll
         for (int kt = 0; kt < A::NTL; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float vv = (l31 < HD) ? vrow[kt * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;
-                ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, ss::mul_rn(st[kt][r], rsum), ot, 0, 0, 0);
+            for (int s8 = 0; s8 < 2; ++s8) {
+                float vh[4], vl[4];
+                ss::lds_read16(vrow + kt * 32 + 16 * s8, vh);
+                ss::lds_read16(vrow + kt * 32 + 16 * s8 + 4, vl);
+                unsigned bh_[4], bl_[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    split2_pk_f16(st[kt][8 * s8 + 2 * j] * ps, st[kt][8 * s8 + 2 * j + 1] * ps, bh_[j], bl_[j]);
+                const f16x8 a_hi = __builtin_bit_cast(f16x8, make_float4(vh[0], vh[1], vh[2], vh[3]));
+                const f16x8 a_lo = __builtin_bit_cast(f16x8, make_float4(vl[0], vl[1], vl[2], vl[3]));
+                const f16x8 b_hi = __builtin_bit_cast(f16x8, make_uint4(bh_[0], bh_[1], bh_[2], bh_[3]));
+                const f16x8 b_lo = __builtin_bit_cast(f16x8, make_uint4(bl_[0], bl_[1], bl_[2], bl_[3]));
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, ot, 0, 0, 0);
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, ot, 0, 0, 0);
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, ot, 0, 0, 0);
             }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[r] *= pv_unscale;
         // rows 0-3 of Ot sit in registers 0-3 of the lower half, rows 4-7 in those of the upper half
         const int t = qt * 32 + l31;
         const int iw = t % bw, ih = (t / bw) % bh, id = t / (bw * bh);

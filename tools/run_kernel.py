@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
-usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low warp ssr ssr2048 strength topk
+usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low attn attn_att warp ssr ssr2048 strength topk
                                                                catt8 catt4 upsoft stem_left conv_s1 conv_s2 deconv"""
 import os
 import sys
@@ -78,6 +78,12 @@ elif name == "stem_left":
     cl, att = R(B, 32, 256, 256), torch.rand(B, 1, 24, 256, 256, device=dev)
     fn = lambda: M.stem_broadcast_half(stem, cl, att)                          # noqa: E731
     nbytes = 4.0 * B * (32 + 24 + 32 * 24) * 256 * 256
+elif name in ("attn", "attn_att"):       # attention_block of hourglass2 ([128,6,64,64], windows 6x4x4) / of the attention-branch hourglass ([128,8,32,32], 4x4x4)
+    blk, d, hw = ((6, 4, 4), 6, 64) if name == "attn" else ((4, 4, 4), 8, 32)
+    ab = M.attention_block(128, 16, blk).to(dev).eval()
+    x = R(B, 128, d, hw, hw)
+    fn = lambda: ab(x)                                                         # noqa: E731
+    nbytes = 4.0 * B * 2 * 128 * d * hw * hw
 elif name in ("conv_mid", "conv_low"):   # hourglass2.conv2: 64 -> 64 at [12,128,128]; conv4: 128 -> 128 at [6,64,64]
     c, d, hw = (64, 12, 128) if name == "conv_mid" else (128, 6, 64)
     x = torch.relu(R(B, c, d, hw, hw))
