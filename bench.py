@@ -439,10 +439,10 @@ def main():
                                           "achieved": nb8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": nb8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": ms8,
                                           "algorithmic_bytes_per_launch": nb8,
-                                          "traffic": 806.1e6,
-                                          "traffic_note": "HBM bytes per launch from PMC passes of tools/run_gwc.py 8 (profiles/"
-                                                          "r01_f_gwc_b8_stream_pmc.md): 2 x FETCH_SIZE + WRITE_SIZE, gfx950 "
-                                                          "correction applied; algorithmic 805.3e6"}
+                                          "traffic": 806.6e6,
+                                          "traffic_note": "HBM bytes per launch from PMC passes of tools/pmc_bytes.sh gwc 8 (profiles/"
+                                                          "r02_e_pmc_gwc_b8.md; r01: 806.1e6): 2 x FETCH_SIZE (268.6 MB) + WRITE_SIZE "
+                                                          "(538.0 MB), gfx950 correction applied; algorithmic 805.3e6"}
         del a8, b8
         # calibration SURVEY.md section 8(d) asks for: what a plain device-to-device copy reaches on this box
         # (read + write bytes over time, 1 GiB, 10 back-to-back copies), to read the fractions against
@@ -472,8 +472,8 @@ def main():
                 "kernel": "gwc_patch_gate_v4<8,true,stream>, batch 8: volume + patch + gate in one launch", "bound": "hbm",
                 "achieved": nb8 / (msf * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": nb8 / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msf, "algorithmic_bytes_per_launch": nb8,
-                "traffic": 910.5e6,
-                "traffic_note": "HBM bytes per launch from PMC passes of tools/pmc_bytes.sh gwc_fused 8 (profiles/r02_c_pmc_gwc_fused_b8.md): "
+                "traffic": 910.6e6,
+                "traffic_note": "HBM bytes per launch from PMC passes of tools/pmc_bytes.sh gwc_fused 8 (profiles/r02_e_pmc_gwc_fused_b8.md): "
                                 "2 x FETCH_SIZE (373.7 MB: the 8-rows-for-6 halo re-reads) + WRITE_SIZE (536.9 MB)"}
         del a8, b8, gl8
         # ... and alone at the bench batch: inside the step it shares the chip with the matching branch's 2-D convolutions
