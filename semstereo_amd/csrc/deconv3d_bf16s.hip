@@ -183,23 +183,31 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
 #pragma unroll
             for (int c = 0; c < SNC; ++c)
                 a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * swstep + c * 2 * Cout * 16, 0));
+            // all 32 eight-byte loads of the K-step first, then the arithmetic: ONE exposed round trip to memory per 16 skip
+            // channels (interleaved by the compiler, each of the four (pd, ph) groups waited for its own 8 loads: four)
+            float2 v[4][8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                  // (pd, ph); the float2 holds pw = 0, 1
                 const unsigned qo = (unsigned)(((size_t)(q >> 1) * out_plane + (size_t)(q & 1) * Wo) * 4);
-                float2 v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int cs = ks * 16 + 8 * half + j;     // channels beyond Cs: a clamped (valid) address, value zeroed
-                    v[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
-                                                          sres, (int)(lane_s + qo + (unsigned)min(cs, Cs - 1) * schan_b), 0, 0));
-                    if (cs >= Cs) v[j] = make_float2(0.f, 0.f);
+                    v[q][j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                             sres, (int)(lane_s + qo + (unsigned)min(cs, Cs - 1) * schan_b), 0, 0));
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (ks * 16 + 8 * half + j >= Cs) v[q][j] = make_float2(0.f, 0.f);
 #pragma unroll
                 for (int pw = 0; pw < 2; ++pw) {
                     unsigned bh[4], bm[4], bl[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        split3_pk(pw ? v[2 * c].y : v[2 * c].x, pw ? v[2 * c + 1].y : v[2 * c + 1].x, bh[c], bm[c], bl[c]);
+                        split3_pk(pw ? v[q][2 * c].y : v[q][2 * c].x, pw ? v[q][2 * c + 1].y : v[q][2 * c + 1].x, bh[c], bm[c], bl[c]);
                     const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
                     const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
                     const int cls = q * 2 + pw;
