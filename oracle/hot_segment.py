@@ -91,6 +91,39 @@ def matching_branch(P, fl4, fr4, att_topk, samples, out=None):
 
 
 @torch.no_grad()
+def matching_truth_tiled(P, fl4, fr4, att_topk, samples, tile=128, halo=48):
+    """models/SemStereo.py:314-323 (the lines of `matching_branch` above) evaluated in FLOAT64 over the whole
+    quarter-resolution map, given 24 candidates and attention weights per pixel -> pred [B,1,H4,W4] float64: the exact
+    answer of the reference graph for these inputs ("truth"), which any fp32 evaluation -- the reference's own
+    included -- can be held against.  The 2-D features and the warp are evaluated on the whole image; the 3-D stack runs
+    tile by tile (float64 convolutions go through im2col: 87 GB for the whole map at 2048^2).  A tile of `tile` pixels plus
+    `halo` on every side that is not an image edge is exact on the tile: the receptive field of concat_stem + hourglass2
+    + classif is <= 36 quarter-resolution pixels and the attention windows of hourglass2 (16 such pixels) stay whole
+    because every cut is a multiple of 16 (tests/test_oracle_golden.py::test_truth_tiles_equal_the_whole_map)."""
+    assert tile % 16 == 0 and halo % 16 == 0 and halo >= 48
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    fl4d, smp, att = fl4.double(), samples.double(), att_topk.double()
+    cl = stack.concat_feature(P64, fl4d)
+    cr = stack.concat_feature(P64, fr4.double())
+    right_w, left_b = ops.SpatialTransformer_grid(cl, cr, smp)
+    B, _, H4, W4 = fl4.shape
+    pred = torch.empty(B, 1, H4, W4, dtype=torch.float64)
+    for ty in range(0, H4, tile):
+        for tx in range(0, W4, tile):
+            y0, y1 = max(ty - halo, 0), min(ty + tile + halo, H4)
+            x0, x1 = max(tx - halo, 0), min(tx + tile + halo, W4)
+            sl = (Ellipsis, slice(y0, y1), slice(x0, x1))
+            vol = att[sl] * torch.cat((left_b[sl], right_w[sl]), dim=1)
+            vol = stack.basic_conv(P64, "concat_stem", vol, is_3d=True)
+            vol = stack.channel_att(P64, "concat_feature_att_4", vol, fl4d[sl])
+            cost = stack.classifier(P64, "classif", stack.hourglass(P64, "hourglass", vol, (6, 4, 4)))
+            p = ops.regression_topk(cost.squeeze(1), smp[sl], 2)
+            ey, ex = min(ty + tile, H4), min(tx + tile, W4)
+            pred[..., ty:ey, tx:ex] = p[..., ty - y0:ey - y0, tx - x0:ex - x0]
+    return pred
+
+
+@torch.no_grad()
 def hot_segment(P, fl4, fr4, fl8, fr8, maxdisp, keep=False, unsigned=False):
     """features_left[1], features_right[1] ([B,128,H/4,W/4]) and
     features_left[2], features_right[2] ([B,256,H/8,W/8]) -> dict with

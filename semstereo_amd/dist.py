@@ -14,13 +14,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
-    (rank, world_size, local_rank).  A single process (no env) needs no group."""
+    (rank, world_size, local_rank).  A single process (no env) needs no group; `force` (or SS_DIST_FORCE_INIT=1)
+    initialises one anyway -- a world of ONE rank over RCCL runs the same communicator set-up, broadcast, all_gather
+    and all_reduce code as N ranks do (tests/test_nccl_world1_gpu.py: the nccl path on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("SS_DIST_FORCE_INIT", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -48,7 +51,7 @@ def shard_batch(tensors, rank, world):
 
 def broadcast_module(module, src=0):
     """One-time weight broadcast so every rank holds rank `src`'s parameters and buffers."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):          # (a world of one rank still runs the collective)
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -58,7 +61,7 @@ def broadcast_module(module, src=0):
 def gather_batch(local, n_items):
     """all_gather of per-rank blocks back into the full batch order.  Blocks may differ in length
     by one (shard_bounds), so they are padded to the largest block for the collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_bounds(n_items, r, world) for r in range(world)]
@@ -74,7 +77,7 @@ def reduce_metrics(n_pairs, abs_err_sum, n_pixels, seconds, device):
     """all_reduce of the benchmark scalars: SUM of pairs / |error| / pixels, MAX of elapsed time."""
     sums = torch.tensor([float(n_pairs), float(abs_err_sum), float(n_pixels)], dtype=torch.float64, device=device)
     tmax = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return sums[0].item(), sums[1].item(), sums[2].item(), tmax[0].item()

@@ -331,11 +331,24 @@ def gen_segment(ms):
         # candidates (no top-24 difference upstream), where the only hard pick left is the top-2 of the costs
         ind = (samples + maxdisp // 4).long().unsqueeze(1)
         out[f"{n}/att_topk"] = f32(torch.gather(cap["aw_prob"], 2, ind).squeeze(1))
+        # float64 answer of the matching branch on the reference's candidates (see gen_segment_full)
+        Pn = P_cal(P, out, n) if n.endswith("_cal") else P
+        out[f"{n}/pred_truth"] = f32(oseg.matching_truth_tiled(Pn, fl4, fr4, torch.gather(cap["aw_prob"], 2, ind), samples))
         print(n, "pred", tuple(pred.shape), "range", float(pred.min()), float(pred.max()),
               "| min gap24_rel %.2e  min gap2 %.2e  median gap2 %.2e  cost std over candidates %.3f" %
               (float(gap24.min()), float(gap2.min()), float(gap2.median()), float(cost_sq.std(dim=1).mean())))
     np.savez_compressed(os.path.join(HERE, "segment.npz"), **out)
     print("segment.npz:", len(out), "arrays")
+
+
+def P_cal(P, out, n):
+    """The case's parameter dict with the calibrated BatchNorm statistics just stored under out[n/bn/...]."""
+    Q = dict(P)
+    pre = f"{n}/bn/"
+    for k, v in out.items():
+        if k.startswith(pre):
+            Q[k[len(pre):]] = torch.from_numpy(np.asarray(v, dtype=np.float32).copy())
+    return Q
 
 
 def gen_segment_full(ms, only=None):
@@ -381,6 +394,21 @@ def gen_segment_full(ms, only=None):
         out[f"{n}/risk2"] = np.flatnonzero((gap2 < 1e-4).reshape(-1).numpy()).astype(np.int32)
         out[f"{n}/gap_stats"] = np.array([float(gap24.min()), float(gap24.median()), float((gap24 < 1e-4).float().mean()),
                                           float(gap2.min()), float(gap2.median()), float((gap2 < 1e-4).float().mean())])
+        # round 3 (strict full-size parity): at the risk24 pixels -- the only ones where another fp32 evaluation may select
+        # other candidates -- the REFERENCE's own 24 candidates, attention weights and margin, so that a test can put
+        # the reference's pick back wherever the HIP path chose differently and then hold EVERY pixel of `pred` to the bound
+        # with no receptive-field excuse
+        r24 = torch.from_numpy(out[f"{n}/risk24"].astype(np.int64))
+        per_px = lambda t: t.reshape(B, -1, H4 * W4).permute(0, 2, 1).reshape(B * H4 * W4, -1)                 # [pixels, channels]
+        ind = (samples + maxdisp // 4).long().unsqueeze(1)
+        att_ref = torch.gather(cap["aw_prob"], 2, ind).squeeze(1)                                            # [B,24,H4,W4], :304
+        out[f"{n}/risk24_samples"] = per_px(samples)[r24].numpy().astype(np.int16)
+        out[f"{n}/risk24_att_topk"] = f32(per_px(att_ref)[r24])
+        out[f"{n}/risk24_gap24_rel"] = f32(per_px(gap24)[r24][:, 0])
+        # ... and the float64 answer of the matching branch (models/SemStereo.py:314-323) on the reference's candidates
+        # ("truth"; the pinned oracle in double precision -- the reference's forward() cannot be split): what an fp32
+        # evaluation of this graph -- the reference's own included -- can be held to at this depth of the soft-argmax
+        out[f"{n}/pred_truth_map"] = f32(oseg.matching_truth_tiled(P_cal(P, out, n), fl4, fr4, att_ref.unsqueeze(1), samples).squeeze(1))
         print(n, "pred range", float(pred.min()), float(pred.max()), "gap stats", out[f"{n}/gap_stats"], "%.0f s" % (time.time() - t0))
         del cap, net
     np.savez_compressed(path, **out)

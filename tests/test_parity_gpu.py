@@ -856,8 +856,8 @@ def test_patch_and_gate_fusion(sa):
 # with no percentage allowance.  DELTA2 = 1e-4: ~10x the error the HIP path shows on the costs (<= 1e-5, per-module bounds
 # above) and ~1e-3 of the typical margin; DELTA24_REL = 1e-5 on the probabilities (every differing pick measured so far sat
 # at a margin of <= 1.2e-7 = one ulp; the full-size fixtures list the pixels below 1e-4).
-DELTA24_REL = 1e-5
-DELTA2 = 1e-4
+DELTA24_REL = cases.DELTA24_REL      # ONE definition (tests/golden/cases.py) for every hot-segment test
+DELTA2 = cases.DELTA2
 RF_RADIUS = 36      # quarter-resolution pixels a changed candidate set can reach through concat_stem + hourglass2 (two
                     # stride-2 stages, 4x4 attention windows at 1/16 of the quarter resolution) + classif
 
@@ -959,6 +959,33 @@ def test_matching_branch_on_the_reference_candidates(sa, golden, name):
     assert not bool(bad.any()), (f"{int(bad.sum())} pixel(s) off by up to {float(err[bad].max()):.2e} px although the "
                                  f"reference's top-2 margin there is >= {float(gap2[bad].min()):.2e}")
     assert float(err[~tie].max()) <= 1e-3 and float(err.median()) <= 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(cases.SEGMENT) + sorted(cases.SEGMENT_CAL))
+def test_hot_segment_strict_on_the_reference_picks(sa, golden, name):
+    """The whole segment with NO receptive-field excuse (tests/strict.py): HIP attention branch; wherever it
+    selected other candidates -- allowed only at a reference margin below DELTA24_REL -- the reference's own candidates and
+    weights are put back; HIP matching branch; every pixel of `pred` within 1e-3 px of the reference's unless the
+    reference's own 2nd / 3rd largest costs are within DELTA2 (bound: max(1e-3, 2 x the reference's own largest distance from
+    the fixture's float64 truth), see tests/test_fullsize_gpu.py)."""
+    if sa.modules.CONV_ENGINE == "bf16x3" and name not in ("s128", "s96x160_b2"):
+        pytest.skip("SS_CONV_ENGINE=bf16x3: beyond the margins assumed here")
+    import strict
+    seg, P = _segment_case(sa, golden, name)
+    g = golden["segment"]
+    if strict.fixture_view(g, name) is None:
+        pytest.skip(f"{name}: no round-3 fixture")
+    before = dict(sa.modules.PATH_COUNTS)
+    rep, v, pred, differs, unexplained = strict.run_strict(seg, g, name)
+    assert sa.modules.PATH_COUNTS["torch"] == before["torch"]
+    for k_, val in rep.items():
+        REPORT[f"strict/{name}/{k_}"] = val
+    ref_self = rep["reference_vs_truth_max_off_ties_px"]
+    bound = max(1e-3, 2.0 * ref_self)
+    assert not bool(unexplained.any()), f"{int(unexplained.sum())} pixel(s) select other candidates at a reference margin >= {DELTA24_REL}"
+    assert bound <= 3e-3 and rep["max_err_off_ties_px"] <= bound, rep
+    assert rep["median_abs_err_px"] <= 1e-5 and rep["epe_vs_reference_off_ties_px"] <= 1e-4, rep
+    assert rep["hip_vs_truth_max_off_ties_px"] <= max(1e-3, 1.5 * ref_self), rep
 
 
 def test_matching_branch_as_close_to_float64_truth_as_the_fp32_oracle(sa):
