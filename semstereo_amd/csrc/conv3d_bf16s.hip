@@ -21,6 +21,7 @@
 // reads the same 16 B per lane per term and step; LDS is left to the activations).
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "split_f16.h"
@@ -308,22 +309,29 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             }
             in_scale = __uint_as_float((unsigned)(127 + E_ONE - e_cur) << 23);
         }
+        // (a chunk of 8 live channels -- every chunk when Cin % 8 == 0 -- takes the copy of this loop without the
+        // per-channel selects: 7 of its 32 VALU instructions per position, ISA count r03)
+        auto stage = [&](auto whole_chunk) {
+            constexpr bool WHOLE = decltype(whole_chunk)::value;
 #pragma unroll
-        for (int i = 0; i < C::NPOS; ++i) {
-            const int p = tid + 256 * i;
-            if (p >= C::CS) continue;
-            unsigned hh[4], mm[4], ll[4];
+            for (int i = 0; i < C::NPOS; ++i) {
+                const int p = tid + 256 * i;
+                if (p >= C::CS) continue;
+                unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float x0 = (2 * c < nlive) ? rin[(2 * c) * C::NPOS + i] : 0.f;
-                const float x1 = (2 * c + 1 < nlive) ? rin[(2 * c + 1) * C::NPOS + i] : 0.f;
-                if (F16) split2_pk_f16(x0 * in_scale, x1 * in_scale, hh[c], mm[c]);
-                else split3_pk(x0, x1, hh[c], mm[c], ll[c]);
+                for (int c = 0; c < 4; ++c) {
+                    const float x0 = (WHOLE || 2 * c < nlive) ? rin[(2 * c) * C::NPOS + i] : 0.f;
+                    const float x1 = (WHOLE || 2 * c + 1 < nlive) ? rin[(2 * c + 1) * C::NPOS + i] : 0.f;
+                    if (F16) split2_pk_f16(x0 * in_scale, x1 * in_scale, hh[c], mm[c]);
+                    else split3_pk(x0, x1, hh[c], mm[c], ll[c]);
+                }
+                lds[0 * C::CS + p] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                lds[1 * C::CS + p] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+                if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
             }
-            lds[0 * C::CS + p] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-            lds[1 * C::CS + p] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
-            if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
-        }
+        };
+        if (nlive == 8) stage(std::true_type{});
+        else stage(std::false_type{});
         if (WLDS) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the LDS-DMA weight loads have landed
         __syncthreads();
         const bool more = ci0 + 8 < Cin;                       // another chunk of THIS tile follows
@@ -461,6 +469,10 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // (the next tile's first chunk occupies the prefetch registers during the epilogue: with both a gate and a residual to
     // fetch, groups of 4 rows keep the kernel out of scratch)
     constexpr int EG = (GATED || NT * MT >= 4) ? 4 : 8;
+    // (a workgroup whose 32 * MT channels all exist -- every one when Cout % 32 == 0 -- takes the copy of the epilogue without
+    // the per-element "channel exists" selects on the load / store offsets: 4 of ~11 VALU instructions per element, ISA count r03)
+    auto epilogue = [&](auto all_channels) {
+    constexpr bool ALLC = decltype(all_channels)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
         for (int q = 0; q < EG; ++q) {
             const int cb = cbase(mt, r0 + q);
-            const bool cok = cb + 4 * half < Cout;
+            const bool cok = ALLC || cb + 4 * half < Cout;
             sc[q] = aff[cb - co0 + 4 * half];
             sh[q] = aff[64 + cb - co0 + 4 * half];
             un[q] = F16 ? aff[128 + cb - co0 + 4 * half] * acc_unscale : 1.0f;      // powers of two: acc * un is exact
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
             for (int q = 0; q < EG; ++q) {
                 const int cb = cbase(mt, r0 + q);
-                const bool cok = cb + 4 * half < Cout;
+                const bool cok = ALLC || cb + 4 * half < Cout;
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
                     rv[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -514,7 +526,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
             for (int g4 = 0; g4 < EG; g4 += 4) {
                 const int cb = cbase(mt, r0 + g4);           // channels cb + 4 * half .. + 3 sit in registers r0 + g4 .. + 3
-                const bool cok = cb + 4 * half < Cout;
+                const bool cok = ALLC || cb + 4 * half < Cout;
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
                     __builtin_amdgcn_raw_buffer_store_b128(
@@ -525,7 +537,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
             for (int q = 0; q < EG; ++q) {
                 const int cb = cbase(mt, r0 + q);
-                const bool cok = cb + 4 * half < Cout;
+                const bool cok = ALLC || cb + 4 * half < Cout;
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[q][i]), ores,
@@ -533,6 +545,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             }
         }
     }
+    };
+    if (co0 + 32 * MT <= Cout) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     SS_STAMP(3);
     }       // tiles of this workgroup (the next one's first chunk is already in the prefetch registers)
     SS_STAMP_FINISH();

@@ -238,6 +238,111 @@ __global__ __launch_bounds__(256) void warp_right_gated(const float* __restrict_
     }
 }
 
+// ---- the warped half of the sparse concat volume written PRE-SPLIT for the matrix-core stem (conv3d_pre.hip): every value as
+// the two fp16 terms of x * 2^(E_ONE - e), 8 channels x 2 terms = 32 bytes per position, [B][C/8][nd][H][W][2][8].  One block
+// exponent e per batch element from a BOUND of the volume, max|y[b]| * max|att[b]| (bilinear weights sum to 1, so no element
+// exceeds it): known before the first element is produced, and everything within 2^-17 of it keeps all 24 bits (below that
+// the absolute error is 2^-39 of the bound -- the contract of the on-the-fly split in conv3d_bf16s.hip, with the tensor's
+// bound in place of the tile's maximum).  Same arithmetic per element as warp_right_gated.
+
+// maxima of |y[b]| and |att[b]| as the bit patterns of non-negative floats: amax[2 * b], amax[2 * b + 1] (zeroed before)
+__global__ __launch_bounds__(256) void absmax2_kernel(const float* __restrict__ y, long long ny, const float* __restrict__ att,
+                                                       long long na, unsigned* __restrict__ amax) {
+    const int b = blockIdx.y;
+    const float* yb = y + (long long)b * ny;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ny; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(yb[i]));
+    unsigned mb = __float_as_uint(m);
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));
+    if ((threadIdx.x & 63) == 0 && mb) atomicMax(&amax[2 * b], mb);
+    if (att != nullptr) {
+        const float* ab = att + (long long)b * na;
+        float ma = 0.f;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long long)gridDim.x * 256) ma = fmaxf(ma, fabsf(ab[i]));
+        unsigned ab_ = __float_as_uint(ma);
+        for (int o = 32; o > 0; o >>= 1) ab_ = max(ab_, (unsigned)__shfl_xor((int)ab_, o));
+        if ((threadIdx.x & 63) == 0 && ab_) atomicMax(&amax[2 * b + 1], ab_);
+    }
+}
+
+__device__ __forceinline__ void split2_pk_f16_w(float x0, float x1, unsigned& h, unsigned& l) {     // (split_f16.h's, local copy)
+    typedef float f32x2_w __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_w __attribute__((ext_vector_type(2)));
+    const f32x2_w v = {x0, x1};
+    const f16x2_w hv = __builtin_convertvector(v, f16x2_w);
+    const f32x2_w r = {x0 - (float)hv[0], x1 - (float)hv[1]};
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_w));
+}
+
+constexpr int W_E_MIN = 16, W_E_ONE = 141;                     // split_f16.h: E_MIN, E_ONE
+
+__global__ __launch_bounds__(256) void warp_right_presplit(const float* __restrict__ y, const float* __restrict__ disp,
+                                                            const float* __restrict__ gate, const unsigned* __restrict__ amax,
+                                                            uint4* __restrict__ xs, int* __restrict__ xexp, int C, int H, int W, int nd,
+                                                            float half_w, float half_h) {
+    const int w = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int h = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int j = blockIdx.z % nd, b = blockIdx.z / nd;
+    // the block exponent of this batch element (every workgroup derives the same value; one of them publishes it)
+    const float bound = __uint_as_float(amax[2 * b]) * (gate ? __uint_as_float(amax[2 * b + 1]) : 1.0f);
+    const int e = min(max((int)(__float_as_uint(bound) >> 23) & 0xff, W_E_MIN), 254);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && j == 0 && threadIdx.x == 0) xexp[b] = e;
+    const float in_scale = __uint_as_float((unsigned)(127 + W_E_ONE - e) << 23);
+    if (h >= H) return;                                        // wave-uniform
+    const bool inside = w < W;
+    const long long plane = (long long)H * W;
+    const int pix = h * W + min(w, W - 1);
+    const float dv = disp[((long long)b * nd + j) * plane + pix];
+    const float g = gate ? gate[((long long)b * nd + j) * plane + pix] : 1.0f;
+    const float gx = ((float)w - dv) / half_w - 1.0f, gy = (float)h / half_h - 1.0f;
+    const float ix = ss::mul_rn(gx + 1.0f, half_w), iy = ss::mul_rn(gy + 1.0f, half_h);
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float fw = ix - xw, fe = 1.0f - fw, fn = iy - yn, fs = 1.0f - fn;
+    const float w_nw = ss::mul_rn(fs, fe), w_ne = ss::mul_rn(fs, fw), w_sw = ss::mul_rn(fn, fe), w_se = ss::mul_rn(fn, fw);
+    const bool xfin = (xw >= -1.0f) && (xw <= (float)(W - 1));
+    const int xi = xfin ? (int)xw : -2;
+    const int xc = min(max(xi, 0), W - 2);
+    const bool west_is_y = (xi == xc + 1), east_is_x = (xi == xc - 1);
+    const bool west_ok = xfin && xi >= 0, east_ok = xfin && xi <= W - 2;
+    const int yi = (int)yn;
+    const bool n_ok = (yn > -1.0f) && (yn < (float)H), s_ok = (yn + 1.0f > -1.0f) && (yn + 1.0f < (float)H);
+    const unsigned off_n = (inside && xfin && n_ok) ? (unsigned)((yi * W + xc) * 4) : 0x80000000u;
+    const unsigned off_s = (inside && xfin && s_ok) ? (unsigned)(((yi + 1) * W + xc) * 4) : 0x80000000u;
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(y + (long long)b * C * plane), 0, (int)min((long long)C * plane * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
+        xs + (long long)b * (C / 8) * nd * plane * 2, 0, (int)min((long long)C * nd * plane * 4, 0x7fffffffLL), 0x00020000);
+    const unsigned off_o = inside ? (unsigned)pix * 32u : 0x80000000u;
+    const int ystep = (int)(plane * 4);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float r8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            const f2 pn = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(yres, (int)off_n, c * ystep, 0));
+            const f2 ps = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(yres, (int)off_s, c * ystep, 0));
+            const float a = west_ok ? (west_is_y ? pn.y : pn.x) : 0.f, bq = east_ok ? (east_is_x ? pn.x : pn.y) : 0.f;
+            const float cq = west_ok ? (west_is_y ? ps.y : ps.x) : 0.f, d = east_ok ? (east_is_x ? ps.x : ps.y) : 0.f;
+            float r = ss::mul_rn(a, w_nw);
+            r = ss::add_rn(r, ss::mul_rn(bq, w_ne));
+            r = ss::add_rn(r, ss::mul_rn(cq, w_sw));
+            r = ss::add_rn(r, ss::mul_rn(d, w_se));
+            if (gate) r = ss::mul_rn(g, r);
+            r8[k] = r * in_scale;                              // exact: a power of two
+        }
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) split2_pk_f16_w(r8[2 * k], r8[2 * k + 1], hh[k], ll[k]);
+        const int soff = (int)((((long long)(c0 / 8) * nd + j) * plane) * 32);
+        const u4 hv = {hh[0], hh[1], hh[2], hh[3]}, lv = {ll[0], ll[1], ll[2], ll[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(hv, ores, (int)off_o, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(lv, ores, (int)(off_o + 16u), soff, 0);
+    }
+}
+
 // ---- backward of SpatialTransformer_grid (autograd of the reference's meshgrid -> normalise -> F.grid_sample composition,
 // models/submodule.py:265-288): one thread per (b, j, h, w), loop over the channels.
 //   grad_y[b,c,tap] += w_tap * g[b,c,j,h,w]                         (scatter through hardware fp32 atomics)
@@ -365,6 +470,27 @@ extern "C" int ss_concat_sampled_fwd(const float* left, const float* right, cons
     SS_REQUIRE(right && disp && out);                    // left == NULL: only the right half, out [B,C,nd,H,W]
     SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nd > 0);
     return launch<MODE_CONCAT>(left, right, disp, att, out, nullptr, B, C, H, W, nd, ss::as_stream(stream));
+}
+
+// The warped half of `att * cat(left broadcast, warp(right))` (models/SemStereo.py:241-244, 316-318) in the pre-split operand
+// form of ss_conv3d_presplit_fwd: xs [B][C/8][nd][H][W][2][8] fp16 (C % 8 == 0), xexp int[3 * B]: [0, B) the block exponents,
+// [B, 3B) scratch of the maxima.  att may be NULL.
+extern "C" int ss_concat_sampled_presplit_fwd(const float* right, const float* disp, const float* att, void* xs, int* xexp, int B,
+                                              int C, int H, int W, int nd, ss_stream_t stream) {
+    SS_REQUIRE(right && disp && xs && xexp);
+    SS_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && H > 0 && W >= 2 && nd > 0);
+    SS_REQUIRE((reinterpret_cast<uintptr_t>(xs) & 15) == 0);
+    if ((long long)C * nd * H * W * 4 >= 0x7fffffffLL || (long long)B * nd > 65535) return SS_ERR_UNSUPPORTED;
+    hipStream_t st = ss::as_stream(stream);
+    unsigned* amax = reinterpret_cast<unsigned*>(xexp + B);
+    if (hipMemsetAsync(amax, 0, (size_t)2 * B * sizeof(unsigned), st) != hipSuccess) return SS_ERR_LAUNCH;
+    const long long ny = (long long)C * H * W, na = (long long)nd * H * W;
+    hipLaunchKernelGGL(absmax2_kernel, dim3(128, B), dim3(256), 0, st, right, ny, att, na, amax);
+    const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
+    const dim3 grid(ss::ceil_div(W, 64), ss::ceil_div(H, 4), B * nd);
+    hipLaunchKernelGGL(warp_right_presplit, grid, dim3(256), 0, st, right, disp, att, amax, reinterpret_cast<uint4*>(xs), xexp, C, H, W,
+                       nd, half_w, half_h);
+    return ss::check_launch();
 }
 
 extern "C" int ss_warp_correlation_fwd(const float* x, const float* y, const float* disp, float* out, int B, int C,

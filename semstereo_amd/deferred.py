@@ -17,18 +17,33 @@ the line-by-line result: matching is an optimisation, never a semantic decision.
 Handles are created only when `on(...)` holds (eval mode, no autograd, HIP tensors, `SS_DEFER` != 0): training and
 autograd calls see ordinary tensors throughout.
 """
+import contextlib
 import os
+import threading
 
 import torch
-import torch.nn.functional as F
 
 ENABLED = os.environ.get("SS_DEFER", "1") != "0"
 STATS = {"fused": {}, "replayed": 0}          # which rules fired (tests and bench.py read this)
 
 
+_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def suspended():
+    """No handles inside this block (this thread): HotSegment's own fused composition calls the same ops and twins and
+    wants their tensors."""
+    _TLS.depth = getattr(_TLS, "depth", 0) + 1
+    try:
+        yield
+    finally:
+        _TLS.depth -= 1
+
+
 def on(module, *tensors):
     """True when ops / twins may hand out handles: deferral enabled and the folded-BN inference path valid."""
-    if not ENABLED:
+    if not ENABLED or getattr(_TLS, "depth", 0):
         return False
     from . import modules as M
     real_ts = [t for t in tensors if isinstance(t, torch.Tensor)]
@@ -95,18 +110,23 @@ class Deferred:
 
     def value(self):
         if self._value is None:
-            for rule in _VALUE_RULES.get(self.op, ()):
-                if rule(self) and self._value is not None:
-                    break
-            if self._value is None:
-                self._value = self._replay()
+            # handles exist only where nothing needs autograd (on()); the value may be asked for later, outside the caller's
+            # no_grad block -- it is computed as it would have been at the call
+            with torch.no_grad():
+                for rule in _VALUE_RULES.get(self.op, ()):
+                    if rule(self) and self._value is not None:
+                        break
+                if self._value is None:
+                    self._value = self._replay()
         return self._value
 
     def _replay(self):
         if self.op in ("item0", "item1"):
             return self.args[0].value()[int(self.op[-1])]
         STATS["replayed"] += 1
-        return self.func(*real(self.args), **real(self.kwargs))
+        args, kwargs = real(self.args), real(self.kwargs)
+        with suspended():                                # the recorded call itself, computing (no handles out of a replay)
+            return self.func(*args, **kwargs)
 
     # -- the tensor-like protocol --------------------------------------------------------------------------------------
     @classmethod
@@ -204,6 +224,26 @@ def _arg(node, pos, key, default=None):
     return node.args[pos] if len(node.args) > pos else default
 
 
+_NEUTRAL = {"dtype": (None,), "_stacklevel": None, "recompute_scale_factor": (None,), "antialias": (False, None), "out": (None,),
+            "align_corners": (None, False), "scale_factor": (None,), "stable": None, "alpha": (1,)}
+
+
+def _plain(node, *used):
+    """True when the recorded call carries nothing beyond the arguments in `used` that could change its meaning: F.softmax /
+    F.interpolate forward ALL their parameters as keywords (dtype=None, _stacklevel=3, antialias=False, ...)."""
+    for k, v in node.kwargs.items():
+        if k in used:
+            continue
+        ok = _NEUTRAL.get(k, ())
+        if ok is not None and not any(v is o or v == o for o in ok):
+            return False
+    return True
+
+
+def _is_softmax(node, dim):
+    return _is(node, "softmax") and _arg(node, 1, "dim") == dim and len(node.args) <= 2 and _plain(node, "dim", "input")
+
+
 def _binary(node, op):
     """(a, b) of a recorded binary call of kind `op`, else None."""
     if not _is(node, op) or len(node.args) != 2 or node.kwargs:
@@ -245,7 +285,7 @@ def _note_offset(node):
 def match_upsampled_prob(node):
     """-> (interpolate node, coarse tensor, size) when `node` is the soft-max over the disparity axis of the squeezed
     trilinear up-sampling of a [B,1,D,H,W] tensor, else None."""
-    if not _is(node, "softmax") or _arg(node, 1, "dim") != 1 or len(node.args) > 2 or set(node.kwargs) - {"dim"}:
+    if not _is_softmax(node, 1):
         return None
     sq = node.args[0]
     if not _is(sq, "squeeze") or _arg(sq, 1, "dim") != 1:
@@ -255,7 +295,7 @@ def match_upsampled_prob(node):
         return None
     if _arg(up, 3, "mode", "nearest") != "trilinear" or _arg(up, 2, "scale_factor") is not None:
         return None
-    if _arg(up, 4, "align_corners") not in (None, False) or set(up.kwargs) - {"size", "mode", "align_corners"}:
+    if _arg(up, 4, "align_corners") not in (None, False) or len(up.args) > 5 or not _plain(up, "size", "mode", "input"):
         return None
     size = _arg(up, 1, "size")
     coarse = real(up.args[0])
@@ -299,13 +339,13 @@ def variance_of(prob, rng, disparity):
 def _match_strength(node):
     """softmax(mul(mean(mul(STN.left, STN.right), dim=1), propagation(sigmoid(add(BETA, mul(GAMMA, VAR))))), dim=1) with
     STN = SpatialTransformer_grid(FL, FR, propagation(unsqueeze(PRED0, 1)))  ->  (fl, fr, pred0, var, gamma, beta)."""
-    if not _is(node, "softmax") or _arg(node, 1, "dim") != 1 or len(node.args) > 2 or set(node.kwargs) - {"dim"}:
+    if not _is_softmax(node, 1):
         return None
     ab = _either(_binary(node.args[0], "mul"), lambda x: _is(x, "mean"), lambda x: _is(x, "propagation"))
     if ab is None:
         return None
     mean, vs = ab
-    if _arg(mean, 1, "dim") != 1 or _arg(mean, 2, "keepdim", False) or len(mean.args) > 2 or set(mean.kwargs) - {"dim"}:
+    if _arg(mean, 1, "dim") != 1 or _arg(mean, 2, "keepdim", False) or len(mean.args) > 3 or not _plain(mean, "dim", "keepdim"):
         return None
     lr = _either(_binary(mean.args[0], "mul"), lambda x: _is(x, "item1"), lambda x: _is(x, "item0"))
     if lr is None or lr[0].args[0] is not lr[1].args[0] or not _is(lr[0].args[0], "stn"):
@@ -372,13 +412,13 @@ def _match_selected_indices(ik):
     if not _is(si, "item1") or not _is(si.args[0], "sort"):
         return None
     s1 = si.args[0]
-    if _arg(s1, 1, "dim") != 2 or _arg(s1, 2, "descending", False) not in (True, 1) or _arg(s1, 3, "stable", False):
+    if _arg(s1, 1, "dim") != 2 or _arg(s1, 2, "descending", False) not in (True, 1):      # (stable or not: ties -> lower index)
         return None
     awp = s1.args[0]
-    if not _is(awp, "softmax") or _arg(awp, 1, "dim") != 2 or len(awp.args) > 2 or set(awp.kwargs) - {"dim"}:
+    if not _is_softmax(awp, 2):
         return None
     aw = awp.args[0]
-    if not _is(aw, "sum") or _arg(aw, 1, "dim") != 1 or _arg(aw, 2, "keepdim", False) is not True:
+    if not _is(aw, "sum") or _arg(aw, 1, "dim") != 1 or _arg(aw, 2, "keepdim", False) is not True or not _plain(aw, "dim", "keepdim"):
         return None
     ps = _either(_binary(aw.args[0], "mul"), lambda x: _is(x, "propagation_prob"), lambda x: _is(x, "unsqueeze"))
     if ps is None or _arg(ps[1], 1, "dim") != 2:
@@ -443,14 +483,14 @@ def _rule_samples(node):                                    # IK.squeeze(1).floa
 
 
 def _rule_pred_att(node):                                   # sum(softmax(squeeze(gather(AW, 2, IK), 1), 1) * SAMPLES, dim=1)   (:307-310)
-    if _arg(node, 1, "dim") != 1 or _arg(node, 2, "keepdim", False) or len(node.args) > 2 or set(node.kwargs) - {"dim"}:
+    if _arg(node, 1, "dim") != 1 or _arg(node, 2, "keepdim", False) or len(node.args) > 3 or not _plain(node, "dim", "keepdim"):
         return False
     pq = _either(_binary(node.args[0], "mul"), lambda x: _is(x, "softmax"), lambda x: _samples_index_node(x) is not None)
     if pq is None:
         return False
     prob, smp = pq
     ik, off = _samples_index_node(smp)
-    if _arg(prob, 1, "dim") != 1 or not _is(prob.args[0], "squeeze") or _arg(prob.args[0], 1, "dim") != 1:
+    if not _is_softmax(prob, 1) or not _is(prob.args[0], "squeeze") or _arg(prob.args[0], 1, "dim") != 1:
         return False
     ga = prob.args[0].args[0]
     if not _is(ga, "gather") or _arg(ga, 1, "dim") != 2 or len(ga.args) < 3 or ga.args[2] is not ik:

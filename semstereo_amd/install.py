@@ -58,6 +58,7 @@ _SWAPS = {
     "classif_att_": M.Classifier,
     "classif": M.Classifier,
     "concat_stem": M.BasicConv,
+    "concat_feature": M.ConcatFeature,
     "patch": M.DepthwisePatch,
     "corr_feature_att_8": M.channelAtt,
     "concat_feature_att_4": M.channelAtt,

@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, ops
+from . import deferred as dfr
 from ._lib import call, ptr
 
 PATH_COUNTS = {"hip": 0, "torch": 0}
@@ -535,6 +536,7 @@ class _ConvBN3d(nn.Sequential):
     """nn.Sequential(Conv3d(bias=False), BatchNorm3d): keys `0.weight`, `1.*`."""
 
     def forward(self, x):
+        x = dfr.real(x)
         if _inference(self, x):
             PATH_COUNTS["hip"] += 1
             return run_convbn(self, "cb", self[0], self[1], x, relu=False)
@@ -582,6 +584,12 @@ class BasicConv(nn.Module):
     def forward(self, x, gate_logits=None, gate=None):
         """gate_logits [B,Cout,H,W] (3-D form only): fuses the channelAtt gate that follows `concat_stem`
         in the model (models/SemStereo.py:319-320) into the conv epilogue; `gate`: its sigmoid, already computed."""
+        if isinstance(x, dfr.Deferred):
+            if self.is_3d and not self.deconv and not x.done and gate_logits is None and gate is None and dfr.on(self):
+                # concat_stem(att_topk * concat_volume), :319: the volume is still an expression and the channelAtt gate of
+                # :320 comes next -- hand the pair on (deferred.stem_of runs the by-halves kernels)
+                return dfr.Deferred.call("stem", lambda mod, v: mod(v), self, x)
+            x = x.value()
         if self.is_3d and not self.deconv and _inference(self, x, gate_logits, gate):
             PATH_COUNTS["hip"] += 1
             g = gate if gate is not None else (None if gate_logits is None else torch.sigmoid(gate_logits).contiguous())
@@ -604,6 +612,35 @@ class BasicConv(nn.Module):
         if gate is not None:
             x = gate.unsqueeze(2) * x
         return x
+
+
+class ConcatFeature(nn.Sequential):
+    """`concat_feature` (models/SemStereo.py:221-223): nn.Sequential(BasicConv(C, C/2, 3x3) , Conv2d(C/2, C/4, 3x3, bias=False));
+    keys `0.conv.weight`, `0.bn.*`, `1.weight`.  Inference: both layers on the 2-D form of the tiled conv kernel."""
+
+    def __init__(self, channels):
+        super().__init__(BasicConv(channels, channels // 2, kernel_size=3, stride=1, padding=1),
+                         nn.Conv2d(channels // 2, channels // 4, 3, 1, 1, bias=False))
+
+    @classmethod
+    def adopt(cls, ref):
+        assert len(ref) == 2 and isinstance(ref[1], nn.Conv2d)
+        self = cls.__new__(cls)
+        first = ref[0] if isinstance(ref[0], BasicConv) else BasicConv.adopt(ref[0])
+        nn.Sequential.__init__(self, first, ref[1])
+        self.train(ref.training)
+        return self
+
+    def forward(self, x):
+        x = dfr.real(x)
+        a, b = self[0], self[1]
+        if (isinstance(getattr(a, "conv", None), nn.Conv2d) and getattr(a, "relu", False) and not getattr(a, "deconv", False)
+                and _inference(self, x)):
+            y = run_conv2d(a, "bc2d", a.conv, a.bn if getattr(a, "use_bn", True) else None, x, True)
+            if y is not None:
+                z = run_conv2d(self, "cf1", b, None, y, False)
+                return z if z is not None else b(y)
+        return super().forward(x)
 
 
 STEM_LEFT_FUSED = os.environ.get("SS_STEM_LEFT_FUSED", "1") != "0"     # Q of the broadcast half on the fly (one launch) or through HBM (two)
@@ -719,6 +756,7 @@ class attention_block(nn.Module):
     def forward(self, x):
         # another head count / width / window than the reference's: the same computation as PyTorch ops on the GPU
         # (visible in PATH_COUNTS["torch"]) instead of an SS_ERR_UNSUPPORTED from deep inside forward()
+        x = dfr.real(x)
         if _inference(self, x) and self.hip_supported():
             PATH_COUNTS["hip"] += 1
             x = x if x.is_contiguous() else x.contiguous()
@@ -830,6 +868,7 @@ class hourglass(nn.Module):
         return deconv3d_hip(x, wd, shift, relu=True, skip=skip, skip_wpack=wr)
 
     def forward(self, x):
+        x = dfr.real(x)
         if not _inference(self, x):
             PATH_COUNTS["torch"] += 1
             conv1 = self.conv1(x)
@@ -869,6 +908,12 @@ class Classifier(nn.Sequential):
         return self
 
     def forward(self, x):
+        x = dfr.real(x)
+        if dfr.on(self, x):
+            # a handle around the result: when the caller up-samples, soft-maxes and regresses it next (:279-285), those
+            # statements and this head's output meet in one kernel (deferred.regression_of); any other use sees the tensor
+            with dfr.suspended():
+                return dfr.Deferred.leaf(self.forward(x), role="cost")
         if _inference(self, x):
             PATH_COUNTS["hip"] += 1
             c0, bn0, c2 = self[0][0], self[0][1], self[2]
@@ -915,7 +960,9 @@ class Propagation(nn.Module):
         return cls().train(ref.training)
 
     def forward(self, disparity_samples):
-        return propagation(disparity_samples)
+        if dfr.on(None, disparity_samples):         # :288-289: recorded; deferred._match_strength recognises the probe they feed
+            return dfr.Deferred.call("propagation", propagation, disparity_samples)
+        return propagation(dfr.real(disparity_samples))
 
 
 class Propagation_prob(nn.Module):
@@ -926,7 +973,9 @@ class Propagation_prob(nn.Module):
         return cls().train(ref.training)
 
     def forward(self, prob_volume):
-        return propagation_prob(prob_volume)
+        if dfr.on(None, prob_volume):               # :295: recorded; deferred._match_selected_indices recognises the selection
+            return dfr.Deferred.call("propagation_prob", propagation_prob, prob_volume)
+        return propagation_prob(dfr.real(prob_volume))
 
 
 class DepthwisePatch(nn.Conv3d):
@@ -945,6 +994,10 @@ class DepthwisePatch(nn.Conv3d):
 
     def forward(self, x, gate_logits=None):
         """gate_logits [B,C,H,W]: fuses the channelAtt gate that follows `patch` in the model."""
+        if isinstance(x, dfr.Deferred):
+            if x.op == "gwc_norm" and not x.done and gate_logits is None and dfr.on(self):
+                return dfr.Deferred.call("patch", lambda mod, v: mod(v), self, x)      # :274; the gate of :276 decides the kernel
+            x = x.value()
         if _inference(self, x, gate_logits):
             PATH_COUNTS["hip"] += 1
             x = x if x.is_contiguous() else x.contiguous()
@@ -1020,6 +1073,17 @@ class channelAtt(nn.Module):
         return torch.sigmoid(att) if sigmoid else att
 
     def forward(self, cv, im):
+        im = dfr.real(im)
+        if isinstance(cv, dfr.Deferred):
+            # :276 after build_gwc_volume_norm + patch, or :320 after concat_stem(att_topk * concat_volume): one fused launch
+            # (sequence) instead of the statements one by one; anything else: the value
+            if dfr.on(self, im):
+                fused = dfr.gated_volume_of(cv, self, im)
+                if fused is None:
+                    fused = dfr.stem_of(cv, self, im)
+                if fused is not None:
+                    return fused
+            cv = cv.value()
         if _inference(self, cv, im):
             PATH_COUNTS["hip"] += 1
             return ops.channel_gate(self.logits(im), cv)
@@ -1068,6 +1132,7 @@ class SSR_upsample(nn.Module):
 
     def forward(self, depth_low, weights, pred_label):
         # ssr_upsample.hip is built for the reference's 6 classes (main_us3d.py:66); other counts: PyTorch ops on the GPU
+        depth_low, weights, pred_label = dfr.real(depth_low), dfr.real(weights), dfr.real(pred_label)
         if _inference(self, depth_low, weights, pred_label) and self.num_classes == 6:
             PATH_COUNTS["hip"] += 1
             depth_low, weights, pred_label = [t if t.is_contiguous() else t.contiguous() for t in (depth_low, weights, pred_label)]

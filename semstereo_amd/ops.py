@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from . import deferred as dfr
 from ._lib import call, ptr
 
 
@@ -79,6 +80,7 @@ def _group_normalise(x, groups):
     return (v / (torch.linalg.vector_norm(v, 2, dim=2, keepdim=True) + 1e-05)).reshape(B, C, H, W)
 
 
+@dfr.realising
 def _build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None):
     """models/submodule.py:198-211 -> [B, G, 2*maxdisp, H, W] (signed disparity range)."""
     _check_pair(refimg_fea, targetimg_fea, num_groups)
@@ -88,10 +90,16 @@ def _build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=Non
     return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), rng, int(num_groups), False)
 
 
-def _build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None):
-    """models/submodule.py:224-238 (the live call, models/SemStereo.py:273)."""
+def _build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _range=None, _defer=True):
+    """models/submodule.py:224-238 (the live call, models/SemStereo.py:273).  In inference the result is a deferred handle
+    (deferred.py): the caller's next two statements, `patch` and the channelAtt gate (:274-276), run with it in ONE kernel."""
+    refimg_fea, targetimg_fea = dfr.real(refimg_fea), dfr.real(targetimg_fea)
     _check_pair(refimg_fea, targetimg_fea, num_groups)
     rng = _range or signed_range(maxdisp)
+    if (_defer and dfr.on(None, refimg_fea, targetimg_fea) and refimg_fea.dtype == torch.float32
+            and gwc_patch_gate_applies(refimg_fea, maxdisp, num_groups, rng)):
+        return dfr.Deferred.call("gwc_norm", lambda a, b, m, g, r: _build_gwc_volume_norm(a, b, m, g, r, _defer=False),
+                               refimg_fea, targetimg_fea, maxdisp, int(num_groups), rng)
     if _needs_grad(refimg_fea, targetimg_fea):
         # normalise once with autograd-visible ops, then the volume kernel with its HIP backward
         return _GwcVolume.apply(_group_normalise(refimg_fea, num_groups), _group_normalise(targetimg_fea, num_groups),
@@ -143,11 +151,13 @@ def _group_corr(fea1, fea2, groups, normalize):
     return out
 
 
+@dfr.realising
 def groupwise_correlation(fea1, fea2, num_groups):
     """models/submodule.py:190-196 -> [B, G, H, W]."""
     return _group_corr(fea1, fea2, int(num_groups), False)
 
 
+@dfr.realising
 def groupwise_correlation_norm(fea1, fea2, num_groups):
     """models/submodule.py:213-221 -> [B, G, H, W]."""
     return _group_corr(fea1, fea2, int(num_groups), True)
@@ -182,6 +192,7 @@ class _ConcatVolume(torch.autograd.Function):
         return gref, gtgt, None, None
 
 
+@dfr.realising
 def _build_concat_volume(refimg_fea, targetimg_fea, maxdisp, _range=None, _mask_left=True):
     """models/submodule.py:173-187 -> [B, 2C, 2*maxdisp, H, W]."""
     _check_pair(refimg_fea, targetimg_fea)
@@ -217,9 +228,16 @@ class _DisparityRegression(torch.autograd.Function):
 
 
 def _disparity_regression(x, maxdisp, _range=None):
-    """models/submodule.py:164-170: [B, 2*maxdisp, H, W] -> [B, H, W]."""
-    assert len(x.shape) == 4
+    """models/submodule.py:164-170: [B, 2*maxdisp, H, W] -> [B, H, W].  Given the deferred handle of
+    `F.softmax(torch.squeeze(F.interpolate(cost, size, mode='trilinear'), 1), dim=1)` (models/SemStereo.py:279-282), the
+    up-sampling, the soft-max, this regression and the variance of :285 are one kernel."""
     rng = _range or signed_range(maxdisp)
+    if isinstance(x, dfr.Deferred):
+        fused = dfr.regression_of(x, rng)
+        if fused is not None:
+            return fused
+        x = x.value()
+    assert len(x.shape) == 4
     assert x.shape[1] == rng[1], "the disparity axis must span the whole range"
     return _DisparityRegression.apply(x, rng)
 
@@ -250,8 +268,14 @@ class _DisparityVariance(torch.autograd.Function):
 
 def _disparity_variance(x, maxdisp, disparity, _range=None):
     """models/submodule.py:257-263: x [B,2m,H,W], disparity [B,1,H,W] -> [B,1,H,W]."""
-    assert len(x.shape) == 4
     rng = _range or signed_range(maxdisp)
+    disparity = dfr.real(disparity)
+    if isinstance(x, dfr.Deferred):
+        fused = dfr.variance_of(x, rng, disparity)          # computed together with the regression of the same handle
+        if fused is not None:
+            return fused
+        x = x.value()
+    assert len(x.shape) == 4
     assert x.shape[1] == rng[1] and disparity.shape == (x.shape[0], 1, x.shape[2], x.shape[3])
     return _DisparityVariance.apply(x, disparity, rng)
 
@@ -331,6 +355,7 @@ class _RegressionTopk(torch.autograd.Function):
 def regression_topk(cost, disparity_samples, k):
     """models/submodule.py:434-442: cost, samples [B,nd,H,W] -> [B,1,H,W].  Ties between equal
     costs resolve to the lower candidate index (the reference's unstable sort leaves them open)."""
+    cost, disparity_samples = dfr.real(cost), dfr.real(disparity_samples)
     assert cost.dim() == 4 and cost.shape == disparity_samples.shape
     k = int(k)
     assert 1 <= k <= cost.shape[1]
@@ -390,6 +415,14 @@ class _WarpSampled(torch.autograd.Function):
 def SpatialTransformer_grid(x, y, disp_range_samples):
     """models/submodule.py:265-288: x, y [B,C,H,W], disp [B,nd,H,W] -> (y_warped, x_warped), both
     [B,C,nd,H,W]."""
+    x, y = dfr.real(x), dfr.real(y)
+    if dfr.on(None, x, y, disp_range_samples):
+        # inference: what the caller does with the two results decides the kernel (:291-293 the 5-candidate probe fed by the
+        # propagated regression of :289; :316-320 the sparse concat volume -> x att_topk -> concat_stem -> gate); any other
+        # use replays this very call
+        assert x.dim() == 4 and x.shape == y.shape
+        return dfr.Deferred.pair(dfr.Deferred.call("stn", lambda a, b, d: SpatialTransformer_grid(a, b, d), x, y, disp_range_samples))
+    disp_range_samples = dfr.real(disp_range_samples)
     assert x.dim() == 4 and x.shape == y.shape and disp_range_samples.dim() == 4
     assert disp_range_samples.shape[0] == y.shape[0] and disp_range_samples.shape[2:] == y.shape[2:]
     return _WarpSampled.apply(x, y, disp_range_samples)

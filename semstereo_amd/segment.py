@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import deferred as dfr
 from . import modules as M
 from . import ops, ops_unsigned
 
@@ -38,7 +39,10 @@ propagation, propagation_prob = M.propagation, M.propagation_prob
 
 
 class HotSegment(nn.Module):
-    OVERLAP = os.environ.get("SS_OVERLAP", "1") != "0"     # two-stream overlap of the branches (inference)
+    #: two-stream overlap of the branches (inference): "auto" = at batch <= 2 only.  Measured (profiles/r03_a_bench_b*_ov*.json):
+    #: batch 1: 466.6 vs 462.4 pairs/s with / without; batch 4: 529.3 vs 531.1; batch 8: 538.7 vs 538.5 -- from batch 4 on the
+    #: attention branch fills the chip by itself and the volume kernel runs 4x slower beside the 2-D convolutions (381 vs 107 us)
+    OVERLAP = {"0": False, "1": True}.get(os.environ.get("SS_OVERLAP", "auto"), "auto")
     #: False: run the line-by-line composition of the reference's forward() (reference-named ops and modules,
     #: PyTorch glue in between) also in inference -- what a reference model gets from `install()` +
     #: `accelerate()` alone, with its forward() untouched.  True: the fused kernels of this file.
@@ -58,9 +62,7 @@ class HotSegment(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
         self.beta = nn.Parameter(2 * torch.ones(1))
         self.patch = M.DepthwisePatch(c8 // 8)
-        self.concat_feature = nn.Sequential(
-            M.BasicConv(c4, c4 // 2, kernel_size=3, stride=1, padding=1),
-            nn.Conv2d(c4 // 2, c4 // 4, 3, 1, 1, bias=False))
+        self.concat_feature = M.ConcatFeature(c4)
         self.corr_feature_att_8 = M.channelAtt(c4 // 4, c8)
         self.concat_feature_att_4 = M.channelAtt(c4 // 4, c4)
         self.hourglass_att = M.hourglass(32)
@@ -68,6 +70,8 @@ class HotSegment(nn.Module):
         self.hourglass = M.hourglass2(32)
         self.classif = M.Classifier(32)
         self.concat_stem = M.BasicConv(c4 // 2, c4 // 4, is_3d=True, kernel_size=3, stride=1, padding=1)
+        self.propagation = M.Propagation()                  # parameter-free (models/SemStereo.py:237-238)
+        self.propagation_prob = M.Propagation_prob()
 
     def load_reference_state_dict(self, state_dict, strict=True):
         """Load the slice of a reference SemStereo state_dict (optionally `module.`-prefixed, as
@@ -81,9 +85,19 @@ class HotSegment(nn.Module):
 
     # ---- models/SemStereo.py:273-310 ---------------------------------------------------
     def attention_branch(self, fl4, fr4, fl8, fr8):
+        """-> (att_topk [B,1,24,H4,W4], samples [B,24,H4,W4], pred_att [B,H4,W4], pred_att0 [B,H4,W4]).  FUSED: this repo's
+        own composition of the fused kernels.  Otherwise the reference's statements one by one, in its order, on the
+        reference-named ops and the twins -- what an untouched forward() executes; in inference those hand out deferred
+        handles (deferred.py) and the same fused kernels run, SS_DEFER=0 gives the plain op-by-op execution."""
+        fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, fl8, fr8)
+        if fast:
+            with dfr.suspended():
+                return HotSegment._attention_branch(self, fl4, fr4, fl8, fr8, True)
+        return HotSegment._attention_branch(self, fl4, fr4, fl8, fr8, False)
+
+    def _attention_branch(self, fl4, fr4, fl8, fr8, fast):
         m8, m4 = self.maxdisp // 8, self.maxdisp // 4
         H4, W4 = fl4.shape[-2:]
-        fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, fl8, fr8)
         groups = fl8.shape[1] // 8
         # the disparity ranges at 1/8 and 1/4 scale, and the op set whose reference-named callables the line-by-line form uses
         unsigned = getattr(self, "unsigned", False)
@@ -114,20 +128,25 @@ class HotSegment(nn.Module):
             strength = ops.sample_strength(fl4, fr4, pred0, var, self.gamma, self.beta)        # :286-293 fused
             att_topk, samples, pred_att = ops.topk_candidates(att_weights, strength, m4, TOPK, _range=r4)  # :295-310 fused
             return att_topk, samples, pred_att, pred0
-        var = torch.sigmoid(self.beta + self.gamma * var)                                      # :286-287
-        var_samples = propagation(var)                                                         # :288
-        disp_samples = propagation(pred0.unsqueeze(1))                                         # :289
+        var = self.beta + self.gamma * var                                                     # :286
+        var = torch.sigmoid(var)                                                               # :287
+        var_samples = self.propagation(var)                                                    # :288
+        disp_samples = self.propagation(pred0.unsqueeze(1))                                    # :289
         right_w, left_b = ops.SpatialTransformer_grid(fl4, fr4, disp_samples)                  # :291
         strength = (left_b * right_w).mean(dim=1)                                              # :292
         strength = torch.softmax(strength * var_samples, dim=1)                                # :293
-        aw = (propagation_prob(att_weights) * strength.unsqueeze(2)).sum(dim=1, keepdim=True)  # :295-297
+        aw = self.propagation_prob(att_weights)                                                # :295
+        aw = aw * strength.unsqueeze(2)                                                        # :296
+        aw = torch.sum(aw, dim=1, keepdim=True)                                                # :297
         aw_prob = F.softmax(aw, dim=2)                                                         # :298
-        _, ind = aw_prob.sort(dim=2, descending=True, stable=True)                                            # :299
-        ind_k = ind[:, :, :TOPK].sort(2, False)[0]                                             # :302-303
+        _, ind = aw_prob.sort(2, True)                                                         # :299
+        ind_k = ind[:, :, :TOPK]                                                               # :302
+        ind_k = ind_k.sort(2, False)[0]                                                        # :303
         att_topk = torch.gather(aw_prob, 2, ind_k)                                             # :304
-        samples = ind_k.squeeze(1).float() + r4[0]                                             # :305 (SemStereo_WHU.py:305: no offset)
-        att_prob = F.softmax(torch.gather(aw, 2, ind_k).squeeze(1), dim=1)                     # :307-308
-        pred_att = (att_prob * samples).sum(dim=1)                                             # :309-310
+        samples = ind_k.squeeze(1).float() - (-r4[0]) if r4[0] else ind_k.squeeze(1).float()   # :305 (SemStereo_WHU.py:305: no offset)
+        att_prob = torch.gather(aw, 2, ind_k).squeeze(1)                                       # :307
+        att_prob = F.softmax(att_prob, dim=1)                                                  # :308
+        pred_att = torch.sum(att_prob * samples, dim=1)                                        # :309-310
         return att_topk, samples, pred_att, pred0
 
     # ---- models/SemStereo.py:314-323 ---------------------------------------------------
@@ -150,7 +169,13 @@ class HotSegment(nn.Module):
         return one_view(fl4), one_view(fr4), self.concat_feature_att_4.logits(fl4, sigmoid=True)
 
     def matching_branch(self, fl4, fr4, att_topk, samples, prelude=None):
-        fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, att_topk)
+        fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, dfr.real(att_topk))
+        if fast:
+            with dfr.suspended():
+                return HotSegment._matching_branch(self, fl4, fr4, dfr.real(att_topk), dfr.real(samples), prelude, True)
+        return dfr.real(HotSegment._matching_branch(self, fl4, fr4, att_topk, samples, prelude, False))
+
+    def _matching_branch(self, fl4, fr4, att_topk, samples, prelude, fast):
         if fast:
             cl, cr, gate4 = prelude if prelude is not None else HotSegment.matching_prelude(self, fl4, fr4)
             if M.CONV_ENGINE != "f32" and samples.shape[1] in (6, 24, 32) and HotSegment.STEM_BY_HALVES:
@@ -165,11 +190,13 @@ class HotSegment(nn.Module):
         else:
             cl = self.concat_feature(fl4)                                                      # :314
             cr = self.concat_feature(fr4)                                                      # :315
-            right_w, left_b = ops.SpatialTransformer_grid(cl, cr, samples)
-            volume = att_topk * torch.cat((left_b, right_w), dim=1)
+            right_w, left_b = ops.SpatialTransformer_grid(cl, cr, samples)                     # :241-242 (concat_volume_generator)
+            volume = torch.cat((left_b, right_w), dim=1)                                       # :243
+            volume = att_topk * volume                                                         # :318
             volume = self.concat_stem(volume)                                                  # :319
             volume = self.concat_feature_att_4(volume, fl4)                                    # :320
-        cost = self.classif(self.hourglass(volume))                                            # :321-322
+        cost = self.hourglass(volume)                                                          # :321
+        cost = self.classif(cost)                                                              # :322
         return ops.regression_topk(cost.squeeze(1), samples, 2)                                # :323
 
     def forward(self, fl4, fr4, fl8, fr8):
@@ -184,6 +211,8 @@ def run_segment(owner, fl4, fr4, fl8, fr8, matching=True):
     `matching=False` stops after the attention branch (the reference's att_weights_only mode)."""
     fused = getattr(owner, "FUSED", HotSegment.FUSED)
     overlap = getattr(owner, "OVERLAP", HotSegment.OVERLAP)
+    if overlap == "auto":
+        overlap = fl4.shape[0] <= 2
     prelude = None
     if matching and fused and overlap and fl4.is_cuda and M._inference(owner, fl4, fr4, fl8, fr8):
         # The attention branch works at 1/8 scale: at small batch most of its kernels cannot fill
@@ -199,7 +228,7 @@ def run_segment(owner, fl4, fr4, fl8, fr8, matching=True):
         for t in prelude:
             t.record_stream(cur)
     pred = HotSegment.matching_branch(owner, fl4, fr4, att_topk, samples, prelude) if matching else None
-    return dict(pred=pred, pred_att=pred_att, samples=samples, att_topk=att_topk, pred_att0=pred0)
+    return dfr.real(dict(pred=pred, pred_att=pred_att, samples=samples, att_topk=att_topk, pred_att0=pred0))
 
 
 class GraphedSegment:

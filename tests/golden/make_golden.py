@@ -405,10 +405,21 @@ def gen_segment_full(ms, only=None):
         out[f"{n}/risk24_samples"] = per_px(samples)[r24].numpy().astype(np.int16)
         out[f"{n}/risk24_att_topk"] = f32(per_px(att_ref)[r24])
         out[f"{n}/risk24_gap24_rel"] = f32(per_px(gap24)[r24][:, 0])
+        # ... and what the EXACT (float64) evaluation of the attention branch selects at those pixels (the pinned oracle in
+        # double precision): where an fp32 implementation and the reference disagree at such a margin, this says whose
+        # rounding it is
+        Pc = P_cal(P, out, n)
+        P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in Pc.items()}
+        with torch.no_grad():
+            _, smp64, _ = oseg.attention_branch(P64, fl8.double(), fr8.double(), fl4.double(), fr4.double(), maxdisp)
+        out[f"{n}/risk24_truth_samples"] = per_px(smp64)[r24].numpy().astype(np.int16)
+        print(n, "float64 attention branch: its candidates equal the reference's on", int((per_px(smp64)[r24] == per_px(samples)[r24]).all(dim=1).sum()),
+              "of", r24.numel(), "risk24 pixels;", int((smp64 != samples).any(dim=1).sum()), "pixels of the whole map differ")
+        del smp64, P64
         # ... and the float64 answer of the matching branch (models/SemStereo.py:314-323) on the reference's candidates
         # ("truth"; the pinned oracle in double precision -- the reference's forward() cannot be split): what an fp32
         # evaluation of this graph -- the reference's own included -- can be held to at this depth of the soft-argmax
-        out[f"{n}/pred_truth_map"] = f32(oseg.matching_truth_tiled(P_cal(P, out, n), fl4, fr4, att_ref.unsqueeze(1), samples).squeeze(1))
+        out[f"{n}/pred_truth_map"] = f32(oseg.matching_truth_tiled(Pc, fl4, fr4, att_ref.unsqueeze(1), samples).squeeze(1))
         print(n, "pred range", float(pred.min()), float(pred.max()), "gap stats", out[f"{n}/gap_stats"], "%.0f s" % (time.time() - t0))
         del cap, net
     np.savez_compressed(path, **out)

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from oracle.ops import (SpatialTransformer_grid, build_gwc_volume_norm, disparity_regression,  # noqa: F401
-                        disparity_variance, propagation, propagation_prob, regression_topk)
+                        disparity_variance, regression_topk)
 
 
 class _Pyramid(nn.Module):
@@ -66,10 +66,10 @@ class StandInSemStereo(nn.Module):
         self.corr_feature_att_8, self.concat_feature_att_4 = M.channelAtt(32, 256), M.channelAtt(32, 128)
         self.hourglass_att, self.hourglass = M.hourglass(32), M.hourglass2(32)
         self.classif_att_, self.classif = M.Classifier(32), M.Classifier(32)
-        self.concat_feature = nn.Sequential(M.BasicConv(128, 64, kernel_size=3, stride=1, padding=1),
-                                            nn.Conv2d(64, 32, 3, 1, 1, bias=False))
+        self.concat_feature = M.ConcatFeature(128)
         self.concat_stem = M.BasicConv(64, 32, is_3d=True, kernel_size=3, stride=1, padding=1)
         self.ssr_upsample = M.SSR_upsample(num_classes)
+        self.propagation, self.propagation_prob = M.Propagation(), M.Propagation_prob()
         self.calls = 0
 
     def concat_volume_generator(self, left_input, right_input, disparity_samples):
@@ -90,27 +90,49 @@ class StandInSemStereo(nn.Module):
         xspx = self.spx8_4(xspx, fl[1])
         xspx = self.spx4_2(xspx, fl[0])
         spx_pred = self.spx2(xspx)
+        # the hot segment, statement by statement in the reference's order (models/SemStereo.py:273-324): an op-by-op drop-in
+        # sees exactly this call sequence, and semstereo_amd.deferred recognises exactly this text
         m4 = self.maxdisp // 4
-        corr = build_gwc_volume_norm(fl[2], fr[2], self.maxdisp // 8, self.chans2[2] // 8)
-        corr = self.patch(corr)
-        cost_att = self.classif_att_(self.hourglass_att(self.corr_feature_att_8(corr, fl[2])))
-        att_weights = F.interpolate(cost_att, [m4 * 2, left.size()[2] // 4, left.size()[3] // 4], mode="trilinear")
-        prob0 = F.softmax(att_weights.squeeze(1), dim=1)
-        pred0 = disparity_regression(prob0, m4)
-        var = torch.sigmoid(self.beta + self.gamma * disparity_variance(prob0, m4, pred0.unsqueeze(1)))
-        right_w, left_b = SpatialTransformer_grid(fl[1], fr[1], propagation(pred0.unsqueeze(1)))
-        strength = torch.softmax((left_b * right_w).mean(dim=1) * propagation(var), dim=1)
-        aw = (propagation_prob(att_weights) * strength.unsqueeze(2)).sum(dim=1, keepdim=True)
+        volume8 = build_gwc_volume_norm(fl[2], fr[2], self.maxdisp // 8, self.chans2[2] // 8)
+        volume8 = self.patch(volume8)
+        logits8 = self.corr_feature_att_8(volume8, fl[2])
+        logits8 = self.hourglass_att(logits8)
+        logits8 = self.classif_att_(logits8)
+        logits4 = F.interpolate(logits8, [m4 * 2, left.size()[2] // 4, left.size()[3] // 4], mode="trilinear")
+        p0 = torch.squeeze(logits4, 1)
+        p0 = F.softmax(p0, dim=1)
+        d0 = disparity_regression(p0, m4)
+        v0 = disparity_variance(p0, m4, d0.unsqueeze(1))
+        v0 = self.beta + self.gamma * v0
+        v0 = torch.sigmoid(v0)
+        v5 = self.propagation(v0)
+        d5 = self.propagation(d0.unsqueeze(1))
+        right5, left5 = SpatialTransformer_grid(fl[1], fr[1], d5)
+        w5 = (left5 * right5).mean(dim=1)
+        w5 = torch.softmax(w5 * v5, dim=1)
+        aw = self.propagation_prob(logits4)
+        aw = aw * w5.unsqueeze(2)
+        aw = torch.sum(aw, dim=1, keepdim=True)
         aw_prob = F.softmax(aw, dim=2)
-        ind_k = aw_prob.sort(2, True)[1][:, :, :24].sort(2, False)[0]
+        _, order = aw_prob.sort(2, True)
+        ind_k = order[:, :, :24]
+        ind_k = ind_k.sort(2, False)[0]
         att_topk = torch.gather(aw_prob, 2, ind_k)
-        samples = ind_k.squeeze(1).float() - m4
-        pred_att = (F.softmax(torch.gather(aw, 2, ind_k).squeeze(1), dim=1) * samples).sum(dim=1)
+        samples = ind_k.squeeze(1).float() - self.maxdisp // 4
+        pk = torch.gather(aw, 2, ind_k).squeeze(1)
+        pk = F.softmax(pk, dim=1)
+        pred_att = pk * samples
+        pred_att = torch.sum(pred_att, dim=1)
         pred_att_up = self.ssr_upsample(pred_att.unsqueeze(1), spx_pred, pred_label)
         if not self.att_weights_only:
-            volume = att_topk * self.concat_volume_generator(self.concat_feature(fl[1]), self.concat_feature(fr[1]), samples)
-            volume = self.concat_feature_att_4(self.concat_stem(volume), fl[1])
-            cost = self.classif(self.hourglass(volume))
+            cl = self.concat_feature(fl[1])
+            cr = self.concat_feature(fr[1])
+            volume = self.concat_volume_generator(cl, cr, samples)
+            volume = att_topk * volume
+            volume = self.concat_stem(volume)
+            volume = self.concat_feature_att_4(volume, fl[1])
+            cost = self.hourglass(volume)
+            cost = self.classif(cost)
             pred = regression_topk(cost.squeeze(1), samples, 2)
             pred_up = self.ssr_upsample(pred, spx_pred, pred_label)
         if self.training:

@@ -35,6 +35,8 @@ def fixture_view(g, name):
         v["risk_samples"] = torch.from_numpy(g[f"{name}/risk24_samples"].astype(np.float32))
         v["risk_att"] = torch.as_tensor(g[f"{name}/risk24_att_topk"])
         v["risk_gap24"] = torch.as_tensor(g[f"{name}/risk24_gap24_rel"])
+        if f"{name}/risk24_truth_samples" in files:          # what the float64 evaluation of the attention branch selects there
+            v["risk_truth_samples"] = torch.from_numpy(g[f"{name}/risk24_truth_samples"].astype(np.float32))
         tie = torch.zeros(n, dtype=torch.bool)
         tie[torch.from_numpy(g[f"{name}/risk2"].astype(np.int64))] = True
         v["tie"] = tie
@@ -66,10 +68,15 @@ def restore_reference_picks(v, att_topk, samples):
     explained[v["risk_idx"][v["risk_gap24"] < cases.DELTA24_REL]] = True
     unexplained = differs & ~explained
     px = torch.nonzero(differs & (row_of >= 0)).reshape(-1)
+    v["last_differing"] = {"pixels": px.tolist(), "reference_margin_rel": [float(v["risk_gap24"][r]) for r in row_of[px]]}
     if px.numel():
         rows = row_of[px]
         b, y, x = px // (H4 * W4), (px % (H4 * W4)) // W4, px % W4
         dev = samples.device
+        if "risk_truth_samples" in v:                       # whose rounding is it?  compare both picks with the exact evaluation's
+            mine = samples[b.to(dev), :, y.to(dev), x.to(dev)].cpu()
+            v["last_differing"]["hip_pick_equals_float64_truth"] = int((mine == v["risk_truth_samples"][rows]).all(dim=1).sum())
+            v["last_differing"]["reference_pick_equals_float64_truth"] = int((v["risk_samples"][rows] == v["risk_truth_samples"][rows]).all(dim=1).sum())
         samples[b.to(dev), :, y.to(dev), x.to(dev)] = v["risk_samples"][rows].to(dev)
         att_topk[b.to(dev), 0, :, y.to(dev), x.to(dev)] = v["risk_att"][rows].to(dev)
     return differs, unexplained
@@ -106,4 +113,5 @@ def run_strict(seg, g, name, device="cuda"):
         pred = seg.matching_branch(fl4, fr4, att_topk, samples)
     rep = strict_report(v, pred, differs)
     rep["unexplained_candidate_differences"] = int(unexplained.sum())
+    rep["differing_pixels"] = v.get("last_differing")
     return rep, v, pred, differs, unexplained

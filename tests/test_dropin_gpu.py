@@ -48,8 +48,22 @@ def test_fused_forward_equals_untouched_forward(sa, att_only):
     previous = sa.install(module)
     try:
         assert sa.accelerate(net) == []                       # the stand-in is already built from the twins
+        from semstereo_amd import deferred as dfr
+        dfr.STATS["fused"].clear()
+        before = dict(sa.modules.PATH_COUNTS)
         with torch.no_grad():
-            (d0,), lab0 = net(left, right)                     # forward() untouched: HIP ops + HIP modules, PyTorch glue
+            (d0,), lab0 = net(left, right)                     # forward() untouched: HIP ops + HIP modules; deferred handles fuse
+        assert sa.modules.PATH_COUNTS["torch"] == before["torch"]
+        want_rules = {"gwc_patch_gate", "upsample_softmax_regression", "sample_strength", "topk_candidates"} | (set() if att_only else {"stem_by_halves"})
+        assert set(dfr.STATS["fused"]) == want_rules and all(v == 1 for v in dfr.STATS["fused"].values()), dfr.STATS
+        dfr.ENABLED = False
+        try:
+            with torch.no_grad():
+                (d00,), _ = net(left, right)                   # ... and with deferral off: every statement its own launch(es)
+        finally:
+            dfr.ENABLED = True
+        e00 = (d00 - d0).abs()
+        assert float(e00.median()) <= 1e-4 and float((e00 <= 4e-3).float().mean()) >= 0.995, (float(e00.median()), float(e00.max()))
         calls = net.calls
         sa.accelerate(net, fuse_forward=True)
         before = dict(sa.modules.PATH_COUNTS)

@@ -86,7 +86,7 @@ def test_accelerate_on_the_real_reference_model(ref_module):
         (want,), _ = net(imgL, imgR)
     w = net.hourglass.conv1[0][0].weight
     done = sa.accelerate(net)
-    assert sorted(done) == sorted(["hourglass_att", "hourglass", "classif_att_", "classif", "concat_stem", "patch",
+    assert sorted(done) == sorted(["hourglass_att", "hourglass", "classif_att_", "classif", "concat_stem", "patch", "concat_feature",
                                    "corr_feature_att_8", "concat_feature_att_4", "ssr_upsample", "propagation",
                                    "propagation_prob"])
     assert list(net.state_dict().keys()) == keys                      # checkpoint compatibility
@@ -165,3 +165,49 @@ def test_install_unsigned_op_set_into_the_reference_whu_module(ref_module):
             net(torch.randn(1, 3, 128, 128), torch.randn(1, 3, 128, 128))
     finally:
         sa.uninstall(mw, prev)
+
+
+def test_deferred_fusion_matches_the_real_reference_forward(ref_module, monkeypatch):
+    """The statement sequences semstereo_amd.deferred recognises are the REFERENCE's: its own, untouched forward()
+    (models/SemStereo.py:246-346) on an installed + accelerated model fires every fused rule exactly once -- volume + patch +
+    gate (:273-276), up-sampling + soft-max + regression + variance (:279-285), the 5-candidate probe (:286-293), the top-24
+    selection (:295-310), sparse concat volume + stem + gate (:316-320) -- and returns what the plain execution returns.
+    (CPU: the fused kernels are stood in for by torch compositions of the same statements, tests/test_deferred.py.)"""
+    import semstereo_amd as sa
+    from semstereo_amd import deferred as dfr
+    from test_deferred import ALL_RULES, _cpu_fused_kernels
+    torch.manual_seed(0)
+    net = ref_module.SemStereo(64, False, True, True, 6).eval()
+    with torch.no_grad():
+        for name, t in net.named_parameters():                 # gamma = 0 (the reference's init) would leave the variance path dead
+            if name == "gamma":
+                t.fill_(0.25)
+    imgL, imgR = torch.randn(1, 3, 128, 128), torch.randn(1, 3, 128, 128)
+    with torch.no_grad():
+        (want,), lab = net(imgL, imgR)                          # the reference alone
+        net.att_weights_only = True
+        (want_att,), _ = net(imgL, imgR)
+        net.att_weights_only = False
+    _cpu_fused_kernels(monkeypatch)
+    prev = sa.install(ref_module)
+    try:
+        sa.accelerate(net)
+        with torch.no_grad():
+            (got,), lab2 = net(imgL, imgR)                      # its forward(), untouched, on the ops + twins with deferral
+        fired = dict(dfr.STATS["fused"])
+        assert set(fired) == ALL_RULES and all(v == 1 for v in fired.values()), fired
+        assert isinstance(got, torch.Tensor) and torch.equal(lab, lab2)
+        # (random PyTorch-default weights: nearly uniform attention, so a hard pick may flip on isolated pixels between two fp32
+        # evaluation orders; everything else agrees to rounding)
+        err = (got - want).abs()
+        assert float(err.median()) <= 1e-4 and float((err <= 4e-3).float().mean()) >= 0.99, (float(err.median()), float(err.max()))
+        # att_weights_only mode (:311, no matching branch)
+        net.att_weights_only = True
+        monkeypatch.setattr(dfr, "STATS", {"fused": {}, "replayed": 0})
+        with torch.no_grad():
+            (got_att,), _ = net(imgL, imgR)
+        assert set(dfr.STATS["fused"]) == ALL_RULES - {"stem_by_halves"}
+        err = (got_att - want_att).abs()
+        assert float(err.median()) <= 1e-4 and float((err <= 4e-3).float().mean()) >= 0.99, (float(err.median()), float(err.max()))
+    finally:
+        sa.uninstall(ref_module, prev)
