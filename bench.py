@@ -313,6 +313,7 @@ def main():
             plain, timed = M.conv3d_bf16s_hip, timer.wrap("concat_stem", M.conv3d_bf16s_hip)
             M.conv3d_bf16s_hip = lambda *a, **k: (timed if (k.get("gate") is not None or (len(a) > 8 and a[8] is not None))
                                                   else plain)(*a, **k)
+            M.stem_volume_half_presplit = timer.wrap("concat_stem_presplit", M.stem_volume_half_presplit)
         # the cost-volume kernel of the step: build_gwc_volume_norm fused with `patch` and the channelAtt gate
         # (models/SemStereo.py:273-276, ss_gwc_patch_gate_fwd); the volume kernel alone when that fusion is off
         semstereo_amd.segment.ops.build_gwc_volume_norm = timer.wrap("gwc", semstereo_amd.ops.build_gwc_volume_norm)
@@ -438,7 +439,9 @@ def main():
         "pairs_per_s_reference_forward_untouched_no_deferral": opbyop_rate,
         "deferred_rules_fired_per_run": fired,
     }
-    ms = timer.mean_ms("concat_stem")
+    ms, presplit = timer.mean_ms("concat_stem"), False
+    if not ms:
+        ms, presplit = timer.mean_ms("concat_stem_presplit"), True
     if ms:
         halves = engine != "f32" and semstereo_amd.HotSegment.STEM_BY_HALVES
         cin_stem = 32 if halves else 64     # by linearity only the warped right half of the volume is convolved
@@ -454,7 +457,10 @@ def main():
             code = 19 if engine == "f16x3" else nterms         # the kernel's NTERMS template argument
             typ = "fp16" if engine == "f16x3" else "bf16"
             ex = nterms * eq                                   # 16-bit MFMA flops actually issued per second
-            res["roofline"] = {"kernel": f"conv3d_bf16s<1,4,2,8,{code},true> (concat_stem: {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]"
+            # the symbol rocprofv3 shows: 4 x 4 x 32 tiles where the depth is a multiple of 4 (conv3d_bf16s.hip's tile choice)
+            sym = ("conv3d_pre<true>" if presplit else
+                   f"conv3d_bf16s<1, 4, 4, 4, {code}, true, 1, 3>" if k % 4 == 0 else f"conv3d_bf16s<1, 4, 2, 8, {code}, true, 1, 3>")
+            res["roofline"] = {"kernel": f"{sym} (concat_stem: {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]"
                                          + (", the warped half of the volume; + residual (the broadcast half, by linearity) + ReLU + channelAtt gate)" if halves
                                             else " + ReLU + channelAtt gate)"),
                                "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -109,6 +109,14 @@ int ss_warp_sampled_bwd(const float* grad_y_warped, const float* grad_x_warped, 
  * concat_stem through ss_stem_left_fwd). */
 int ss_concat_sampled_fwd(const float* left, const float* right, const float* disp, const float* att,
                           float* out, int B, int C, int H, int W, int nd, ss_stream_t stream);
+/* The right (warped) half of the same volume, att[b,j] * warp(right)[b,:,j] (models/SemStereo.py:241-244, 316-318), written
+ * PRE-SPLIT for the matrix core: every value as the two fp16 terms of x * 2^(141 - e), 8 channels per 16-byte slot,
+ *   xs [B][C/8][2 terms][nd][H][W][8] fp16 (C % 8 == 0, 4 bytes per value: the footprint of the fp32 volume),
+ *   xexp int[3*B]: [0,B) the block exponent e of each batch element (from the bound max|right[b]| * max|att[b]|),
+ *                  [B,3B) scratch for the two maxima.
+ * Consumed by ss_conv3d_presplit_fwd, which stages it by LDS-DMA with no conversion.  att may be NULL. */
+int ss_concat_sampled_presplit_fwd(const float* right, const float* disp, const float* att, void* xs, int* xexp,
+                                   int B, int C, int H, int W, int nd, ss_stream_t stream);
 /* The left (broadcast) half of concat_stem (models/SemStereo.py:319) by linearity:
  *   out[b,co,j,h,w] = sum_{kd,kh,kw} att[b, j+kd-1, h+kh-1, w+kw-1] * q[b, tap*Cout + co, h+kh-1, w+kw-1]
  * (zero outside), tap = kd*9+kh*3+kw, q [B,27*Cout,H,W] = the 1x1 convolution of the 2-D left concat
@@ -231,6 +239,14 @@ int ss_conv3d_bf16s_partial_fwd(const float* in, const void* wsplit, const float
                                 const float* shift, const float* gate, float* out,
                                 int B, int Cin, int D, int H, int W, int Cout, int relu, int nterms,
                                 ss_stream_t stream);
+/* concat_stem on the pre-split warped half (models/SemStereo.py:319-320): Conv3d(k3, s1, p1, bias=False) over
+ * xs / xexp of ss_concat_sampled_presplit_fwd (Cin % 8 == 0), out = gate * relu?(scale * (partial + conv) + shift);
+ * wsplit from ss_pack_conv3d_weights_f16s; partial [B,Cout,D,H,W], scale / shift [Cout], gate [B,Cout,H,W] may be NULL.
+ * Same results contract as ss_conv3d_bf16s_partial_fwd with nterms = 19 (the block exponent is per batch element
+ * instead of per staged tile). */
+int ss_conv3d_presplit_fwd(const void* xs, const int* xexp, const void* wsplit, const float* partial, const float* scale,
+                           const float* shift, const float* gate, float* out, int B, int Cin, int D, int H, int W,
+                           int Cout, int relu, ss_stream_t stream);
 /* Conv3d weight [Cout,Cin,3,3,3] fp32 -> split/packed bf16 fragments
  * [ceil(Cin/8)][14 tap pairs][3 terms][2 halves][Cout][8] (ceil(Cin/8)*14*3*2*Cout*16 bytes). */
 int ss_pack_conv3d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);

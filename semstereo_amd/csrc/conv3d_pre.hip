@@ -3,7 +3,8 @@
 // the two fp16 terms of the matrix-core form of conv3d_bf16s.hip (x * 2^(E_ONE - e) = hi + lo, e one block exponent per
 // batch element), 8 channels x 2 terms = 32 bytes per position, in exactly the 16-byte slots this kernel's LDS tile holds:
 //
-//     xs [B][Cin/8][D][H][W][2 terms][8 channels] fp16        xexp [B] int: the biased exponent e
+//     xs [B][Cin/8][2 terms][D][H][W][8 channels] fp16        xexp [B] int: the biased exponent e
+// (term-major: a DMA instruction's 64 lanes then read 64 consecutive 16-byte slots of a row, whole cache lines)
 //
 // The operand is then staged by LDS-DMA loads (buffer_load_dwordx4 ... lds): no prefetch registers, no conversion, no
 // per-chunk maximum, no accumulator rescale -- the K loop is MFMAs, LDS fragment reads, the weight-fragment ring and one DMA
@@ -84,19 +85,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_pre(const uint4* __restrict__ x
             const int r = p / P_IW;
             const int gw = ow0 - 1 + wx, gh = oh0 - 1 + r % P_IH, gd = od0 - 1 + r / P_IH;
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            po[i] = ok ? (unsigned)(((size_t)gd * plane + (size_t)gh * W + gw) * 32) : 0x80000000u;     // outside: zeros
+            po[i] = ok ? (unsigned)(((size_t)gd * plane + (size_t)gh * W + gw) * 16) : 0x80000000u;     // outside: zeros
         }
     };
     unsigned poff[P_NPOS];
     make_poff(blockIdx.x, poff);
     const long long chunk_bytes = (long long)D * (long long)plane * 32;
-    const int chunk_b = (int)chunk_bytes;
+    const int term_b = (int)(chunk_bytes / 2);                  // bytes of one term of one chunk
     const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(xs) + (size_t)b * nchunks * D * plane * 2, 0, (int)min((long long)nchunks * chunk_bytes, 0x7fffffffLL), 0x00020000);
     // DMA instruction k = 2 * i + term of chunk `q` into buffer `buf` (`dead`: nothing follows -- an offset beyond the buffer)
     auto dma = [&](int k, int buf, int q, unsigned dead) {
         const int i = k >> 1, term = k & 1;
-        lds_dma16(ires, &lds[(buf * 2 + term) * P_CS + slot0(i)], (int)((poff[i] | dead) + 16u * term), q * chunk_b);
+        lds_dma16(ires, &lds[(buf * 2 + term) * P_CS + slot0(i)], (int)(poff[i] | dead), (2 * q + term) * term_b);
     };
     if (tid == 0) lds[P_ZSLOT] = make_uint4(0u, 0u, 0u, 0u);
     float* aff = reinterpret_cast<float*>(&lds[P_ZSLOT + 2]);   // scale, shift, 2^-(weight scale) of the workgroup's 32 channels
@@ -189,7 +190,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_pre(const uint4* __restrict__ x
 #pragma unroll
                 for (int c = 0; c < 2; ++c) aq[k][c] = tq[k][c];
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the next chunk has landed in the other buffer
+        // the next chunk has landed in the other buffer: its DMA loads were issued in steps 0 .. 9, and vmcnt retires in order, so
+        // "at most the 8 weight-fragment loads of steps 10 .. 13 outstanding" is enough -- vmcnt(0) would also wait for those
+        // (an exposed L2 round trip per chunk: 315 vs 296 us for the on-the-fly form, r03_d)
+        static_assert(2 * P_NPOS == 10 && P_KSTEPS == 14, "vmcnt(8): 4 steps x 2 fragment loads after the last DMA");
+        __builtin_amdgcn_s_waitcnt(0x0F78);                      // vmcnt(8)
         __syncthreads();
         cur = nxt;
     }

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void warp_right_gated(const float* __restrict_
 }
 
 // ---- the warped half of the sparse concat volume written PRE-SPLIT for the matrix-core stem (conv3d_pre.hip): every value as
-// the two fp16 terms of x * 2^(E_ONE - e), 8 channels x 2 terms = 32 bytes per position, [B][C/8][nd][H][W][2][8].  One block
+// the two fp16 terms of x * 2^(E_ONE - e), 8 channels per 16-byte slot, [B][C/8][2 terms][nd][H][W][8].  One block
 // exponent e per batch element from a BOUND of the volume, max|y[b]| * max|att[b]| (bilinear weights sum to 1, so no element
 // exceeds it): known before the first element is produced, and everything within 2^-17 of it keeps all 24 bits (below that
 // the absolute error is 2^-39 of the bound -- the contract of the on-the-fly split in conv3d_bf16s.hip, with the tensor's
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void warp_right_presplit(const float* __restri
         const_cast<float*>(y + (long long)b * C * plane), 0, (int)min((long long)C * plane * 4, 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
         xs + (long long)b * (C / 8) * nd * plane * 2, 0, (int)min((long long)C * nd * plane * 4, 0x7fffffffLL), 0x00020000);
-    const unsigned off_o = inside ? (unsigned)pix * 32u : 0x80000000u;
+    const unsigned off_o = inside ? (unsigned)pix * 16u : 0x80000000u;
     const int ystep = (int)(plane * 4);
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -336,10 +336,10 @@ __global__ __launch_bounds__(256) void warp_right_presplit(const float* __restri
         unsigned hh[4], ll[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) split2_pk_f16_w(r8[2 * k], r8[2 * k + 1], hh[k], ll[k]);
-        const int soff = (int)((((long long)(c0 / 8) * nd + j) * plane) * 32);
+        const int soff_h = (int)((((long long)(c0 / 8) * 2 * nd + j) * plane) * 16), soff_l = soff_h + (int)((long long)nd * plane * 16);
         const u4 hv = {hh[0], hh[1], hh[2], hh[3]}, lv = {ll[0], ll[1], ll[2], ll[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(hv, ores, (int)off_o, soff, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(lv, ores, (int)(off_o + 16u), soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hv, ores, (int)off_o, soff_h, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(lv, ores, (int)off_o, soff_l, 0);
     }
 }
 

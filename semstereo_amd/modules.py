@@ -690,6 +690,36 @@ def stem_volume_half(stem, right_vol, partial, gate=None):
     return conv3d_bf16s_hip(right_vol, wr, stem.conv.out_channels, scale, shift, bool(stem.relu), nterms, None, g, partial=partial)
 
 
+#: SS_STEM_PRESPLIT=1: the warped half handed to the stem PRE-SPLIT (ss_concat_sampled_presplit_fwd -> ss_conv3d_presplit_fwd:
+#: LDS-DMA staging, no conversion, no per-chunk maximum in the conv; f16x3 engine only).  OFF by default: measured r03_d / r03_e
+#: (profiles/r03_e_bench_b1*.json) the stem launch takes 313-317 us in that form against 297-298 us with the fp32 volume and the
+#: on-the-fly split, the step 442.9 vs 452.3 pairs/s -- removing ALL staging arithmetic beside the matrix pipe does not speed
+#: the kernel up (nor did removing 16 % of it: 4.2 -> 3.55 VALU per MFMA at unchanged time, profiles/r03_b_pmc_conv_stem.txt)
+STEM_PRESPLIT = os.environ.get("SS_STEM_PRESPLIT", "0") != "0"
+
+
+def stem_presplit_applies(stem, right):
+    return (STEM_PRESPLIT and CONV_ENGINE == "f16x3" and right.shape[1] % 8 == 0 and stem.conv.in_channels == 2 * right.shape[1]
+            and _conv_geometry(stem.conv) == (3, 1))
+
+
+def stem_volume_half_presplit(stem, xs, xexp, partial, gate=None):
+    """stem_volume_half on the pre-split warped half (xs, xexp of ops.concat_volume_sampled_presplit)."""
+    assert stem.is_3d and not stem.deconv and CONV_ENGINE == "f16x3" and _inference(stem, partial, gate)
+    B, nchunks, _, D, H, W, _ = xs.shape
+    _, _, wr, scale, shift = _stem_halves_params(stem, nchunks * 8)
+    Cout = stem.conv.out_channels
+    g = None if gate is None else gate.contiguous()
+    dev = _lib.require_device(partial, scale, shift, g)
+    out = torch.empty((B, Cout, D, H, W), dtype=torch.float32, device=xs.device)
+    if partial is not None:
+        assert partial.shape == out.shape and partial.is_contiguous()
+    with torch.cuda.device(dev if dev is not None else xs.device):
+        call("ss_conv3d_presplit_fwd", ptr(xs), ptr(xexp), ptr(wr), ptr(partial), ptr(scale), ptr(shift), ptr(g), ptr(out),
+             B, nchunks * 8, D, H, W, Cout, int(bool(stem.relu)))
+    return out
+
+
 def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate=None):
     """`stem` (a 3x3x3 stride-1 BasicConv with 2C input channels) applied to cat(att * left broadcast over the
     candidates, right_vol) WITHOUT building the left half of that volume or convolving it: by linearity its

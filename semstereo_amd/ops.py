@@ -445,6 +445,23 @@ def concat_volume_sampled(left, right, disparity_samples, att=None):
     return out
 
 
+def concat_volume_sampled_presplit(right, disparity_samples, att=None):
+    """The warped half of `att * concat_volume` (models/SemStereo.py:241-244, 316-318) in the pre-split operand form of the
+    matrix-core stem (ss_conv3d_presplit_fwd): -> (xs int16 [B, C/8, 2, nd, H, W, 8], xexp int32 [3B]).  Inference only."""
+    right, disp = _c(right), _c(disparity_samples)
+    if att is not None:
+        att = _c(att.reshape(att.shape[0], att.shape[-3], att.shape[-2], att.shape[-1]))
+    dev = _lib.require_device(right, disp, att)
+    B, C, H, W = right.shape
+    nd = disp.shape[1]
+    assert C % 8 == 0
+    xs = torch.empty((B, C // 8, 2, nd, H, W, 8), dtype=torch.int16, device=right.device)
+    xexp = torch.empty(3 * B, dtype=torch.int32, device=right.device)
+    with torch.cuda.device(dev):
+        call("ss_concat_sampled_presplit_fwd", ptr(right), ptr(disp), ptr(att), ptr(xs), ptr(xexp), B, C, H, W, nd)
+    return xs, xexp
+
+
 def stem_left(q, att):
     """Left (broadcast) half of concat_stem by linearity (stem_left.hip): q [B, 27*Cout, H, W] = the 1x1
     projections of the 2-D left features onto the stem's left-half weights, att [B,1,nd,H,W] or [B,nd,H,W]

@@ -182,8 +182,12 @@ class HotSegment(nn.Module):
                 # the left half of the volume is the 2-D map `cl` broadcast over the candidates: neither built
                 # nor convolved (modules.stem_of_broadcast_and_volume); only the warped right half is a volume
                 partial = M.stem_broadcast_half(self.concat_stem, cl, att_topk)                # :319, broadcast half
-                right = ops.concat_volume_sampled(None, cr, samples, att_topk)                 # :316 + :318, warped half
-                volume = M.stem_volume_half(self.concat_stem, right, partial, gate4)           # :319 + :320 (gate4: sigmoid done)
+                if M.stem_presplit_applies(self.concat_stem, cr):
+                    xs, xexp = ops.concat_volume_sampled_presplit(cr, samples, att_topk)       # :316 + :318, warped half, pre-split
+                    volume = M.stem_volume_half_presplit(self.concat_stem, xs, xexp, partial, gate4)   # :319 + :320
+                else:
+                    right = ops.concat_volume_sampled(None, cr, samples, att_topk)             # :316 + :318, warped half
+                    volume = M.stem_volume_half(self.concat_stem, right, partial, gate4)       # :319 + :320 (gate4: sigmoid done)
             else:
                 volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                  # :316 + :318 fused
                 volume = self.concat_stem(volume, gate=gate4)                                  # :319 + :320 fused

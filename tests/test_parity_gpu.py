@@ -506,6 +506,61 @@ def test_stem_by_halves_equals_the_full_convolution(sa, shape):
         sa.modules.STEM_LEFT_FUSED = old
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 24, 9, 37), (1, 32, 6, 5, 70), (1, 32, 32, 3, 3), (1, 32, 24, 40, 96), (1, 32, 6, 13, 65)])
+@pytest.mark.parametrize("gated", [True, False])
+def test_stem_on_the_presplit_warped_half(sa, shape, gated):
+    """models/SemStereo.py:316-320 with the warped half handed over PRE-SPLIT (ss_concat_sampled_presplit_fwd ->
+    ss_conv3d_presplit_fwd: two fp16 terms per value with one block exponent per batch element, staged by LDS-DMA):
+    (a) the pre-split volume decodes to the fp32 kernel's values to 2^-22 of the bound; (b) the stem on it equals the stem
+    on the fp32 volume (on-the-fly split, per-tile exponents) to rounding, and is as close to the float64 convolution;
+    shapes with ragged tiles in every direction, a depth that is not a multiple of the 4-plane tile, image borders."""
+    if sa.modules.CONV_ENGINE != "f16x3":
+        pytest.skip("the pre-split form exists for the f16x3 engine")
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, C, nd, H, W = shape
+    cl, cr = dd.t_normalish((B, C, H, W), 311), dd.t_normalish((B, C, H, W), 312) * 3.0
+    samples = dd.distinct_sorted_candidates(B, nd, H, W, max(nd, W // 2), 313)
+    att = dd.t_uniform((B, 1, nd, H, W), 314, 0.0, 0.7)
+    gate = torch.sigmoid(dd.t_normalish((B, C, H, W), 315)) if gated else None
+    stem = sa.modules.BasicConv(2 * C, C, is_3d=True, kernel_size=3, stride=1, padding=1)
+    with torch.no_grad():
+        stem.conv.weight.copy_(dd.t_uniform((C, 2 * C, 3, 3, 3), 316, -1, 1) * (3.0 / (2 * C * 27)) ** 0.5)
+        stem.bn.weight.copy_(dd.t_uniform((C,), 317, 0.6, 1.4)); stem.bn.bias.copy_(dd.t_uniform((C,), 318, -0.1, 0.1))
+        stem.bn.running_mean.copy_(dd.t_uniform((C,), 319, -0.1, 0.1)); stem.bn.running_var.copy_(dd.t_uniform((C,), 320, 0.6, 1.4))
+    stem = stem.cuda().eval()
+    with torch.no_grad():
+        right = sa.ops.concat_volume_sampled(None, dev(cr), dev(samples), dev(att))            # fp32 [B,C,nd,H,W]
+        xs, xexp = sa.ops.concat_volume_sampled_presplit(dev(cr), dev(samples), dev(att))
+        # (a) decode: (hi + lo) * 2^(e - 141)
+        e = xexp[:B].cpu()
+        bound = (cr.abs().reshape(B, -1).max(dim=1).values * att.abs().reshape(B, -1).max(dim=1).values)
+        assert bool(((torch.frexp(bound).exponent + 126) == e).all()), (e, bound)                # biased exponent of the bound
+        terms = xs.view(torch.float16).reshape(B, C // 8, 2, nd, H, W, 8).float()
+        dec = (terms[:, :, 0] + terms[:, :, 1]) * torch.pow(2.0, (xexp[:B].float() - 141.0)).reshape(B, 1, 1, 1, 1, 1)
+        dec = dec.permute(0, 1, 5, 2, 3, 4).reshape(B, C, nd, H, W)
+        err_dec = (dec - right).abs().reshape(B, -1).max(dim=1).values.cpu()
+        assert bool((err_dec <= bound * 2.0 ** -21).all()), (err_dec, bound)
+        # (b) the stem
+        partial = sa.modules.stem_broadcast_half(stem, dev(cl), dev(att))
+        g = None if gate is None else dev(gate)
+        y_pre = sa.modules.stem_volume_half_presplit(stem, xs, xexp, partial, g)
+        y_f32 = sa.modules.stem_volume_half(stem, right, partial, g)
+    assert y_pre.shape == y_f32.shape == (B, C, nd, H, W)
+    d = float((y_pre - y_f32).abs().max())
+    REPORT[f"stem_presplit_vs_f32_volume/{shape}/{gated}"] = d
+    assert d <= 2e-5, d
+    vol = torch.cat((att * cl.unsqueeze(2).expand(B, C, nd, H, W), right.cpu()), dim=1)
+    sc, sh = sa.modules.fold_bn(stem.bn)
+    ref = F.conv3d(vol.double(), stem.conv.weight.detach().cpu().double(), None, 1, 1)
+    ref = F.relu(ref * sc.cpu().double().reshape(1, -1, 1, 1, 1) + sh.cpu().double().reshape(1, -1, 1, 1, 1))
+    if gate is not None:
+        ref = gate.double().unsqueeze(2) * ref
+    e_pre, e_f32 = float((y_pre.double().cpu() - ref).abs().max()), float((y_f32.double().cpu() - ref).abs().max())
+    REPORT[f"stem_presplit/{shape}/{gated}"] = e_pre
+    assert e_pre <= 2.0 * e_f32 + 1e-6, (e_pre, e_f32)
+
+
 HEAD_CASES = [
     # (B, Cin, D, H, W, relu): the 32 -> 1 classifier heads; W not a multiple of 30, both tile shapes, tiny volumes
     (2, 32, 5, 9, 37, False),
