@@ -137,6 +137,46 @@ def steady_ms(run, iters=20, warm_ms=200.0):
     return e0.elapsed_time(e1) / iters
 
 
+def steady_ms_rotating(runs, iters=21, warm_ms=200.0):
+    """As steady_ms over a LIST of launches of the same kernel on DIFFERENT buffer sets, visited round-robin: with more than
+    256 MiB of inputs between two visits of a set nothing of a launch's input is left in the Infinity Cache from the previous
+    one (a replay of ONE 268 MB input set is partly MALL-served, and FETCH_SIZE counts those hits)."""
+    n = len(runs)
+    for r in runs:
+        r()
+    torch.cuda.synchronize()
+    t0, k = time.time(), 0
+    while (time.time() - t0) * 1e3 < warm_ms:
+        for _ in range(9):
+            runs[k % n]()
+            k += 1
+        torch.cuda.synchronize()
+    iters = (iters + n - 1) // n * n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        runs[i % n]()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of a kernel from the PMC passes of tools/pmc_bytes.sh, as collected in profiles/pmc_traffic.json
+    ({key: {total_bytes, read_bytes, written_bytes, source}}): read at run time, so the line cannot carry a number that no
+    profile file holds.  -> (bytes or None, note)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(key)
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return None, "no PMC record for this kernel in profiles/pmc_traffic.json"
+    return rec["total_bytes"], (f"HBM bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes (tools/pmc_bytes.sh; FETCH_SIZE x 2 on gfx950): "
+                                f"{rec['read_bytes'] / 1e6:.1f} MB read + {rec['written_bytes'] / 1e6:.1f} MB written; transcribed_from "
+                                f"profiles/{rec['source']} (not measured in this run)")
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this file and relay
     rank 0's stdout (the JSON line).  The parent has made no GPU/HIP call (nothing before this point touches
@@ -465,10 +505,18 @@ def main():
                                             else " + ReLU + channelAtt gate)"),
                                "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ex / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
+                               "frac_of_best_gemm_on_random_data": ex / 1247.0,
                                "algorithmic_flop_per_launch": nterms * flops,
                                "note": f"{nterms} {typ} products per fp32 product (fp16 and bf16 MFMA peaks are equal); fp32-equivalent rate {eq:.1f} TFLOP/s = "
                                        f"{eq / MFMA_F32_PEAK_TFLOPS:.2f} x the {MFMA_F32_PEAK_TFLOPS} TFLOP/s fp32-MFMA peak",
                                "fp32_equivalent_tflops": eq}
+            if (H, W, maxdisp, engine) == (1024, 1024, 128, "f16x3") and halves and not presplit:
+                tb, tnote = pmc_traffic("stem_b1")
+                res["roofline"]["traffic"] = None if tb is None else tb * B
+                res["roofline"]["traffic_note"] = tnote
+            res["roofline"]["peak_note"] = ("peak = the 2.5 PFLOP/s nominal dense fp16 / bf16 MFMA rate at 2.4 GHz; MI355X_MICROARCH.md measures the best "
+                                            "dense bf16 GEMM loop at 1,247 TFLOP/s on random data (the chip holds 1.90-1.95 GHz there): "
+                                            "frac_of_best_gemm_on_random_data reads the launch against that")
     ms, fused_gwc = timer.mean_ms("gwc"), False
     if not ms:
         ms, fused_gwc = timer.mean_ms("gwc_fused"), True
@@ -488,52 +536,59 @@ def main():
                                                "configs[2] (batch 8) is below"}
         # the cost-volume kernel at BASELINE.json configs[2] (batch 8, the HBM-roofline configuration),
         # 20 back-to-back launches between two HIP events on the launch stream
+        lib = semstereo_amd._lib
         g8 = torch.Generator(device=device).manual_seed(7)
-        a8 = torch.randn(8, 256, H8, W8, generator=g8, device=device)
-        b8 = torch.randn(8, 256, H8, W8, generator=g8, device=device)
-        ms8 = steady_ms(lambda: semstereo_amd.ops.build_gwc_volume_norm(a8, b8, maxdisp // 8, 32))
+        NSETS = 3                                            # 3 x 268 MB of inputs: 537 MB between two visits of a set (MALL: 256 MiB)
+        sets = [(torch.randn(8, 256, H8, W8, generator=g8, device=device), torch.randn(8, 256, H8, W8, generator=g8, device=device),
+                 torch.randn(8, 32, H8, W8, generator=g8, device=device), torch.empty(8, 32, D8, H8, W8, device=device)) for _ in range(NSETS)]
+        m8 = maxdisp // 8
+
+        def gwc_run(a, b_, gl, o):
+            return lambda: lib.call("ss_gwc_volume_fwd", lib.ptr(a), lib.ptr(b_), lib.ptr(o), 8, 256, H8, W8, -m8, 2 * m8, 32, 1)
+        ms8 = steady_ms(gwc_run(*sets[0]))
+        ms8_cold = steady_ms_rotating([gwc_run(*st) for st in sets])
         nb8 = 8 * nbytes / B
+        tb, tnote = pmc_traffic("gwc_b8")
         res["roofline_cost_volume_b8"] = {"kernel": "gwc_volume_v4<8,true,stream>, batch 8 (BASELINE.json configs[2])", "bound": "hbm",
                                           "achieved": nb8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": nb8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": ms8,
+                                          "frac_cold": nb8 / (ms8_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms_cold": ms8_cold,
+                                          "cold_note": f"frac: the same 268 MB input set replayed back to back (its reads are partly served by the 256 MiB "
+                                                       f"Infinity Cache); frac_cold: {NSETS} input / output sets round-robin, 537 MB of other inputs and "
+                                                       f"1.07 GB of other outputs between two visits of a set -- every byte comes from and goes to HBM",
                                           "algorithmic_bytes_per_launch": nb8,
-                                          "traffic": 806.6e6,
-                                          "traffic_note": "HBM bytes per launch from PMC passes of tools/pmc_bytes.sh gwc 8 (profiles/"
-                                                          "r02_e_pmc_gwc_b8.md; r01: 806.1e6): 2 x FETCH_SIZE (268.6 MB) + WRITE_SIZE "
-                                                          "(538.0 MB), gfx950 correction applied; algorithmic 805.3e6"}
-        del a8, b8
-        # calibration SURVEY.md section 8(d) asks for: what a plain device-to-device copy reaches on this box
-        # (read + write bytes over time, 1 GiB, 10 back-to-back copies), to read the fractions against
-        src = torch.empty(256 << 20, dtype=torch.float32, device=device)
+                                          "traffic": tb, "traffic_note": tnote}
+        # calibration SURVEY.md section 8(d) asks for: what a plain streaming copy reaches on this box (this repo's 16-byte-per-lane
+        # nontemporal copy kernel, 1 GiB, read + write bytes over time; torch's copy_ beside it)
+        src = torch.empty(256 << 20, dtype=torch.float32, device=device).normal_()
         dst = torch.empty_like(src)
-        for _ in range(3):
-            dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2.0 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        nbc = src.numel() * 4
+        msc = steady_ms(lambda: lib.call("ss_tool_copy_fwd", lib.ptr(src), lib.ptr(dst), nbc), iters=10, warm_ms=100.0)
+        copy_gbs = 2.0 * nbc / (msc * 1e-3) / 1e9
+        mst = steady_ms(lambda: dst.copy_(src), iters=10, warm_ms=100.0)
         res["hbm_copy_measured_gbs"] = copy_gbs
+        res["hbm_copy_note"] = "ss_tool_copy_fwd: 16 bytes per lane, nontemporal, 1 GiB -> 1 GiB (MI355X_MICROARCH.md: 6.29 TB/s for a float4 copy)"
+        res["hbm_copy_torch_gbs"] = 2.0 * nbc / (mst * 1e-3) / 1e9
         res["roofline_cost_volume_b8"]["frac_of_measured_copy"] = res["roofline_cost_volume_b8"]["achieved"] / copy_gbs
+        res["roofline_cost_volume_b8"]["frac_cold_of_measured_copy"] = nb8 / (ms8_cold * 1e-3) / 1e9 / copy_gbs
         del src, dst
         # the fused form of the step (volume -> patch -> gate in one launch) at the same batch 8
-        g8 = torch.Generator(device=device).manual_seed(7)
-        a8 = torch.randn(8, 256, H8, W8, generator=g8, device=device)
-        b8 = torch.randn(8, 256, H8, W8, generator=g8, device=device)
-        gl8 = torch.randn(8, 32, H8, W8, generator=g8, device=device)
-        if semstereo_amd.ops.gwc_patch_gate_applies(a8, maxdisp // 8, 32):
-            run = lambda: semstereo_amd.ops.gwc_patch_gate(a8, b8, maxdisp // 8, 32, seg.patch.weight, gl8)     # noqa: E731
-            msf = steady_ms(run)
+        if semstereo_amd.ops.gwc_patch_gate_applies(sets[0][0], m8, 32):
+            pw = seg.patch.weight.detach().contiguous()
+
+            def fused_run(a, b_, gl, o):
+                return lambda: lib.call("ss_gwc_patch_gate_fwd", lib.ptr(a), lib.ptr(b_), lib.ptr(pw), lib.ptr(gl), lib.ptr(o), 8, 256, H8, W8,
+                                        -m8, 2 * m8, 32, 1)
+            msf = steady_ms(fused_run(*sets[0]))
+            msf_cold = steady_ms_rotating([fused_run(*st) for st in sets])
+            tb, tnote = pmc_traffic("gwc_fused_b8")
             res["roofline_cost_volume_fused_b8"] = {
                 "kernel": "gwc_patch_gate_v4<8,true,stream>, batch 8: volume + patch + gate in one launch", "bound": "hbm",
                 "achieved": nb8 / (msf * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": nb8 / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msf, "algorithmic_bytes_per_launch": nb8,
-                "traffic": 910.6e6,
-                "traffic_note": "HBM bytes per launch from PMC passes of tools/pmc_bytes.sh gwc_fused 8 (profiles/r02_e_pmc_gwc_fused_b8.md): "
-                                "2 x FETCH_SIZE (373.7 MB: the 8-rows-for-6 halo re-reads) + WRITE_SIZE (536.9 MB)"}
-        del a8, b8, gl8
+                "frac_cold": nb8 / (msf_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms_cold": msf_cold,
+                "traffic": tb, "traffic_note": tnote}
+        del sets
         # ... and alone at the bench batch: inside the step it shares the chip with the matching branch's 2-D convolutions
         # on the second stream (roofline_cost_volume above is that concurrent figure)
         gB = torch.Generator(device=device).manual_seed(8)
@@ -583,9 +638,11 @@ def main():
             "kernel": "conv3d_head_bf16s<4,8,2,6,CL> (classif.2: Conv3d(32,1,3) over [B,32,24,H/4,W/4], channels-last input), launched alone",
             "bound": "hbm", "achieved": nbh / (msh * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbh / (msh * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msh, "algorithmic_bytes_per_launch": nbh,
-            "traffic": 291.6e6 * B if (H, W, maxdisp) == (1024, 1024, 128) else None,
-            "traffic_note": "HBM bytes per pair from PMC passes of tools/pmc_bytes.sh head_cl 1 (profiles/r02_e_pmc_head_cl_b1.md): "
-                            "2 x FETCH_SIZE (284.1 MB: the 6x10-rows-for-4x8 halo re-reads that miss L2) + WRITE_SIZE (7.5 MB)"}
+            "traffic": None}
+        if (H, W, maxdisp) == (1024, 1024, 128):
+            tb, tnote = pmc_traffic("head_cl_b1")
+            res["roofline_classifier_head"]["traffic"] = None if tb is None else tb * B
+            res["roofline_classifier_head"]["traffic_note"] = tnote
         del xcl, outh
     except Exception as e:       # noqa: BLE001
         res["roofline_classifier_head"] = {"error": repr(e)}
@@ -606,6 +663,38 @@ def main():
                                "sample": f"1 pair {H}x{W} maxdisp={maxdisp} through oracle.hot_segment "
                                          f"(PyTorch CPU fp32 restatement of the reference), {cdt:.1f} s, "
                                          f"{nthreads} of {os.cpu_count()} host threads"}
+
+        # per-op rows: the oracle's restatement of each reference op on the live shapes of one pair,
+        # best of 2 after a warm-up call, on `nthreads` host threads; the volume builders also on ONE thread (the reference's
+        # slice loop of build_gwc_volume_norm -- 2 * maxdisp/8 x torch.norm on sliced views -- anti-scales with threads)
+        def best_of(fn, reps=2):
+            fn()
+            best = 1e30
+            for _ in range(reps):
+                t0_ = time.perf_counter()
+                fn()
+                best = min(best, time.perf_counter() - t0_)
+            return best
+        g_c = torch.Generator().manual_seed(11)
+        c8l, c8r = cpu_in[2], cpu_in[3]
+        cc = torch.randn(1, 32, H4, W4, generator=g_c)
+        prob4 = torch.softmax(torch.randn(1, 2 * (maxdisp // 4), H4, W4, generator=g_c), dim=1)
+        smp4 = ref["samples"]
+        cost4 = torch.randn(1, k, H4, W4, generator=g_c)
+        per_op = {
+            "build_gwc_volume_norm [1,256,H/8,W/8] x2 -> [1,32,D8,H/8,W/8]": lambda: oops.build_gwc_volume_norm(c8l, c8r, maxdisp // 8, 32),
+            "build_gwc_volume (same shapes)": lambda: oops.build_gwc_volume(c8l, c8r, maxdisp // 8, 32),
+            "build_concat_volume [1,32,H/4,W/4] x2 -> [1,64,D4,H/4,W/4]": lambda: oops.build_concat_volume(cc, cc, maxdisp // 4),
+            "SpatialTransformer_grid + cat + att (24 candidates, [1,32,H/4,W/4])": lambda: ref["att_topk"] * torch.cat(oops.SpatialTransformer_grid(cc, cc, smp4)[::-1], dim=1),
+            "disparity_regression [1,D4,H/4,W/4]": lambda: oops.disparity_regression(prob4, maxdisp // 4),
+            "regression_topk k=2 [1,24,H/4,W/4]": lambda: oops.regression_topk(cost4, smp4, 2),
+        }
+        rows = {name_: {"seconds": best_of(fn_), "threads": nthreads} for name_, fn_ in per_op.items()}
+        torch.set_num_threads(1)
+        for name_ in list(per_op)[:3]:
+            rows[name_]["seconds_one_thread"] = best_of(per_op[name_], reps=1)
+        torch.set_num_threads(nthreads)
+        res["cpu_baseline"]["per_op"] = rows
 
         def parity(o):
             pred, rpred = o["pred"][:1].cpu(), ref["pred"]

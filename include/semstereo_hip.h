@@ -355,6 +355,10 @@ int ss_window_attention_fwd(const float* x, const float* wqkv_t, const float* bq
 int ss_window_attention_core_fwd(const float* qkv, const float* bqkv, float* y, int B, int C, int D, int H,
                                  int W, int heads, int bd, int bh, int bw, ss_stream_t stream);
 
+/* Measurement aid (bench.py): a plain device copy, 16 bytes per lane, nontemporal -- the HBM rate a streaming kernel can
+ * reach on this box, which SURVEY.md section 8(d) asks the bandwidth fractions to be read against.  bytes % 16 == 0. */
+int ss_tool_copy_fwd(const void* src, void* dst, long long bytes, ss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

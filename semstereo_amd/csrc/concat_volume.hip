@@ -118,6 +118,29 @@ __global__ void concat_volume_bwd_kernel(const float* __restrict__ gout, float* 
 
 }  // namespace
 
+// ---- HBM calibration: a plain 16-byte-per-lane device copy, what SURVEY.md section 8(d) asks the bandwidth fractions to be read
+// against on THIS box (torch's copy_ reaches 64 % of the 8 TB/s spec, a float4 copy 79 %: MI355X_MICROARCH.md) ----
+namespace {
+typedef unsigned copy_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy16_kernel(const copy_u4* __restrict__ src, copy_u4* __restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const copy_u4 v = __builtin_nontemporal_load(src + i);
+        __builtin_nontemporal_store(v, dst + i);
+    }
+}
+}  // namespace
+
+extern "C" int ss_tool_copy_fwd(const void* src, void* dst, long long bytes, ss_stream_t stream) {
+    SS_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0);
+    SS_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0);
+    const long long n = bytes / 16;
+    const long long blocks = std::min<long long>(ss::ceil_div_ll(n, 256), 256LL * 32);       // grid-stride: 32 workgroups per CU
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, ss::as_stream(stream),
+                       reinterpret_cast<const copy_u4*>(src), reinterpret_cast<copy_u4*>(dst), n);
+    return ss::check_launch();
+}
+
 extern "C" int ss_concat_volume_fwd(const float* ref, const float* tgt, float* out, int B, int C, int H, int W,
                                     int dmin, int ndisp, int mask_left, ss_stream_t stream) {
     SS_REQUIRE(ref && tgt && out);

@@ -2,7 +2,7 @@
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
 usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low attn attn_att warp ssr ssr2048 strength topk
-                                                               catt8 catt4 upsoft stem_left conv_s1 conv_s2 deconv"""
+                                                               catt8 catt4 upsoft stem_left stem conv_s1 conv_s2 deconv"""
 import os
 import sys
 import time
@@ -106,6 +106,13 @@ elif name == "conv_s1_cl":       # the stride-1 32 -> 32 conv with channels-last
     lib = sa._lib
     fn = lambda: lib.call("ss_conv3d_bf16s_cl_fwd", lib.ptr(x), lib.ptr(ws), lib.ptr(sc), lib.ptr(sh), lib.ptr(mid), B, 32, 24, 256, 256, 32, 1, 19)   # noqa: E731
     nbytes = 4.0 * B * 2 * 32 * 24 * 256 * 256
+elif name == "stem":             # the dominant launch: concat_stem on the warped half, continuing the broadcast half's partial sum, gated
+    x = R(B, 32, 24, 256, 256)
+    ws = M.pack_conv_weight_bf16s(R(32, 32, 3, 3, 3) * 0.03, 19)
+    part, gate = R(B, 32, 24, 256, 256), torch.rand(B, 32, 256, 256, device=dev)
+    sc, sh = torch.rand(32, device=dev) + 0.5, R(32) * 0.1
+    fn = lambda: M.conv3d_bf16s_hip(x, ws, 32, sc, sh, True, 19, None, gate, partial=part)       # noqa: E731
+    nbytes = 4.0 * B * (3 * 32 * 24 + 32) * 256 * 256
 elif name in ("conv_s2", "conv_s1", "deconv"):
     if name == "deconv":            # hourglass2.conv6: 64 -> 32 to [24,256,256] with the 1x1x1 skip projection of a 32-channel volume
         hg = M.hourglass2(32).to(dev).eval()
