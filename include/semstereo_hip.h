@@ -355,6 +355,32 @@ int ss_window_attention_fwd(const float* x, const float* wqkv_t, const float* bq
 int ss_window_attention_core_fwd(const float* qkv, const float* bqkv, float* y, int B, int C, int D, int H,
                                  int W, int heads, int bd, int bh, int bw, ss_stream_t stream);
 
+/* ---- training side of the 3-D stack (main_us3d.py:186-222): what the matrix-core forward / dgrad / wgrad kernels leave over ---- */
+/* BatchNorm with BATCH statistics + optional ReLU (convbn_3d, models/submodule_other.py:845-848; BasicConv,
+ * models/submodule.py:89-116, in train()): x [B,C,N] (N = D*H*W or H*W), weight / bias [C] or NULL -> y, and mean / invstd /
+ * var_unbiased [C] (for the backward and the running statistics).  work: 2*C doubles of scratch. */
+int ss_batchnorm_train_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean, float* invstd,
+                           float* var_unbiased, double* work, int B, int C, long long N, float eps, int relu,
+                           ss_stream_t stream);
+/* ... backward: grad_x [B,C,N]; grad_bias[c] = work[2c], grad_weight[c] = work[2c+1] (doubles).  y is read only when relu. */
+int ss_batchnorm_train_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                           const float* weight, float* grad_x, double* work, int B, int C, long long N, int relu,
+                           ss_stream_t stream);
+/* sums[c] (double) = sum over batch and positions of a[b,c,:]: bias gradients of the 1x1x1 projections of attention_block
+ * (models/submodule_other.py:799-800). */
+int ss_channel_sum_fwd(const float* a, double* sums, int B, int C, long long N, ss_stream_t stream);
+/* Weight gradient of `patch` (depthwise Conv3d (1,3,3), models/SemStereo.py:219): grad_w [C,1,1,3,3]. */
+int ss_depthwise_patch_wgrad_fwd(const float* grad_out, const float* in, float* grad_w, int B, int C, int D, int H, int W,
+                                 ss_stream_t stream);
+/* channelAtt's gate (models/SemStereo.py:101-102), gradient of the logits:
+ * grad_att [B,C,H,W] = s (1 - s) * sum_d grad_out[b,c,d] * cv[b,c,d], s = sigmoid(att_logits).  (The gradient of cv is
+ * ss_channel_gate_fwd applied to grad_out.) */
+int ss_channel_gate_bwd_logits(const float* grad_out, const float* cv, const float* att_logits, float* grad_att, int B, int C,
+                               int D, int H, int W, ss_stream_t stream);
+/* Backward of ss_window_attention_core_fwd (models/submodule_other.py:805-834) for volumes whose H, W are multiples of
+ * the window (no pad tokens): qkv [B,3C,D,H,W], grad_y [B,C,D,H,W] -> grad_qkv [B,3C,D,H,W]. */
+int ss_window_attention_core_bwd(const float* qkv, const float* grad_y, float* grad_qkv, int B, int C, int D, int H, int W,
+                                 int heads, int bd, int bh, int bw, ss_stream_t stream);
 /* Measurement aid (bench.py): a plain device copy, 16 bytes per lane, nontemporal -- the HBM rate a streaming kernel can
  * reach on this box, which SURVEY.md section 8(d) asks the bandwidth fractions to be read against.  bytes % 16 == 0. */
 int ss_tool_copy_fwd(const void* src, void* dst, long long bytes, ss_stream_t stream);

@@ -13,9 +13,25 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS = 1e-5
+TRAINING = False        # True: BatchNorm normalises with the BATCH statistics (model.train(), main_us3d.py:186-222)
+
+
+class training_mode:
+    """with stack.training_mode(): the functional stack behaves as the reference's modules do in train() -- used with autograd
+    on the CPU as the gradient oracle of the HIP training path (tests/test_parity_gpu.py)."""
+
+    def __enter__(self):
+        global TRAINING
+        self.prev, TRAINING = TRAINING, True
+
+    def __exit__(self, *a):
+        global TRAINING
+        TRAINING = self.prev
 
 
 def bn(P, key, x):
+    if TRAINING:
+        return F.batch_norm(x, None, None, P[key + ".weight"], P[key + ".bias"], True, 0.0, BN_EPS)
     return F.batch_norm(x, P[key + ".running_mean"], P[key + ".running_var"],
                         P[key + ".weight"], P[key + ".bias"], False, 0.0, BN_EPS)
 

@@ -1,0 +1,333 @@
+// Training-side kernels of the 3-D aggregation stack (main_us3d.py:186-222 back-propagates through every module of
+// models/SemStereo.py:273-323): what the matrix-core forward / dgrad / wgrad kernels (conv3d_bf16s.hip, deconv3d_bf16s.hip,
+// conv3d_wgrad.hip) leave over -- BatchNorm with BATCH statistics (+ ReLU) forward and backward, the weight gradient of the
+// depthwise `patch` convolution, the logits gradient of the channelAtt gate, per-channel sums (bias gradients), and the
+// backward of the windowed attention core.  All HBM-bound element-wise / reduction kernels in fp32 with float64 reduction
+// totals (hardware f64 atomics), laid out for coalesced 16-byte accesses along W.
+#include "common.h"
+
+namespace {
+
+// ---- per-channel reductions over [B, C, N] (N = D*H*W) -----------------------------------------------------------------------
+// block (chunk, c): sums of a slice of the channel's B*N elements; 256 threads x float4; totals in double through atomics
+// sums[c*NS + k]; MODE 0: (x, x^2)   MODE 1: (g', g' * xhat) with g' = g * (y > 0 if relu), xhat = (x - mean) * invstd
+//                MODE 2: (g)         MODE 3: (g * cv summed over D for the gate: see gate_bwd_logits instead)
+template <int MODE>
+__global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                              const float* __restrict__ y, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, double* __restrict__ sums, int C,
+                                                              long long N, long long per_block, int relu) {
+    const int c = blockIdx.y;
+    const long long total = (long long)gridDim.z * N;       // (unused: batch is blockIdx.z)
+    (void)total;
+    const int b = blockIdx.z;
+    const long long base = ((long long)b * C + c) * N;
+    const long long i0 = (long long)blockIdx.x * per_block, i1 = min(i0 + per_block, N);
+    float s0 = 0.f, s1 = 0.f;
+    const float mu = (MODE == 1) ? mean[c] : 0.f, is = (MODE == 1) ? invstd[c] : 0.f;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        if (MODE == 0) {
+            const float v = a[base + i];
+            s0 += v; s1 += v * v;
+        } else if (MODE == 1) {
+            float g = a[base + i];
+            if (relu && !(y[base + i] > 0.f)) g = 0.f;
+            s0 += g; s1 += g * ((x[base + i] - mu) * is);
+        } else {
+            s0 += a[base + i];
+        }
+    }
+    __shared__ double red[2][4];
+    double d0 = s0, d1 = s1;
+    for (int o = 32; o > 0; o >>= 1) {
+        d0 += __shfl_xor(d0, o);
+        d1 += __shfl_xor(d1, o);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d0; red[1][threadIdx.x >> 6] = d1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        constexpr int NS = (MODE == 2) ? 1 : 2;
+        atomicAdd(&sums[c * NS], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        if (NS == 2) atomicAdd(&sums[c * NS + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// sums (x, x^2) -> mean, invstd (biased variance, as F.batch_norm normalises with), var_unbiased for the running statistic
+__global__ void bn_finish_stats_kernel(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ invstd,
+                                       float* __restrict__ var_unbiased, int C, double count, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / count;
+    const double v = fmax(sums[2 * c + 1] / count - m * m, 0.0);
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+    var_unbiased[c] = (float)(count > 1.0 ? v * count / (count - 1.0) : v);
+}
+
+// y = (x - mean) * invstd * w + b  [ReLU]
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int C, long long N,
+                                                        long long total, int relu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / N) % C);
+    const float sc = invstd[c] * (w ? w[c] : 1.f), sh = (bias ? bias[c] : 0.f) - mean[c] * sc;
+    float v = x[i] * sc + sh;
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = v;
+}
+
+// dx = w * invstd * (g' - sum_g / M - xhat * sum_gx / M),  g' = g * (y > 0 if relu);  M = elements per channel
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ w,
+                                                            const double* __restrict__ sums, float* __restrict__ dx, int C,
+                                                            long long N, long long total, double count, int relu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / N) % C);
+    float gv = g[i];
+    if (relu && !(y[i] > 0.f)) gv = 0.f;
+    const float xh = (x[i] - mean[c]) * invstd[c];
+    const float mg = (float)(sums[2 * c] / count), mgx = (float)(sums[2 * c + 1] / count);
+    dx[i] = (w ? w[c] : 1.f) * invstd[c] * (gv - mg - xh * mgx);
+}
+
+// ---- depthwise (1,3,3) `patch` convolution: weight gradient dW[c, kh, kw] = sum g[b,c,d,h,w] * x[b,c,d,h+kh-1,w+kw-1] ----------
+__global__ __launch_bounds__(256) void depthwise_patch_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                     float* __restrict__ dw, int C, int D, int H, int W,
+                                                                     int rows_per_block) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const long long base = ((long long)b * C + c) * D * H * W;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, D * H);
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const int d = r / H, h = r - d * H;
+        for (int w = threadIdx.x; w < W; w += 256) {
+            const float gv = g[base + ((long long)d * H + h) * W + w];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hh = h + kh - 1;
+                if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ww = w + kw - 1;
+                    if ((unsigned)ww < (unsigned)W) acc[kh * 3 + kw] += gv * x[base + ((long long)d * H + hh) * W + ww];
+                }
+            }
+        }
+    }
+    __shared__ float red[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v = acc[t];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[t][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) unsafeAtomicAdd(&dw[c * 9 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// ---- channelAtt gate out = sigmoid(a)[b,c,h,w] * cv[b,c,d,h,w]: d_a = s (1 - s) * sum_d g * cv ----------------------------------
+__global__ __launch_bounds__(256) void gate_bwd_logits_kernel(const float* __restrict__ g, const float* __restrict__ cv,
+                                                               const float* __restrict__ a, float* __restrict__ da, int D,
+                                                               long long plane, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // over [B*C, H*W]
+    if (i >= total) return;
+    const long long bc = i / plane, p = i - bc * plane;
+    const float* gp = g + bc * D * plane + p;
+    const float* cp = cv + bc * D * plane + p;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += gp[d * plane] * cp[d * plane];
+    const float sg = 1.0f / (1.0f + expf(-a[i]));
+    da[i] = sg * (1.0f - sg) * s;
+}
+
+// ---- windowed attention core, backward (models/submodule_other.py:805-834) ------------------------------------------------------
+// qkv [B,3C,D,H,W] (C = heads * 8), gy [B,C,D,H,W] = gradient of y = softmax(q k^T * scale) v per (window, head), un-partitioned.
+// -> gqkv [B,3C,D,H,W].  One workgroup per (window, head): q, k, v, gy tiles [T][8] and the probabilities [T][T] in LDS.
+// Unpadded volumes only (H % bh == 0, W % bw == 0: no pad tokens, no mask).
+template <int T>
+__global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ gy,
+                                                                         float* __restrict__ gqkv, int C, int D, int H, int W,
+                                                                         int heads, int bd, int bh, int bw, float scale) {
+    constexpr int HD = 8;
+    extern __shared__ __attribute__((aligned(16))) float sm_att[];          // 4 x [T][9] + 2 x [T][T + 1] floats (88 KB at T = 96)
+    float (*q)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(sm_att);
+    float (*k)[HD + 1] = q + T;
+    float (*v)[HD + 1] = k + T;
+    float (*go)[HD + 1] = v + T;
+    float (*P)[T + 1] = reinterpret_cast<float (*)[T + 1]>(sm_att + 4 * T * (HD + 1));
+    float (*dS)[T + 1] = P + T;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int nw = W / bw, nh = H / bh;
+    int win = blockIdx.x;
+    const int ww = win % nw; win /= nw;
+    const int wh = win % nh; win /= nh;
+    const int wd = win;
+    const long long plane = (long long)H * W, vol = (long long)D * plane;
+    auto pos = [&](int t) {                       // token t of the window -> flat spatial offset (d, h, w order as the partition)
+        const int tw = t % bw, th = (t / bw) % bh, td = t / (bw * bh);
+        return (long long)(wd * bd + td) * plane + (long long)(wh * bh + th) * W + (ww * bw + tw);
+    };
+    const float* qb = qkv + (long long)b * 3 * C * vol;
+    for (int e = threadIdx.x; e < T * HD; e += 256) {
+        const int t = e / HD, j = e % HD;
+        const long long p = pos(t);
+        const int ch = head * HD + j;
+        q[t][j] = qb[(long long)ch * vol + p];
+        k[t][j] = qb[(long long)(C + ch) * vol + p];
+        v[t][j] = qb[(long long)(2 * C + ch) * vol + p];
+        go[t][j] = gy[((long long)b * C + ch) * vol + p];
+    }
+    __syncthreads();
+    // P = softmax(q k^T * scale) row-wise; dP = go v^T
+    for (int e = threadIdx.x; e < T * T; e += 256) {
+        const int i = e / T, j = e % T;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { s += q[i][c] * k[j][c]; dp += go[i][c] * v[j][c]; }
+        P[i][j] = s * scale;
+        dS[i][j] = dp;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 256) {
+        float mx = -INFINITY;
+        for (int j = 0; j < T; ++j) mx = fmaxf(mx, P[i][j]);
+        float sum = 0.f;
+        for (int j = 0; j < T; ++j) { const float e_ = expf(P[i][j] - mx); P[i][j] = e_; sum += e_; }
+        float dot = 0.f;
+        for (int j = 0; j < T; ++j) { P[i][j] /= sum; dot += P[i][j] * dS[i][j]; }
+        for (int j = 0; j < T; ++j) dS[i][j] = P[i][j] * (dS[i][j] - dot) * scale;       // d(logits before scale)
+    }
+    __syncthreads();
+    float* gb = gqkv + (long long)b * 3 * C * vol;
+    for (int e = threadIdx.x; e < T * HD; e += 256) {
+        const int t = e / HD, c = e % HD;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < T; ++j) {
+            dq += dS[t][j] * k[j][c];
+            dk += dS[j][t] * q[j][c];
+            dv += P[j][t] * go[j][c];
+        }
+        const long long p = pos(t);
+        const int ch = head * HD + c;
+        gb[(long long)ch * vol + p] = dq;
+        gb[(long long)(C + ch) * vol + p] = dk;
+        gb[(long long)(2 * C + ch) * vol + p] = dv;
+    }
+}
+
+int reduce_grid(long long N, long long& per_block) {
+    long long blocks = (N + 16383) / 16384;                  // ~64 elements per thread
+    if (blocks > 65535) blocks = 65535;
+    per_block = (N + blocks - 1) / blocks;
+    return (int)blocks;
+}
+
+}  // namespace
+
+// BatchNorm with batch statistics (training, models/submodule_other.py:845-848 / models/submodule.py:89-116) + optional ReLU.
+// x [B,C,N] (N = D*H*W or H*W), weight / bias [C] (may be NULL) -> y, and mean / invstd / var_unbiased [C] for the backward and
+// the running statistics; work: 2*C doubles of scratch.
+extern "C" int ss_batchnorm_train_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean, float* invstd,
+                                      float* var_unbiased, double* work, int B, int C, long long N, float eps, int relu,
+                                      ss_stream_t stream) {
+    SS_REQUIRE(x && y && mean && invstd && var_unbiased && work && B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535);
+    hipStream_t st = ss::as_stream(stream);
+    if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
+    long long per_block;
+    const int gx = reduce_grid(N, per_block);
+    hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(gx, C, B), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, work, C, N, per_block, 0);
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ss::ceil_div(C, 64)), dim3(64), 0, st, work, mean, invstd, var_unbiased, C,
+                       (double)B * (double)N, eps);
+    const long long total = (long long)B * C * N;
+    const long long blocks = ss::ceil_div_ll(total, 256);
+    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, mean, invstd, weight, bias, y, C, N, total, relu);
+    return ss::check_launch();
+}
+
+// Its backward: grad_y, x, y (needed only with relu), mean, invstd, weight -> grad_x [B,C,N], grad_weight / grad_bias [C] as
+// doubles in work[2c + 1] / work[2c] (sum g' * xhat, sum g').
+extern "C" int ss_batchnorm_train_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                                      const float* weight, float* grad_x, double* work, int B, int C, long long N, int relu,
+                                      ss_stream_t stream) {
+    SS_REQUIRE(grad_y && x && mean && invstd && grad_x && work && B > 0 && C > 0 && N > 0 && (y || !relu) && C <= 65535 && B <= 65535);
+    hipStream_t st = ss::as_stream(stream);
+    if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
+    long long per_block;
+    const int gx = reduce_grid(N, per_block);
+    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(gx, C, B), dim3(256), 0, st, grad_y, x, y, mean, invstd, work, C, N, per_block, relu);
+    const long long total = (long long)B * C * N;
+    const long long blocks = ss::ceil_div_ll(total, 256);
+    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x, C,
+                       N, total, (double)B * (double)N, relu);
+    return ss::check_launch();
+}
+
+// sums[c] (double) = sum over batch and positions of a[b, c, :]  (bias gradients of the 1x1x1 projections)
+extern "C" int ss_channel_sum_fwd(const float* a, double* sums, int B, int C, long long N, ss_stream_t stream) {
+    SS_REQUIRE(a && sums && B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535);
+    hipStream_t st = ss::as_stream(stream);
+    if (hipMemsetAsync(sums, 0, (size_t)C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
+    long long per_block;
+    const int gx = reduce_grid(N, per_block);
+    hipLaunchKernelGGL(channel_reduce_kernel<2>, dim3(gx, C, B), dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, sums, C, N, per_block, 0);
+    return ss::check_launch();
+}
+
+// weight gradient of the depthwise `patch` Conv3d (kernel (1,3,3), padding (0,1,1), models/SemStereo.py:219): grad_w [C,1,1,3,3]
+extern "C" int ss_depthwise_patch_wgrad_fwd(const float* grad_out, const float* in, float* grad_w, int B, int C, int D, int H, int W,
+                                            ss_stream_t stream) {
+    SS_REQUIRE(grad_out && in && grad_w && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && B <= 65535);
+    hipStream_t st = ss::as_stream(stream);
+    if (hipMemsetAsync(grad_w, 0, (size_t)C * 9 * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    const int rows = D * H, rows_per_block = max(1, ss::ceil_div(rows, 64));
+    hipLaunchKernelGGL(depthwise_patch_wgrad_kernel, dim3(ss::ceil_div(rows, rows_per_block), C, B), dim3(256), 0, st, grad_out, in, grad_w,
+                       C, D, H, W, rows_per_block);
+    return ss::check_launch();
+}
+
+// channelAtt gate (models/SemStereo.py:101-102), gradient of the logits: grad_att [B,C,H,W] = s (1 - s) * sum_d grad_out * cv
+extern "C" int ss_channel_gate_bwd_logits(const float* grad_out, const float* cv, const float* att_logits, float* grad_att, int B, int C,
+                                          int D, int H, int W, ss_stream_t stream) {
+    SS_REQUIRE(grad_out && cv && att_logits && grad_att && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+    const long long plane = (long long)H * W, total = (long long)B * C * plane;
+    const long long blocks = ss::ceil_div_ll(total, 256);
+    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gate_bwd_logits_kernel, dim3((unsigned)blocks), dim3(256), 0, ss::as_stream(stream), grad_out, cv, att_logits,
+                       grad_att, D, plane, total);
+    return ss::check_launch();
+}
+
+// Backward of ss_window_attention_core_fwd for volumes whose H, W are multiples of the window (no pad tokens):
+// qkv [B,3C,D,H,W], grad_y [B,C,D,H,W] -> grad_qkv [B,3C,D,H,W].  Windows of 64 or 96 tokens, 8 channels per head.
+extern "C" int ss_window_attention_core_bwd(const float* qkv, const float* grad_y, float* grad_qkv, int B, int C, int D, int H, int W,
+                                            int heads, int bd, int bh, int bw, ss_stream_t stream) {
+    SS_REQUIRE(qkv && grad_y && grad_qkv && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && heads > 0 && bd > 0 && bh > 0 && bw > 0);
+    if (C != heads * 8 || D % bd || H % bh || W % bw || B > 65535 || heads > 65535) return SS_ERR_UNSUPPORTED;
+    const int T = bd * bh * bw;
+    const long long windows = (long long)(D / bd) * (H / bh) * (W / bw);
+    if (windows > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    const float scale = 1.0f / sqrtf(8.0f);
+    hipStream_t st = ss::as_stream(stream);
+    const dim3 grid((unsigned)windows, heads, B);
+    const size_t lds = (size_t)(4 * T * 9 + 2 * T * (T + 1)) * sizeof(float);
+    if (T == 64) {
+        auto kern = window_attention_core_bwd_kernel<64>;
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, qkv, grad_y, grad_qkv, C, D, H, W, heads, bd, bh, bw, scale);
+    } else if (T == 96) {
+        auto kern = window_attention_core_bwd_kernel<96>;
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, qkv, grad_y, grad_qkv, C, D, H, W, heads, bd, bh, bw, scale);
+    } else {
+        return SS_ERR_UNSUPPORTED;
+    }
+    return ss::check_launch();
+}

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from . import deferred as dfr
+from . import train as T
 from ._lib import call, ptr
 
 PATH_COUNTS = {"hip": 0, "torch": 0}
@@ -437,6 +438,8 @@ def conv3d_wgrad_hip(grad_out, x, Cout, Cin, stride):
 
 def _conv_k3_forward(x, w, stride):
     """Conv3d(k3, p1, stride, no bias) on the selected engine, weights packed on the fly (they change every step)."""
+    if CONV_ENGINE != "f32" and w.shape[0] == 1 and stride == 1 and w.shape[1] in (16, 32, 64):
+        return conv3d_head_bf16s_hip(x, pack_head_weight_bf16s(w), None, None, False, _aux_nterms())      # the 32 -> 1 classifier heads
     if CONV_ENGINE == "f32":
         return conv3d_hip(x, pack_conv_weight(w), None, None, 3, stride, False)
     nterms = _tiled_nterms()
@@ -512,10 +515,13 @@ def _is_k3(conv, stride_ok=(1, 2)):
 def conv3d_train(conv, x):
     """nn.Conv3d's forward for the training path: the HIP autograd function for 3x3x3 layers on the GPU (stride 2 needs even
     sizes: its data gradient is the k3-s2-p1-op1 transposed convolution), the stock layer otherwise."""
-    if (TRAIN_HIP and x.is_cuda and x.dtype == torch.float32 and isinstance(conv, nn.Conv3d) and _is_k3(conv) and conv.out_channels > 1
+    if (TRAIN_HIP and x.is_cuda and x.dtype == torch.float32 and isinstance(conv, nn.Conv3d) and _is_k3(conv)
             and (conv.stride[0] == 1 or all(n % 2 == 0 for n in x.shape[2:]))):
         PATH_COUNTS["hip_train"] = PATH_COUNTS.get("hip_train", 0) + 1
         return _Conv3dK3.apply(x, conv.weight, conv.stride[0])
+    if isinstance(conv, (nn.Conv3d, nn.Conv2d)) and T.is_k1(conv):
+        return T.conv_k1(x, conv.weight, conv.bias)                       # redir1 / redir2, channelAtt.im_att (counts its own path)
+    PATH_COUNTS["torch"] += 1
     return conv(x)
 
 
@@ -525,6 +531,7 @@ def deconv3d_train(deconv, x):
             and deconv.dilation == (1, 1, 1) and deconv.groups == 1 and deconv.bias is None):
         PATH_COUNTS["hip_train"] = PATH_COUNTS.get("hip_train", 0) + 1
         return _Deconv3dK3.apply(x, deconv.weight)
+    PATH_COUNTS["torch"] += 1
     return deconv(x)
 
 
@@ -540,8 +547,12 @@ class _ConvBN3d(nn.Sequential):
         if _inference(self, x):
             PATH_COUNTS["hip"] += 1
             return run_convbn(self, "cb", self[0], self[1], x, relu=False)
-        PATH_COUNTS["torch"] += 1
-        return self[1](conv3d_train(self[0], x))          # conv: HIP forward / dgrad / wgrad; BatchNorm (batch statistics): PyTorch
+        return self.train_forward(x)
+
+    def train_forward(self, x, relu=False):
+        """conv -> BatchNorm with batch statistics [-> ReLU]: HIP forward / dgrad / wgrad kernels (train.py); each helper counts
+        the path it took."""
+        return T.batchnorm_train(self[1], conv3d_train(self[0], x), relu=relu)
 
 
 def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
@@ -596,19 +607,24 @@ class BasicConv(nn.Module):
             return run_convbn(self, "bc", self.conv, self.bn if self.use_bn else None, x, relu=bool(self.relu), gate=g)
         if gate is not None:
             assert gate_logits is None
-        if self.is_3d:
-            PATH_COUNTS["torch"] += 1
-        elif not self.deconv and gate_logits is None and gate is None and _inference(self, x):
+        if not self.is_3d and not self.deconv and gate_logits is None and gate is None and _inference(self, x):
             y = run_conv2d(self, "bc2d", self.conv, self.bn if self.use_bn else None, x, bool(self.relu))
             if y is not None:
                 return y
-        x = conv3d_train(self.conv, x) if (self.is_3d and not self.deconv) else self.conv(x)
+        # training / autograd: HIP autograd functions (train.py) where they apply, each counting the path it took
+        if self.deconv:
+            PATH_COUNTS["torch"] += 1
+            x = self.conv(x)
+        elif self.is_3d or T.is_k1(self.conv):
+            x = conv3d_train(self.conv, x)
+        else:
+            x = T.conv2d_k3(self.conv, x)
         if self.use_bn:
-            x = self.bn(x)
-        if self.relu:
+            x = T.batchnorm_train(self.bn, x, relu=bool(self.relu)) if self.bn.training else (F.relu(self.bn(x)) if self.relu else self.bn(x))
+        elif self.relu:
             x = F.relu(x)
         if gate_logits is not None:
-            x = torch.sigmoid(gate_logits).unsqueeze(2) * x
+            x = T.channel_gate(gate_logits, x)
         if gate is not None:
             x = gate.unsqueeze(2) * x
         return x
@@ -640,7 +656,9 @@ class ConcatFeature(nn.Sequential):
             if y is not None:
                 z = run_conv2d(self, "cf1", b, None, y, False)
                 return z if z is not None else b(y)
-        return super().forward(x)
+        if _inference(self, x):
+            return super().forward(x)
+        return T.conv2d_k3(b, a(x))                               # training: BasicConv's own training path, then the 3x3 Conv2d
 
 
 STEM_LEFT_FUSED = os.environ.get("SS_STEM_LEFT_FUSED", "1") != "0"     # Q of the broadcast half on the fly (one launch) or through HBM (two)
@@ -815,6 +833,8 @@ class attention_block(nn.Module):
                 call("ss_window_attention_fwd", ptr(x), ptr(wq), ptr(bq), ptr(wo), ptr(bo), ptr(out),
                      B, C, D, H, W, self.num_heads, self.block[0], self.block[1], self.block[2])
             return out
+        if not _inference(self, x) and self.hip_supported() and T.window_attention_applies(x, self.num_heads, self.block):
+            return T.window_attention(x, self.qkv_3d, self.final1x1, self.num_heads, self.block)
         PATH_COUNTS["torch"] += 1
         return self._forward_torch(x)
 
@@ -900,13 +920,15 @@ class hourglass(nn.Module):
     def forward(self, x):
         x = dfr.real(x)
         if not _inference(self, x):
-            PATH_COUNTS["torch"] += 1
-            conv1 = self.conv1(x)
-            conv2 = self.conv2(conv1)
-            conv3 = self.conv3(conv2)
-            conv4 = self.attention_block(self.conv4(conv3))
-            conv5 = F.relu(self.conv5[1](deconv3d_train(self.conv5[0], conv4)) + self.redir2(conv2))
-            return F.relu(self.conv6[1](deconv3d_train(self.conv6[0], conv5)) + self.redir1(x))
+            def cbr(seq, t):                       # nn.Sequential(convbn_3d, ReLU): conv -> BatchNorm (batch statistics) -> ReLU fused
+                cb = seq[0]
+                return cb.train_forward(t, relu=True) if isinstance(cb, _ConvBN3d) and cb[1].training else seq(t)
+            conv1 = cbr(self.conv1, x)
+            conv2 = cbr(self.conv2, conv1)
+            conv3 = cbr(self.conv3, conv2)
+            conv4 = self.attention_block(cbr(self.conv4, conv3))
+            conv5 = F.relu(T.batchnorm_train(self.conv5[1], deconv3d_train(self.conv5[0], conv4)) + self.redir2(conv2))
+            return F.relu(T.batchnorm_train(self.conv6[1], deconv3d_train(self.conv6[0], conv5)) + self.redir1(x))
         PATH_COUNTS["hip"] += 1
         c1 = run_convbn(self, "c1", self.conv1[0][0], self.conv1[0][1], x, relu=True)
         c2 = run_convbn(self, "c2", self.conv2[0][0], self.conv2[0][1], c1, relu=True)
@@ -959,8 +981,10 @@ class Classifier(nn.Sequential):
                 return classifier_cl_hip(x, ws0, sc, sh, nt0, ws2, nt2)
             y = run_convbn(self, "h0", c0, bn0, x, relu=True)
             return run_convbn(self, "h2", c2, None, y, relu=False)
-        PATH_COUNTS["torch"] += 1
-        return super().forward(x)
+        cb = self[0]
+        if isinstance(cb, _ConvBN3d) and cb[1].training:
+            return conv3d_train(self[2], cb.train_forward(x, relu=True))            # conv -> BN (batch statistics) -> ReLU -> 32 -> 1 conv
+        return conv3d_train(self[2], F.relu(cb(x)))
 
 
 _PROP_TAPS = ((-1, -1), (0, 0), (1, 1), (1, -1), (-1, 1))    # models/submodule.py:295-300 / 367-372
@@ -1039,9 +1063,8 @@ class DepthwisePatch(nn.Conv3d):
             with torch.cuda.device(dev):
                 call("ss_depthwise_patch_fwd", ptr(x), ptr(w), ptr(g), ptr(out), B, C, D, H, W)
             return out
-        PATH_COUNTS["torch"] += 1
-        y = super().forward(x)
-        return y if gate_logits is None else torch.sigmoid(gate_logits).unsqueeze(2) * y
+        y = T.depthwise_patch(self, x)
+        return y if gate_logits is None else T.channel_gate(gate_logits, y)
 
 
 class channelAtt(nn.Module):
@@ -1117,8 +1140,9 @@ class channelAtt(nn.Module):
         if _inference(self, cv, im):
             PATH_COUNTS["hip"] += 1
             return ops.channel_gate(self.logits(im), cv)
-        PATH_COUNTS["torch"] += 1
-        return torch.sigmoid(self.im_att(im).unsqueeze(2)) * cv
+        a, b = self.im_att[0], self.im_att[1]
+        att = conv3d_train(b, a(im)) if isinstance(b, nn.Conv2d) and T.is_k1(b) else self.im_att(im)
+        return T.channel_gate(att, cv)
 
 
 class SSR_upsample(nn.Module):

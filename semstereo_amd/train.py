@@ -1,0 +1,307 @@
+"""Training side of the 3-D aggregation stack on the HIP kernels (main_us3d.py:186-222 back-propagates through every
+module of models/SemStereo.py:273-323): torch.autograd.Function wrappers whose forward AND backward are this repo's
+kernels, for what the 3x3x3 conv / transposed-conv functions of modules.py (`_Conv3dK3`, `_Deconv3dK3`) leave over:
+
+  batchnorm_train      BatchNorm2d / 3d with BATCH statistics (+ fused ReLU)     convbn_3d, BasicConv in train()
+  conv_k1              1x1(x1) convolutions with optional bias                    redir1/2, attention_block.qkv_3d / final1x1,
+                                                                                  channelAtt.im_att
+  conv2d_k3            3x3 Conv2d                                                 concat_feature
+  depthwise_patch      the depthwise (1,3,3) `patch` Conv3d                       models/SemStereo.py:219
+  channel_gate         sigmoid(att)[:, :, None] * cv                              channelAtt, models/SemStereo.py:101-102
+  window_attention     the windowed attention core                                models/submodule_other.py:805-834
+
+Each falls back to the stock PyTorch layer (and counts it in modules.PATH_COUNTS["torch"]) for shapes the kernels are not
+built for.  `modules.TRAIN_HIP = False` (SS_TRAIN_HIP=0) sends everything to PyTorch.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import call, ptr
+
+
+def _M():
+    from . import modules
+    return modules
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _on(x):
+    return _M().TRAIN_HIP and x.is_cuda and x.dtype == torch.float32
+
+
+def _count(kind):
+    pc = _M().PATH_COUNTS
+    pc[kind] = pc.get(kind, 0) + 1
+
+
+# ---- BatchNorm with batch statistics (+ ReLU) ---------------------------------------------------------------------------------
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        x = _c(x)
+        B, C = x.shape[0], x.shape[1]
+        N = x[0, 0].numel()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd, var_u = torch.empty_like(mean), torch.empty_like(mean)
+        work = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            call("ss_batchnorm_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd), ptr(var_u), ptr(work),
+                 B, C, N, float(eps), int(relu))
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
+        ctx.relu, ctx.has_bias = bool(relu), bias is not None
+        ctx.mark_non_differentiable(mean, var_u)
+        return y, mean, var_u
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        x, y, mean, invstd, weight = ctx.saved_tensors
+        g = _c(g)
+        B, C = x.shape[0], x.shape[1]
+        N = x[0, 0].numel()
+        gx = torch.empty_like(x)
+        work = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            call("ss_batchnorm_train_bwd", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(work), B, C, N,
+                 int(ctx.relu))
+        sums = work.reshape(C, 2)
+        gw = sums[:, 1].float() if weight is not None else None
+        gb = sums[:, 0].float() if ctx.has_bias else None
+        return gx, gw, gb, None, None
+
+
+def batchnorm_train(bn, x, relu=False):
+    """bn(x) [-> ReLU] for a BatchNorm2d / 3d in train(): batch statistics, running statistics updated as F.batch_norm does."""
+    if not (_on(x) and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training and x.shape[1] <= 65535):
+        _count("torch")
+        y = bn(x)
+        return F.relu(y) if relu else y
+    _count("hip_train")
+    y, mean, var_u = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1.0 - m).add_(var_u, alpha=m)
+    return y
+
+
+# ---- 1x1(x1) convolutions -----------------------------------------------------------------------------------------------------
+
+def _as5d(x):
+    return x if x.dim() == 5 else x.unsqueeze(2)             # [B,C,H,W] -> [B,C,1,H,W]
+
+
+def _k1_forward(x5, w2d, bias):
+    """y[b,co,pos] = sum_ci w[co,ci] * x[b,ci,pos] (+ bias) on the exact-fp32 matrix-core kernel (ss_conv3d_fwd, k = 1)."""
+    M = _M()
+    wp = M.pack_conv_weight(w2d.reshape(w2d.shape[0], w2d.shape[1], 1, 1, 1))
+    return M.conv3d_hip(x5, wp, None, None if bias is None else _c(bias.detach().float()), 1, 1, False)
+
+
+class _ConvK1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x5 = _c(_as5d(x))
+        w2d = w.detach().reshape(w.shape[0], w.shape[1])
+        ctx.save_for_backward(x5, w)
+        ctx.was4d, ctx.has_bias = x.dim() == 4, bias is not None
+        y = _k1_forward(x5, w2d, bias)
+        return y.squeeze(2) if ctx.was4d else y
+
+    @staticmethod
+    def backward(ctx, g):
+        x5, w = ctx.saved_tensors
+        M = _M()
+        g5 = _c(_as5d(g))
+        Cout, Cin = w.shape[0], w.shape[1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _k1_forward(g5, w.detach().reshape(Cout, Cin).t().contiguous(), None)
+            gx = gx.squeeze(2) if ctx.was4d else gx
+        if ctx.needs_input_grad[1]:
+            # the 3x3x3 weight-gradient kernel on the same tensors: its centre tap is the 1x1x1 gradient
+            gw = M.conv3d_wgrad_hip(g5, x5, Cout, Cin, 1)[:, :, 1, 1, 1].reshape(w.shape).contiguous()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            sums = torch.empty(Cout, dtype=torch.float64, device=g5.device)
+            with torch.cuda.device(g5.device):
+                call("ss_channel_sum_fwd", ptr(g5), ptr(sums), g5.shape[0], Cout, g5[0, 0].numel())
+            gb = sums.float()
+        return gx, gw, gb
+
+
+def conv_k1(x, weight, bias=None):
+    """1x1 Conv2d / 1x1x1 Conv3d / Linear over the channel axis of [B,C,*spatial]."""
+    if _on(x) and x.dim() in (4, 5):
+        _count("hip_train")
+        return _ConvK1.apply(x, weight, bias)
+    _count("torch")
+    w = weight.reshape(weight.shape[0], weight.shape[1], *([1] * (x.dim() - 2)))
+    return (F.conv3d if x.dim() == 5 else F.conv2d)(x, w, bias)
+
+
+def is_k1(conv):
+    k = conv.kernel_size
+    return (all(v == 1 for v in k) and all(v == 1 for v in conv.stride) and all(v == 0 for v in conv.padding) and conv.groups == 1
+            and all(v == 1 for v in conv.dilation))
+
+
+# ---- 3x3 Conv2d (concat_feature) ----------------------------------------------------------------------------------------------
+
+class _Conv2dK3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        M = _M()
+        x = _c(x)
+        ctx.save_for_backward(x, w)
+        nt = M._tiled_nterms() if M.CONV_ENGINE != "f32" else 6
+        return M.conv2d_bf16s_hip(x, M.pack_conv2d_weight_bf16s(w.detach(), nt), w.shape[0], None, None, False, nt)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        M = _M()
+        g = _c(g)
+        gx = gw = None
+        nt = M._tiled_nterms() if M.CONV_ENGINE != "f32" else 6
+        if ctx.needs_input_grad[0]:
+            wt = w.detach().transpose(0, 1).flip(2, 3).contiguous()
+            gx = M.conv2d_bf16s_hip(g, M.pack_conv2d_weight_bf16s(wt, nt), w.shape[1], None, None, False, nt)
+        if ctx.needs_input_grad[1]:
+            # depth-1 volumes through the 3x3x3 weight-gradient kernel: its kd = 1 plane is the 3x3 gradient
+            gw = M.conv3d_wgrad_hip(g.unsqueeze(2), x.unsqueeze(2), w.shape[0], w.shape[1], 1)[:, :, 1].contiguous()
+        return gx, gw
+
+
+def conv2d_k3(conv, x):
+    M = _M()
+    if _on(x) and M._is_plain_3x3(conv):
+        _count("hip_train")
+        return _Conv2dK3.apply(x, conv.weight)
+    _count("torch")
+    return conv(x)
+
+
+# ---- depthwise `patch` --------------------------------------------------------------------------------------------------------
+
+def _patch_forward(x, w):
+    x = _c(x)
+    B, C, D, H, W = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        call("ss_depthwise_patch_fwd", ptr(x), ptr(_c(w)), None, ptr(out), B, C, D, H, W)
+    return out
+
+
+class _DepthwisePatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _c(x)
+        ctx.save_for_backward(x, w)
+        return _patch_forward(x, w.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _c(g)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _patch_forward(g, w.detach().flip(3, 4).contiguous())          # correlation with the flipped 3x3 taps
+        if ctx.needs_input_grad[1]:
+            B, C, D, H, W = x.shape
+            gw = torch.empty_like(w)
+            with torch.cuda.device(x.device):
+                call("ss_depthwise_patch_wgrad_fwd", ptr(g), ptr(x), ptr(gw), B, C, D, H, W)
+        return gx, gw
+
+
+def depthwise_patch(conv, x):
+    if _on(x) and x.dim() == 5:
+        _count("hip_train")
+        return _DepthwisePatch.apply(x, conv.weight)
+    _count("torch")
+    return nn.Conv3d.forward(conv, x)
+
+
+# ---- channelAtt gate ----------------------------------------------------------------------------------------------------------
+
+class _ChannelGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att, cv):
+        from . import ops
+        att, cv = _c(att), _c(cv)
+        ctx.save_for_backward(att, cv)
+        return ops.channel_gate(att, cv)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        att, cv = ctx.saved_tensors
+        g = _c(g)
+        ga = gc = None
+        if ctx.needs_input_grad[0]:
+            B, C, D, H, W = cv.shape
+            ga = torch.empty_like(att)
+            with torch.cuda.device(cv.device):
+                call("ss_channel_gate_bwd_logits", ptr(g), ptr(cv), ptr(att), ptr(ga), B, C, D, H, W)
+        if ctx.needs_input_grad[1]:
+            gc = ops.channel_gate(att, g)
+        return ga, gc
+
+
+def channel_gate(att_logits, cv):
+    if _on(cv):
+        _count("hip_train")
+        return _ChannelGate.apply(att_logits, cv)
+    _count("torch")
+    return torch.sigmoid(att_logits).unsqueeze(2) * cv
+
+
+# ---- windowed attention core --------------------------------------------------------------------------------------------------
+
+class _WindowAttentionCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bqkv, heads, block):
+        qkv = _c(qkv)
+        B, C3, D, H, W = qkv.shape
+        C = C3 // 3
+        y = torch.empty((B, C, D, H, W), dtype=qkv.dtype, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            call("ss_window_attention_core_fwd", ptr(qkv), ptr(_c(bqkv.detach().float())), ptr(y), B, C, D, H, W, heads, block[0], block[1], block[2])
+        ctx.save_for_backward(qkv)
+        ctx.cfg = (heads, tuple(block))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (qkv,) = ctx.saved_tensors
+        heads, block = ctx.cfg
+        g = _c(g)
+        B, C3, D, H, W = qkv.shape
+        gq = torch.empty_like(qkv)
+        with torch.cuda.device(qkv.device):
+            call("ss_window_attention_core_bwd", ptr(qkv), ptr(g), ptr(gq), B, C3 // 3, D, H, W, heads, block[0], block[1], block[2])
+        return gq, None, None, None
+
+
+def window_attention_applies(x, heads, block):
+    B, C, D, H, W = x.shape
+    return (_on(x) and C == heads * 8 and D % block[0] == 0 and H % block[1] == 0 and W % block[2] == 0
+            and block[0] * block[1] * block[2] in (64, 96))
+
+
+def window_attention(x, qkv_linear, final_conv, heads, block):
+    """attention_block.forward (models/submodule_other.py:790-837) for volumes whose H, W are multiples of the window: the
+    qkv projection and final1x1 as 1x1x1 convolutions with bias, the attention core per (window, head)."""
+    _count("hip_train")
+    qkv = conv_k1(x, qkv_linear.weight, qkv_linear.bias)
+    y = _WindowAttentionCore.apply(qkv, qkv_linear.bias, heads, tuple(block))
+    return conv_k1(y, final_conv.weight, final_conv.bias)

@@ -1419,36 +1419,140 @@ def test_deconv3d_training_forward_dgrad_wgrad_in_hip(sa, case):
     assert e_y <= 2e-6 and e_x <= 2e-6 and e_w <= 5e-6, (e_y, e_x, e_w)
 
 
+def _rel(a, ref):
+    return float((a.double().cpu() - ref.double().cpu()).abs().max()) / (float(ref.double().abs().max()) + 1e-30)
+
+
+def test_training_kernels_vs_float64_autograd(sa):
+    """semstereo_amd/train.py: every HIP autograd function (forward AND backward kernels) against the float64 CPU autograd of
+    the PyTorch op it replaces -- BatchNorm with batch statistics (+ ReLU, running statistics), 1x1(x1) convolutions with and
+    without bias on 4-D and 5-D tensors, the 3x3 Conv2d, the depthwise `patch`, the channelAtt gate, the windowed attention
+    block (both window shapes of the model)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    T = sa.train
+    before = dict(sa.modules.PATH_COUNTS)
+
+    def run(fn_hip, fn_ref, inputs, tol, name):
+        hip_in = [dev(t).clone().requires_grad_(True) for t in inputs]
+        ref_in = [t.double().clone().requires_grad_(True) for t in inputs]
+        y, yr = fn_hip(*hip_in), fn_ref(*ref_in)
+        REPORT[f"train/{name}/fwd"] = _rel(y, yr)
+        assert _rel(y, yr) <= tol, (name, "forward", _rel(y, yr))
+        go = dd.t_normalish(tuple(yr.shape), 777)
+        y.backward(dev(go)); yr.backward(go.double())
+        for i, (a_, r_) in enumerate(zip(hip_in, ref_in)):
+            e = _rel(a_.grad, r_.grad)
+            REPORT[f"train/{name}/grad{i}"] = e
+            assert e <= tol, (name, "grad of input", i, e)
+
+    # BatchNorm3d / 2d, batch statistics, with and without ReLU
+    for relu, shape in ((True, (2, 8, 3, 5, 7)), (False, (3, 4, 6, 9)), (True, (1, 32, 4, 16, 20))):
+        C = shape[1]
+        bn = (nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d)(C).cuda().train()
+        bnr = (nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d)(C).double().train()
+
+        def hip(x, w, b_):
+            bn.weight, bn.bias = nn.Parameter(w.detach()), nn.Parameter(b_.detach())
+            y_ = T._BatchNormTrain.apply(x, w, b_, bn.eps, relu)[0]
+            return y_
+
+        def ref(x, w, b_):
+            y_ = F.batch_norm(x, None, None, w, b_, True, 0.0, bnr.eps)
+            return F.relu(y_) if relu else y_
+        run(hip, ref, [dd.t_normalish(shape, 701) * 2 + 0.3, dd.t_uniform((C,), 702, 0.5, 1.5), dd.t_uniform((C,), 703, -0.3, 0.3)], 2e-5, f"bn{shape}{relu}")
+        x = dev(dd.t_normalish(shape, 704))
+        y = T.batchnorm_train(bn, x, relu)                         # running statistics as F.batch_norm updates them
+        bn2 = (nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d)(C).cuda().train()
+        bn2(x)
+        assert _rel(bn.running_mean, bn2.running_mean) <= 1e-5 and _rel(bn.running_var, bn2.running_var) <= 1e-5
+        assert int(bn.num_batches_tracked) == 1
+    # 1x1 convolutions: redir (32 -> 32, no bias, 5-D), qkv (128 -> 384, bias), im_att (256 -> 128 on a 2-D map, bias)
+    for (cin, cout, shp, bias) in ((32, 32, (2, 3, 6, 9), False), (128, 384, (1, 4, 8, 8), True), (256, 128, (2, 12, 20), True), (64, 32, (1, 7, 5), True)):
+        ins = [dd.t_normalish((shp[0], cin) + shp[1:], 711), dd.t_uniform((cout, cin) + (1,) * (len(shp) - 1), 712, -0.2, 0.2)]
+        if bias:
+            ins.append(dd.t_uniform((cout,), 713, -0.5, 0.5))
+        conv = F.conv3d if len(shp) == 4 else F.conv2d
+        run(lambda x, w, b_=None: T.conv_k1(x, w, b_), lambda x, w, b_=None: conv(x, w, b_), ins, 2e-5, f"k1_{cin}_{cout}_{len(shp)}")
+    # 3x3 Conv2d (concat_feature)
+    c2 = nn.Conv2d(16, 24, 3, 1, 1, bias=False).cuda()
+    run(lambda x, w: T._Conv2dK3.apply(x, w), lambda x, w: F.conv2d(x, w, None, 1, 1), [dd.t_normalish((2, 16, 9, 37), 721), dd.t_uniform((24, 16, 3, 3), 722, -0.2, 0.2)],
+        2e-5, "conv2d_k3")
+    assert sa.modules._is_plain_3x3(c2)
+    # depthwise patch
+    run(lambda x, w: T._DepthwisePatch.apply(x, w), lambda x, w: F.conv3d(x, w, None, 1, (0, 1, 1), 1, 8),
+        [dd.t_normalish((2, 8, 5, 9, 12), 731), dd.t_uniform((8, 1, 1, 3, 3), 732, -1, 1)], 2e-5, "patch")
+    # channelAtt gate
+    run(lambda a_, cv: T._ChannelGate.apply(a_, cv), lambda a_, cv: torch.sigmoid(a_).unsqueeze(2) * cv,
+        [dd.t_normalish((2, 8, 6, 10), 741), dd.t_normalish((2, 8, 4, 6, 10), 742)], 2e-5, "gate")
+    # attention block, both window shapes
+    for blk, shape in (((4, 4, 4), (1, 128, 8, 8, 12)), ((6, 4, 4), (2, 128, 6, 8, 8))):
+        ab = sa.modules.attention_block(128, 16, blk)
+        with torch.no_grad():
+            for i, p_ in enumerate(ab.parameters()):
+                p_.copy_(dd.t_uniform(tuple(p_.shape), 750 + i, -0.1, 0.1))
+        abr = __import__("copy").deepcopy(ab).double()
+        ab = ab.cuda().train()
+        x = dd.t_normalish(shape, 760)
+        xh, xr = dev(x).requires_grad_(True), x.double().requires_grad_(True)
+        assert T.window_attention_applies(xh, 16, blk)
+        y, yr = ab(xh), abr._forward_torch(xr)
+        assert _rel(y, yr) <= 2e-5, _rel(y, yr)
+        go = dd.t_normalish(shape, 761)
+        y.backward(dev(go)); yr.backward(go.double())
+        assert _rel(xh.grad, xr.grad) <= 5e-5, _rel(xh.grad, xr.grad)
+        for (n_, p_), (_, pr_) in zip(ab.named_parameters(), abr.named_parameters()):
+            REPORT[f"train/attention{blk}/{n_}"] = _rel(p_.grad, pr_.grad)
+            assert _rel(p_.grad, pr_.grad) <= 5e-5, (n_, _rel(p_.grad, pr_.grad))
+    assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "a PyTorch layer ran inside the HIP training functions"
+
+
 def test_hot_segment_training_step_runs_on_the_hip_stack(sa):
     """A training-mode pass of the hot segment (BatchNorm with batch statistics, autograd on: main_us3d.py:186-222): every
-    3x3x3 convolution and transposed convolution runs the HIP autograd functions, every parameter receives a finite
-    gradient, and the gradients agree with the same pass on the stock PyTorch layers (SS_TRAIN_HIP=0)."""
+    module of the 3-D stack runs HIP autograd functions (no PyTorch layer: PATH_COUNTS["torch"] does not move), every
+    parameter receives a finite gradient, and the gradients agree with the ORACLE's -- the functional restatement of the
+    graph (oracle/hot_segment.py) in training mode, float64, CPU autograd."""
     if sa.modules.CONV_ENGINE == "bf16x3":
         pytest.skip("SS_CONV_ENGINE=bf16x3: this bound is for the fp32-accurate engines")
     name = "s128"
     fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
-    grads = {}
-    for hip in (True, False):
-        seg, P = _segment(sa, maxdisp)
-        seg.train()
-        sa.modules.TRAIN_HIP = hip
-        try:
-            before = sa.modules.PATH_COUNTS.get("hip_train", 0)
-            r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
-            n = sa.modules.PATH_COUNTS.get("hip_train", 0) - before
-            assert (n == 15) if hip else (n == 0), n       # 2 hourglasses x (4 convs + 2 transposed convs) + concat_stem + 2 classifier convs
-            (r["pred"].mean() + r["pred_att"].mean()).backward()
-        finally:
-            sa.modules.TRAIN_HIP = True
-        grads[hip] = {k: v.grad.detach().clone() for k, v in seg.named_parameters() if v.grad is not None}
-    assert set(grads[True]) == set(grads[False]) and len(grads[True]) > 60
-    worst = 0.0
-    for k, g in grads[True].items():
-        assert bool(torch.isfinite(g).all()), k
-        ref = grads[False][k]
-        worst = max(worst, float((g - ref).abs().max()) / (float(ref.abs().max()) + 1e-12))
-    REPORT["segment_train/worst_relative_grad_diff"] = worst
-    assert worst <= 5e-3, worst           # top-k picks and batch statistics amplify fp32 rounding; typical 1e-5
+    seg, P = _segment(sa, maxdisp)
+    seg.train()
+    before = dict(sa.modules.PATH_COUNTS)
+    r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
+    assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "a PyTorch layer ran in the training pass of the 3-D stack"
+    assert sa.modules.PATH_COUNTS.get("hip_train", 0) - before.get("hip_train", 0) >= 60
+    (r["pred"].mean() + r["pred_att"].mean()).backward()
+    grads = {k: v.grad.detach().cpu() for k, v in seg.named_parameters() if v.grad is not None}
+    assert len(grads) > 60 and all(bool(torch.isfinite(g_).all()) for g_ in grads.values())
+    # the oracle: same parameters, float64, CPU autograd, BatchNorm on batch statistics
+    P64 = {k: v.double().clone().requires_grad_(v.is_floating_point() and not k.endswith(("running_mean", "running_var"))) for k, v in P.items()}
+    with ostack.training_mode():
+        att, smp, pred_att = oseg.attention_branch(P64, fl8.double(), fr8.double(), fl4.double(), fr4.double(), maxdisp)
+        pred = oseg.matching_branch(P64, fl4.double(), fr4.double(), att, smp)
+    (pred.mean() + pred_att.mean()).backward()
+    same = (r["samples"].detach().cpu().double() == smp).all(dim=1)
+    REPORT["segment_train/pixels_with_the_oracles_candidates"] = float(same.double().mean())
+    errs = {}
+    for k, g_ in grads.items():
+        ref = P64[k].grad
+        assert ref is not None, k
+        errs[k] = float((g_.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+    # gamma / beta (models/SemStereo.py:204-205) are scalars whose gradient is a sum of signed per-pixel contributions through the
+    # 5-candidate probe that nearly cancel: held to the scale of the other gradients instead of to their own magnitude
+    gscale = max(float(P64[k].grad.abs().max()) for k in grads)
+    for k in ("gamma", "beta"):
+        REPORT[f"segment_train/{k}_grad"] = [float(grads[k].reshape(-1)[0]), float(P64[k].grad.reshape(-1)[0])]
+        assert float((grads[k].double() - P64[k].grad).abs().max()) <= 1e-4 * gscale, (k, grads[k], P64[k].grad, gscale)
+        errs.pop(k)
+    worst = max(errs.values())
+    med = sorted(errs.values())[len(errs) // 2]
+    REPORT["segment_train/worst_relative_grad_diff_vs_oracle_f64"] = worst
+    REPORT["segment_train/median_relative_grad_diff_vs_oracle_f64"] = med
+    # batch statistics over 8 x 8 x 8 voxels at the coarsest level and the hard top-24 / top-2 picks amplify fp32 rounding:
+    # typical 1e-5, worst parameter a few 1e-4
+    assert med <= 1e-4 and worst <= 5e-3, (med, worst, max(errs, key=errs.get))
 
 
 # --------------------------------------------------------------------------------------
