@@ -204,8 +204,11 @@ def launch_ranks(n, argv):
     signal.signal(signal.SIGTERM, end_ranks)
     signal.signal(signal.SIGINT, end_ranks)
 
+    launch_ranks.relayed = 0
+
     def relay():
         for line in procs[0].stdout:
+            launch_ranks.relayed += 1
             sys.stdout.write(line)
             sys.stdout.flush()
     t = threading.Thread(target=relay, daemon=True)
@@ -303,8 +306,14 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher: become the parent of N ranks BEFORE anything touches the GPU (not even is_available())
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        # no launcher: become the parent of N ranks BEFORE anything touches the GPU (not even is_available()).  The rendezvous port
+        # is found by bind-and-close, which another process may take before rank 0 binds it: one retry on a fresh port
+        t_launch = time.time()
+        rc = launch_ranks(args.gpus, sys.argv[1:])
+        if rc != 0 and not launch_ranks.relayed and time.time() - t_launch < 60 and os.environ.get("SS_LAUNCH_RETRY", "1") != "0":
+            print("bench.py: the ranks failed; retrying once on another rendezvous port", file=sys.stderr)
+            rc = launch_ranks(args.gpus, sys.argv[1:])
+        sys.exit(rc)
 
     # one rank per GPU over RCCL; SS_DIST_BACKEND=gloo lets the N > 1 control flow be rehearsed with several
     # ranks on ONE GPU (RCCL refuses two ranks on a device) -- the numbers of such a run mean nothing

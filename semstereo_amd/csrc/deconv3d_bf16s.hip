@@ -185,9 +185,12 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
                 a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * swstep + c * 2 * Cout * 16, 0));
             // all 32 eight-byte loads of the K-step first, then the arithmetic: ONE exposed round trip to memory per 16 skip
             // channels (interleaved by the compiler, each of the four (pd, ph) groups waited for its own 8 loads: four)
+            // (r03: in TWO batches of 16 -- all 32 at once left the kernel 2 VGPRs short: 12 bytes of scratch per lane)
+#pragma unroll
+            for (int q0 = 0; q0 < 4; q0 += 2) {
             float2 v[4][8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                  // (pd, ph); the float2 holds pw = 0, 1
+            for (int q = q0; q < q0 + 2; ++q) {            // (pd, ph); the float2 holds pw = 0, 1
                 const unsigned qo = (unsigned)(((size_t)(q >> 1) * out_plane + (size_t)(q & 1) * Wo) * 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = q0; q < q0 + 2; ++q) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (ks * 16 + 8 * half + j >= Cs) v[q][j] = make_float2(0.f, 0.f);
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
                     acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], h8, acc[cls], 0, 0, 0);
                     acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], h8, acc[cls], 0, 0, 0);
                 }
+            }
             }
         }
     };

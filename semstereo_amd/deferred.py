@@ -513,11 +513,12 @@ def gated_volume_of(cv, gate_module, im):
     if not _is(vol, "gwc_norm") or vol.done or not isinstance(patch, M.DepthwisePatch):
         return None
     fl, fr, maxdisp, groups, rng = vol.args
-    if not ops.gwc_patch_gate_applies(fl, maxdisp, groups, rng):
+    logits = gate_module.logits(im)
+    if not ops.gwc_patch_gate_applies(fl, maxdisp, groups, rng, fr, logits):
         return None
     M.PATH_COUNTS["hip"] += 1
     _fused("gwc_patch_gate")
-    return ops.gwc_patch_gate(fl, fr, maxdisp, groups, patch.weight, gate_module.logits(im), _range=rng)
+    return ops.gwc_patch_gate(fl, fr, maxdisp, groups, patch.weight, logits, _range=rng)
 
 
 # ---- rule: sparse concat volume -> x att_topk -> concat_stem -> gate, :316-320 ----------------------------------------------

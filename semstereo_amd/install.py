@@ -102,10 +102,21 @@ def _fused_class(base):
     if cls is None:
         def forward(self, left, right):
             return fused_inference_forward(self, left, right, reference_forward=super(cls, self).forward)
+        def reduce_ex(self, protocol):
+            # whole-model pickling (torch.save(model), multiprocessing spawn): as an instance of the reference's own class --
+            # this subclass exists only in the running process (accelerate(..., fuse_forward=True) again after loading)
+            return (_rebuild_as, (base, self.__dict__.copy()))
         cls = type(base.__name__, (base,), {"forward": forward, "_ss_fused_forward": True, "_ss_reference_class": base,
+                                            "__reduce_ex__": reduce_ex,
                                             "__module__": base.__module__, "__qualname__": base.__qualname__})
         _FUSED_CLASSES[base] = cls
     return cls
+
+
+def _rebuild_as(base, state):
+    obj = base.__new__(base)
+    obj.__dict__.update(state)
+    return obj
 
 
 def restore_forward(model):
@@ -122,7 +133,9 @@ def fused_inference_forward(self, left, right, reference_forward=None):
     `([disp_full_res], label_logits)`, disp = 4 * SSR_upsample(pred).  Everything else (training, autograd,
     segmentation-only models) is handed to the reference's own forward()."""
     if reference_forward is None:
-        reference_forward = super(type(self), self).forward
+        ref_cls = getattr(type(self), "_ss_reference_class", None)
+        assert ref_cls is not None or type(self).forward is not fused_inference_forward, "no reference forward() to hand the call to"
+        reference_forward = (ref_cls or type(self)).forward.__get__(self)
     if (self.training or not self.stereo_if or not left.is_cuda
             or (torch.is_grad_enabled() and (left.requires_grad or right.requires_grad
                                              or any(p.requires_grad for p in self.parameters())))):

@@ -18,6 +18,7 @@ layers on the GPU -- the HIP stack is an inference path; PATH_COUNTS records whi
 parameters (this is what `semstereo_amd.install.accelerate` uses).
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -54,6 +55,7 @@ class _ParamCache:
 
     def __init__(self):
         self._store = {}
+        self.owner = None                    # weakref to the module the cache belongs to (set by _cache)
 
     def get(self, key, sources, build):
         stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in sources)
@@ -65,16 +67,45 @@ class _ParamCache:
         return hit[1]
 
 
+class _ReplicaCache:
+    """The cache view of an nn.DataParallel replica: entries live on the ORIGINAL module (whose `_ss_cache` object the
+    replica's shallow-copied __dict__ shares), keyed by the replica's device, and are valid while the original's
+    parameters and buffers are unchanged -- the replica's own tensors are fresh broadcast copies on every forward that
+    the caching allocator tends to hand the same address with version 0, so their (data_ptr, version) says nothing.
+    Packed weights are built from the replica's device-local copies, once per device and weight update instead of once per
+    forward (~50 pack launches per GPU and step)."""
+
+    def __init__(self, shared, owner, device):
+        self.shared, self.owner, self.device = shared, owner, str(device)
+
+    def get(self, key, sources, build):
+        stamp = tuple((t.data_ptr(), t._version) for t in list(self.owner.parameters()) + list(self.owner.buffers()))
+        k = ("replica", self.device, key)
+        hit = self.shared._store.get(k)
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                hit = (stamp, build())
+            self.shared._store[k] = hit
+        return hit[1]
+
+
 def _cache(module):
-    """Per-module cache of derived tensors.  An nn.DataParallel replica gets a throw-away cache: its __dict__ is a
-    shallow copy of the original's (so `_ss_cache` would be the SAME object on every GPU), and its parameters are
-    fresh broadcast copies on each forward that the caching allocator tends to hand the same address with version 0
-    -- a (data_ptr, version) stamp cannot tell new weights from old ones there."""
-    if module.__dict__.get("_is_replica", False):
-        return _ParamCache()
+    """Per-module cache of derived tensors (packed weights, folded affines)."""
     c = module.__dict__.get("_ss_cache")
+    if module.__dict__.get("_is_replica", False):
+        owner = c.owner() if c is not None and c.owner is not None else None
+        if owner is None:
+            return _ParamCache()              # a replica of a module that never ran on its own: nothing to validate against
+        dev_ = next((t.device for t in list(module.__dict__.get("_former_parameters", {}).values()) + list(module.buffers()) if t is not None), "?")
+        for m in module.modules():
+            fp = [t for t in getattr(m, "_former_parameters", {}).values() if t is not None]
+            if fp:
+                dev_ = fp[0].device
+                break
+        return _ReplicaCache(c, owner, dev_)
     if c is None:
         c = module.__dict__["_ss_cache"] = _ParamCache()
+        c.owner = weakref.ref(module)
     return c
 
 
@@ -1110,7 +1141,7 @@ class channelAtt(nn.Module):
         """im_att(im) [B,cv_chan,H,W] (its sigmoid when `sigmoid`): one HIP launch in inference for the reference's shapes."""
         if _inference(self, im) and im.is_cuda:
             prm = self._hip_params()
-            if prm is not None:
+            if prm is not None and im.shape[1] * im.shape[2] * im.shape[3] * 4 < 2 ** 31:     # (the kernel's 32-bit offsets per element)
                 PATH_COUNTS["hip"] += 1
                 w1, sc, sh, w2, b2 = prm
                 im = im if im.is_contiguous() else im.contiguous()

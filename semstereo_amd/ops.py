@@ -97,7 +97,7 @@ def _build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _rang
     _check_pair(refimg_fea, targetimg_fea, num_groups)
     rng = _range or signed_range(maxdisp)
     if (_defer and dfr.on(None, refimg_fea, targetimg_fea) and refimg_fea.dtype == torch.float32
-            and gwc_patch_gate_applies(refimg_fea, maxdisp, num_groups, rng)):
+            and gwc_patch_gate_applies(refimg_fea, maxdisp, num_groups, rng, targetimg_fea)):
         return dfr.Deferred.call("gwc_norm", lambda a, b, m, g, r: _build_gwc_volume_norm(a, b, m, g, r, _defer=False),
                                refimg_fea, targetimg_fea, maxdisp, int(num_groups), rng)
     if _needs_grad(refimg_fea, targetimg_fea):
@@ -107,9 +107,13 @@ def _build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups, _rang
     return _gwc_forward(_c(refimg_fea), _c(targetimg_fea), rng, int(num_groups), True)
 
 
-def gwc_patch_gate_applies(fea, maxdisp, num_groups, _range=None):
-    """Shapes ss_gwc_patch_gate_fwd is built for (otherwise: the volume kernel + the patch kernel)."""
+def gwc_patch_gate_applies(fea, maxdisp, num_groups, _range=None, *others):
+    """Shapes (and operand alignment: 16-byte loads) ss_gwc_patch_gate_fwd is built for (otherwise: the volume kernel + the
+    patch kernel).  `others`: the remaining device operands of the call (right features, gate logits), checked for alignment."""
     B, C, H, W = fea.shape
+    for t in (fea,) + others:
+        if t is not None and t.is_cuda and (t.data_ptr() % 16 != 0 or not t.is_contiguous()):
+            return False
     cg = C // num_groups
     dmin, nd = _range or signed_range(maxdisp)
     halo = (max(-dmin, dmin + nd - 1, 0) + 3) // 4 * 4

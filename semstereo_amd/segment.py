@@ -104,7 +104,7 @@ class HotSegment(nn.Module):
         lib = ops_unsigned if unsigned else ops
         r8 = ops.unsigned_range(m8) if unsigned else ops.signed_range(m8)
         r4 = ops.unsigned_range(m4) if unsigned else ops.signed_range(m4)
-        if fast and HotSegment.GWC_PATCH_FUSED and isinstance(self.patch, M.DepthwisePatch) and ops.gwc_patch_gate_applies(fl8, m8, groups, r8):
+        if fast and HotSegment.GWC_PATCH_FUSED and isinstance(self.patch, M.DepthwisePatch) and ops.gwc_patch_gate_applies(fl8, m8, groups, r8, fr8):
             M.PATH_COUNTS["hip"] += 1
             cost_att = ops.gwc_patch_gate(fl8, fr8, m8, groups, self.patch.weight, self.corr_feature_att_8.logits(fl8), _range=r8)   # :273-276 fused
         elif fast:

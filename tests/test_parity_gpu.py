@@ -1592,6 +1592,48 @@ def test_unsigned_op_set_vs_reference_fixture(sa, golden):
         check(f"bwd/uconcat/{i}", x, r, 1e-5)
 
 
+def test_op_library_at_configs0_maxdisp48(sa):
+    """BASELINE.json configs[0]: a 256 x 256 pair at maxdisp = 48 (m8 = 6, m4 = 12: disparity ranges that are NOT multiples
+    of 4 / 8, so the volume kernels take their generic forms and the gwc -> patch -> gate fusion does not apply).  The
+    whole graph needs maxdisp % 64 == 0, so this is the op library stand-alone against the oracle."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    m8, m4, H8, H4 = 6, 12, 32, 64
+    fl8, fr8 = dd.stereo_features(1, 256, H8, H8, 881, 3)
+    assert not sa.ops.gwc_patch_gate_applies(fl8, m8, 32)
+    check("md48/gwc_norm", sa.ops.build_gwc_volume_norm(dev(fl8), dev(fr8), m8, 32), oops.build_gwc_volume_norm(fl8, fr8, m8, 32), 2e-6)
+    check("md48/gwc", sa.ops.build_gwc_volume(dev(fl8), dev(fr8), m8, 32), oops.build_gwc_volume(fl8, fr8, m8, 32), 1e-6, 1e-6)
+    cl, cr = dd.stereo_features(1, 32, H4, H4, 882, 6)
+    got = sa.ops.build_concat_volume(dev(cl), dev(cr), m4)
+    assert torch.equal(got.cpu(), oops.build_concat_volume(cl, cr, m4))
+    coarse = dd.t_normalish((1, 1, m4, H8, H8), 883) * 2.0
+    up = F.interpolate(coarse, [2 * m4, H4, H4], mode="trilinear")
+    prob = F.softmax(up.squeeze(1), dim=1)
+    want0 = oops.disparity_regression(prob, m4)
+    check("md48/regression", sa.ops.disparity_regression(dev(prob), m4), want0, 1e-5)
+    check("md48/variance", sa.ops.disparity_variance(dev(prob), m4, dev(want0.unsqueeze(1))), oops.disparity_variance(prob, m4, want0.unsqueeze(1)), 1e-4)
+    assert sa.ops.upsample_softmax_regression_applies(dev(coarse), m4, H4, H4)
+    up_h, p0, var = sa.ops.upsample_softmax_regression(dev(coarse), m4, H4, H4)
+    check("md48/upsample", up_h, up, 2e-6)
+    check("md48/upsample_regression", p0, want0, 1e-5)
+    check("md48/upsample_variance", var, oops.disparity_variance(prob, m4, want0.unsqueeze(1)), 1e-4)
+    fl4, fr4 = dd.stereo_features(1, 128, H4, H4, 884, 6)
+    g_, b_ = torch.full((1,), 0.25), torch.full((1,), 2.0)
+    v_ = torch.sigmoid(b_ + g_ * oops.disparity_variance(prob, m4, want0.unsqueeze(1)))
+    rw, lb = oops.SpatialTransformer_grid(fl4, fr4, oops.propagation(want0.unsqueeze(1)))
+    st_want = torch.softmax((lb * rw).mean(dim=1) * oops.propagation(v_), dim=1)
+    st = sa.ops.sample_strength(dev(fl4), dev(fr4), dev(want0), dev(oops.disparity_variance(prob, m4, want0.unsqueeze(1))), dev(g_), dev(b_))
+    check("md48/strength", st, st_want, 2e-6)
+    aw = (oops.propagation_prob(up) * st_want.unsqueeze(2)).sum(dim=1, keepdim=True)
+    awp = F.softmax(aw, dim=2)
+    ind_k = awp.sort(dim=2, descending=True, stable=True)[1][:, :, :6].sort(2, False)[0]
+    att, smp, pa = sa.ops.topk_candidates(dev(up), dev(st_want), m4, 6)           # 6 of 24 planes (the 24-candidate kernels need D4 >= 24)
+    assert torch.equal(smp.cpu(), ind_k.squeeze(1).float() - m4)
+    check("md48/att_topk", att, torch.gather(awp, 2, ind_k), 1e-6)
+    cost = dd.t_normalish((1, 6, H4, H4), 885)
+    check("md48/regression_topk", sa.ops.regression_topk(dev(cost), smp, 2), oops.regression_topk(cost, smp.cpu(), 2), 1e-5)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", sorted(cases.SEGMENT_WHU))
 def test_hot_segment_whu_vs_reference_fixture(sa, golden, name, fused):

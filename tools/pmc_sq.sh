@@ -33,7 +33,7 @@ for k, d in agg.items():
     wc = m["SQ_WAVE_CYCLES"]
     print("  -- of wave cycles: wait_any %.1f %%, wait_inst_any %.1f %%, active_inst_any %.1f %% (wait_inst_lds %.1f %%, active valu %.1f %%, active lds %.1f %%)" % tuple(
         100 * m.get(c, 0) / wc for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS")))
-    print("  -- clock %.2f GHz-equivalent cycles per XCD: %.0f; matrix pipe busy %.1f %%" % (0, m["GRBM_GUI_ACTIVE"] / 8, 100 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * m["GRBM_GUI_ACTIVE"] / 8)))
+    print("  -- cycles per XCD (GRBM_GUI_ACTIVE / 8): %.0f; matrix pipe busy %.1f %%" % (m["GRBM_GUI_ACTIVE"] / 8, 100 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * m["GRBM_GUI_ACTIVE"] / 8)))
 PY
 rm -rf $out/pmcs_*
 cat $out/pmc_sq_$k.txt
