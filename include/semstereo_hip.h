@@ -366,6 +366,11 @@ int ss_batchnorm_train_fwd(const float* x, const float* weight, const float* bia
 int ss_batchnorm_train_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
                            const float* weight, float* grad_x, double* work, int B, int C, long long N, int relu,
                            ss_stream_t stream);
+/* Weight gradient of the 1x1(x1) convolutions (redir1 / redir2 `models/SemStereo.py:131-132`, attention_block.qkv_3d /
+ * final1x1 `models/submodule_other.py:799-800`, channelAtt.im_att `models/SemStereo.py:92-95`):
+ * grad_out [B,Cout,npos], in [B,Cin,npos] -> grad_w [Cout,Cin]. */
+int ss_conv_k1_wgrad_fwd(const float* grad_out, const float* in, float* grad_w, int B, int Cin, int Cout, long long npos,
+                         ss_stream_t stream);
 /* sums[c] (double) = sum over batch and positions of a[b,c,:]: bias gradients of the 1x1x1 projections of attention_block
  * (models/submodule_other.py:799-800). */
 int ss_channel_sum_fwd(const float* a, double* sums, int B, int C, long long N, ss_stream_t stream);

@@ -16,6 +16,8 @@
 // positions outside the tensors read zeros from beyond the buffer).  The K range is split over the grid and the partial
 // tiles are combined with hardware fp32 atomics (summation order, hence the last bits, vary from run to run -- like the
 // vendor libraries' default weight-gradient algorithms).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -92,7 +94,71 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_k3(const float* __restrict__
     }
 }
 
+// ---- 1x1x1 convolutions (redir1 / redir2, attention_block.qkv_3d / final1x1, channelAtt.im_att):
+//   dW[co, ci] = sum_{b, pos} gout[b, co, pos] * in[b, ci, pos]
+// A [32 x 32] tile per workgroup, the (long) K range = positions split over the grid.  Both operands are staged 128 positions at
+// a time through LDS with coalesced 16-byte loads along the position axis (row stride 129 floats: the MFMA's lane = channel
+// reads are then conflict-free across channels); each of the 4 waves multiplies 32 of the 128 positions
+// (v_mfma_f32_32x32x2_f32, two positions per instruction) and adds its tile to dW with hardware fp32 atomics.
+__global__ __launch_bounds__(256) void conv_wgrad_k1(const float* __restrict__ gout, const float* __restrict__ in,
+                                                      float* __restrict__ dw, int Cin, int Cout, long long npos, long long pos_per_wg,
+                                                      int ci_tiles) {
+    constexpr int LS = 129;
+    __shared__ float ga[32 * LS], xa[32 * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int co0 = (blockIdx.y / ci_tiles) * 32, ci0 = (blockIdx.y % ci_tiles) * 32;
+    const int b = blockIdx.z;
+    const float* gb = gout + (long long)b * Cout * npos;
+    const float* xb = in + (long long)b * Cin * npos;
+    const long long p0 = (long long)blockIdx.x * pos_per_wg, p1 = min(p0 + pos_per_wg, npos);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int row = tid >> 3, col = (tid & 7) * 16;                 // this thread stages 16 consecutive positions of one channel row
+    for (long long p = p0; p < p1; p += 128) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long long pp = p + col + k;
+            const bool ok = pp < p1;
+            ga[row * LS + col + k] = (ok && co0 + row < Cout) ? gb[(long long)(co0 + row) * npos + pp] : 0.f;
+            xa[row * LS + col + k] = (ok && ci0 + row < Cin) ? xb[(long long)(ci0 + row) * npos + pp] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = 32 * wave + 2 * k + half;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[l31 * LS + c], xa[l31 * LS + c], acc, 0, 0, 0);
+        }
+    }
+    if (ci0 + l31 < Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < Cout) unsafeAtomicAdd(dw + (long long)co * Cin + ci0 + l31, acc[r]);
+        }
+    }
+}
+
 }  // namespace
+
+// Weight gradient of a 1x1(x1) convolution: grad_out [B,Cout,npos], in [B,Cin,npos] -> grad_w [Cout,Cin].
+extern "C" int ss_conv_k1_wgrad_fwd(const float* grad_out, const float* in, float* grad_w, int B, int Cin, int Cout, long long npos,
+                                    ss_stream_t stream) {
+    SS_REQUIRE(grad_out && in && grad_w);
+    SS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && npos > 0 && B <= 65535);
+    hipStream_t st = ss::as_stream(stream);
+    if (hipMemsetAsync(grad_w, 0, (size_t)Cout * Cin * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    const int ci_tiles = ss::ceil_div(Cin, 32), tiles = ci_tiles * ss::ceil_div(Cout, 32);
+    if (tiles > 65535) return SS_ERR_UNSUPPORTED;
+    long long splits = std::max<long long>(1, 2048 / ((long long)tiles * B));
+    long long pos_per_wg = std::max<long long>(128, ss::ceil_div_ll(ss::ceil_div_ll(npos, splits), 128) * 128);
+    const long long gx = ss::ceil_div_ll(npos, pos_per_wg);
+    if (gx > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_wgrad_k1, dim3((unsigned)gx, tiles, B), dim3(256), 0, st, grad_out, in, grad_w, Cin, Cout, npos, pos_per_wg,
+                       ci_tiles);
+    return ss::check_launch();
+}
 
 extern "C" int ss_conv3d_wgrad_fwd(const float* grad_out, const float* in, float* grad_w, int B, int Cin, int D, int H, int W,
                                    int Cout, int stride, ss_stream_t stream) {

@@ -69,8 +69,12 @@ def _fname(func):
     return _NAMES.get(getattr(func, "__name__", ""), None)
 
 
+_STATS_LOCK = threading.Lock()
+
+
 def _fused(rule):
-    STATS["fused"][rule] = STATS["fused"].get(rule, 0) + 1
+    with _STATS_LOCK:                       # (nn.DataParallel: one thread per replica)
+        STATS["fused"][rule] = STATS["fused"].get(rule, 0) + 1
 
 
 class Deferred:

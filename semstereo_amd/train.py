@@ -128,8 +128,10 @@ class _ConvK1(torch.autograd.Function):
             gx = _k1_forward(g5, w.detach().reshape(Cout, Cin).t().contiguous(), None)
             gx = gx.squeeze(2) if ctx.was4d else gx
         if ctx.needs_input_grad[1]:
-            # the 3x3x3 weight-gradient kernel on the same tensors: its centre tap is the 1x1x1 gradient
-            gw = M.conv3d_wgrad_hip(g5, x5, Cout, Cin, 1)[:, :, 1, 1, 1].reshape(w.shape).contiguous()
+            gw = torch.empty((Cout, Cin), dtype=torch.float32, device=g5.device)
+            with torch.cuda.device(g5.device):
+                call("ss_conv_k1_wgrad_fwd", ptr(g5), ptr(x5), ptr(gw), g5.shape[0], Cin, Cout, g5[0, 0].numel())
+            gw = gw.reshape(w.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             sums = torch.empty(Cout, dtype=torch.float64, device=g5.device)
             with torch.cuda.device(g5.device):

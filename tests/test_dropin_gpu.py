@@ -132,6 +132,41 @@ def test_data_parallel_replicas_run_their_own_forward_in_two_threads(sa):
     sa.restore_forward(net)
 
 
+def test_data_parallel_replicas_with_the_untouched_forward(sa):
+    """The reference's own multi-GPU form (nn.DataParallel, test_us3d.py:58) on a model that was only install()ed and
+    accelerate()d -- forward() untouched, no fuse_forward: each replica's thread builds its own deferred handles (they are
+    per-call objects; deferral state is thread-local), every fused rule fires once per replica and call, the replicas pack
+    their weights once per device and weight version (modules._ReplicaCache), and the result equals the single-thread call."""
+    import torch.nn as nn
+    from semstereo_amd import deferred as dfr
+    net, module = _build(sa)
+    left, right = _images(B=2)
+    previous = sa.install(module)
+    try:
+        with torch.no_grad():
+            (want,), lab = net(left, right)
+        try:
+            dp = nn.DataParallel(net, device_ids=[0, 0])
+        except Exception as e:
+            pytest.skip(f"DataParallel(device_ids=[0, 0]) not accepted: {e}")
+        before = dict(sa.modules.PATH_COUNTS)
+        for it in range(3):
+            dfr.STATS["fused"].clear()
+            with torch.no_grad():
+                (got,), lab2 = dp(left, right)
+            assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "a replica fell back to PyTorch layers"
+            assert set(dfr.STATS["fused"]) == {"gwc_patch_gate", "upsample_softmax_regression", "sample_strength", "topk_candidates",
+                                                "stem_by_halves"} and all(v == 2 for v in dfr.STATS["fused"].values()), dfr.STATS
+            assert got.shape == want.shape and torch.equal(lab2, lab)
+            err = (got - want).abs()
+            assert float(err.median()) <= 1e-4 and float((err <= 4e-3).float().mean()) >= 0.995, (float(err.median()), float(err.max()))
+        # the replicas' packed weights live on the original's cache, keyed by device: built in the first call, reused after
+        store = net.hourglass.__dict__["_ss_cache"]._store
+        assert any(isinstance(k, tuple) and k[0] == "replica" for k in store), list(store)[:5]
+    finally:
+        sa.uninstall(module, previous)
+
+
 def test_graphed_segment_replays_the_eager_result(sa):
     """GraphedSegment: the step captured into a HIP graph (both streams) gives bit-identical outputs to the eager call, also
     for new inputs copied into the captured buffers."""
