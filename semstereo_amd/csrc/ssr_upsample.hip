@@ -52,7 +52,14 @@ __device__ __forceinline__ float upsampled(const float* __restrict__ low, int h,
     return ss::add_rn(ss::mul_rn(ly0, t0), ss::mul_rn(ly1, t1));
 }
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The head is 18 exponentials and 18 divisions per pixel beside 26 bytes of traffic: libm's expf (~20 instructions) and the
+// IEEE division (~10) made it instruction-bound (0.29 of HBM, r02).  exp: the 6-instruction compensated v_exp_f32 of common.h
+// (1.5 ulp); 1 / d: v_rcp_f32 (1 ulp) + one Newton step (<= 1 ulp of the quotient for the d in [1, 1 + 5e34] that occur).
+__device__ __forceinline__ float recip_nr(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return r * (2.0f - d * r);
+}
+__device__ __forceinline__ float sigmoidf(float x) { return recip_nr(1.0f + ss::exp_fast(fminf(-x, 80.0f))); }
 
 // one pixel: everything after the 3x3 neighbourhood `nb` of BN0(up) and the raw centre value are known
 __device__ __forceinline__ float ssr_pixel(const float (&nb)[9], float centre, const float (&labv)[NCLS], const float (&wt)[NCLS],
@@ -72,10 +79,11 @@ __device__ __forceinline__ float ssr_pixel(const float (&nb)[9], float centre, c
     for (int c = 0; c < NCLS; ++c) mx = fmaxf(mx, labv[c]);
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) { lab[c] = expf(labv[c] - mx); sum = ss::add_rn(sum, lab[c]); }
+    for (int c = 0; c < NCLS; ++c) { lab[c] = ss::exp_fast(fmaxf(labv[c] - mx, -100.0f)); sum = ss::add_rn(sum, lab[c]); }
     float z[NCLS];
+    const float rsum = recip_nr(sum);                         // sum in [1, 6]
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) z[c] = ss::mul_rn(lab[c] / sum, wt[c]);
+    for (int c = 0; c < NCLS; ++c) z[c] = ss::mul_rn(ss::mul_rn(lab[c], rsum), wt[c]);
     float p1[NCLS];
 #pragma unroll
     for (int o = 0; o < NCLS; ++o) {
