@@ -14,6 +14,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import semstereo_amd as sa  # noqa: E402
+from semstereo_amd import deferred as _dfr  # noqa: E402
+_dfr.ENABLED = False          # these tools time / inspect each op by itself: no deferred handles
 from semstereo_amd import modules as M  # noqa: E402
 
 PEAK_TF, PEAK_GBS = 157.3, 8000.0

@@ -10,6 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import semstereo_amd as sa  # noqa: E402
+from semstereo_amd import deferred as _dfr  # noqa: E402
+_dfr.ENABLED = False          # these tools time / inspect each op by itself: no deferred handles
 from semstereo_amd import modules as M  # noqa: E402
 from semstereo_amd import ops  # noqa: E402
 from oracle import hot_segment as oseg  # noqa: E402

@@ -10,6 +10,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import semstereo_amd as sa  # noqa: E402
+from semstereo_amd import deferred as _dfr  # noqa: E402
+_dfr.ENABLED = False          # these tools time / inspect each op by itself: no deferred handles
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20

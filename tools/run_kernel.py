@@ -25,8 +25,9 @@ R = lambda *s: torch.randn(*s, device=dev)                                  # no
 if name in ("gwc", "gwc_fused", "patch"):
     fl, fr, gl = R(B, 256, 128, 128), R(B, 256, 128, 128), R(B, 32, 128, 128)
     patch = M.DepthwisePatch(32).to(dev).eval()
-    vol = O.build_gwc_volume_norm(fl, fr, 16, 32)
-    fn = {"gwc": lambda: O.build_gwc_volume_norm(fl, fr, 16, 32),
+    from semstereo_amd import deferred as dfr              # (in inference the op hands out a deferred handle: ask for its value)
+    vol = dfr.real(O.build_gwc_volume_norm(fl, fr, 16, 32))
+    fn = {"gwc": lambda: dfr.real(O.build_gwc_volume_norm(fl, fr, 16, 32)),
           "gwc_fused": lambda: O.gwc_patch_gate(fl, fr, 16, 32, patch.weight, gl),
           "patch": lambda: patch(vol, gl)}[name]
     nbytes = {"gwc": 4.0 * B * (2 * 256 + 32 * 32) * 128 * 128, "gwc_fused": 4.0 * B * (2 * 256 + 32 + 32 * 32) * 128 * 128,
