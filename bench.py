@@ -637,14 +637,15 @@ def main():
     # bandwidth kernel VERDICT r1 #6 named (268 MB in 83 us then), alone at the bench batch
     try:
         xcl = torch.relu(torch.randn(B, 24, H4, W4, 32, generator=torch.Generator(device=device).manual_seed(10), device=device))
-        wsh = M.pack_head_weight_bf16s(torch.randn(1, 32, 3, 3, 3, device=device) * 0.03)
+        hnt = M._head_nterms()
+        wsh = M.pack_head_weight_bf16s(torch.randn(1, 32, 3, 3, 3, device=device) * 0.03, hnt)
         outh = torch.empty(B, 1, xcl.shape[1], H4, W4, device=device)
         lib = semstereo_amd._lib
-        runh = lambda: lib.call("ss_conv3d_head_bf16s_cl_fwd", lib.ptr(xcl), lib.ptr(wsh), None, None, lib.ptr(outh), B, 32, xcl.shape[1], H4, W4, 0, 6)   # noqa: E731
+        runh = lambda: lib.call("ss_conv3d_head_bf16s_cl_fwd", lib.ptr(xcl), lib.ptr(wsh), None, None, lib.ptr(outh), B, 32, xcl.shape[1], H4, W4, 0, hnt)   # noqa: E731
         msh = steady_ms(runh)
         nbh = 4.0 * B * 33 * xcl.shape[1] * H4 * W4
         res["roofline_classifier_head"] = {
-            "kernel": "conv3d_head_bf16s<4,8,2,6,CL> (classif.2: Conv3d(32,1,3) over [B,32,24,H/4,W/4], channels-last input), launched alone",
+            "kernel": f"conv3d_head_bf16s<4, 8, 2, {hnt}, true> (classif.2: Conv3d(32,1,3) over [B,32,24,H/4,W/4], channels-last input), launched alone",
             "bound": "hbm", "achieved": nbh / (msh * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbh / (msh * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": msh, "algorithmic_bytes_per_launch": nbh,
             "traffic": None}

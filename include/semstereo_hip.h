@@ -272,11 +272,16 @@ int ss_pack_conv2d_weights_f16s(const float* w, void* wsplit, int Cout, int Cin,
 /* The single-output-channel classifier heads, nn.Conv3d(C, 1, 3, padding=1, bias=False)
  * (models/SemStereo.py:228-234, classif.2 / classif_att_.2), on the split-bf16 engine with the 27 taps as
  * the matrix rows:  out [B,1,D,H,W] = relu?(scale[0] * conv(in [B,Cin,D,H,W]) + shift[0]);
- * Cin in {16, 32, 64}; wsplit from ss_pack_conv3d_head_weights_bf16s ((Cin/16)*3*2*32*16 bytes). */
+ * Cin in {16, 32, 64}; nterms 6 / 3: wsplit from ss_pack_conv3d_head_weights_bf16s ((Cin/16)*3*2*32*16 bytes); nterms 19: from
+ * ss_pack_conv3d_head_weights_f16s. */
 int ss_conv3d_head_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                              float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
                              ss_stream_t stream);
 int ss_pack_conv3d_head_weights_bf16s(const float* w, void* wsplit, int Cin, ss_stream_t stream);
+/* nterms = 19 of the two head entry points: two fp16 terms, three products, block floating point (one power-of-two scale
+ * for the weights, one per input row from a wave-wide maximum) -- half the matrix work of nterms = 6 at the same accuracy
+ * class.  wsplit: (Cin/16)*2*2*32*16 bytes of terms + one float (2^-scale). */
+int ss_pack_conv3d_head_weights_f16s(const float* w, void* wsplit, int Cin, ss_stream_t stream);
 /* The two layers of a classifier (nn.Sequential(convbn_3d(32,32,3,1,1), ReLU, Conv3d(32,1,3,p1)), models/SemStereo.py:228-234)
  * hand their intermediate over CHANNELS-LAST, [B][D][H][W][C]: it is private to the Sequential, and with a position's
  * channels contiguous the first layer stores 16 bytes per lane and instruction and the head loads 16 (the head spends half

@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -63,6 +64,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restr
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              float* __restrict__ out, int D, int H, int W, int tiles_w,
                                                              int tiles_h, int relu) {
+    // NTERMS = F16X3 (19): TWO fp16 terms, three products (half the matrix work of the six bf16 ones), block floating point as
+    // in conv3d_bf16s.hip: the weights carry ONE power-of-two scale (stored behind the packed terms), every input row is scaled
+    // by the power of two of its own maximum (a wave-wide reduce) and its partial rows are un-scaled as they go to LDS.
+    constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;
     constexpr int IH = TH + 2, NR = (TD + 2) * IH, Cin = KS * 16;
     extern __shared__ __attribute__((aligned(16))) float S[];     // [9][NR][32]
@@ -79,7 +84,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restr
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) a[ks][c] = __builtin_bit_cast(bf16x8, wsplit[((ks * 3 + c) * 2 + half) * 32 + l31]);
+        for (int c = 0; c < NC; ++c) a[ks][c] = __builtin_bit_cast(bf16x8, wsplit[((ks * (F16 ? 2 : 3) + c) * 2 + half) * 32 + l31]);
+    // f16 form: 2^-(weight scale), one float behind the KS * 2 * 2 * 32 fragment slots
+    const float w_unscale = F16 ? *reinterpret_cast<const float*>(wsplit + KS * 2 * 2 * 32) : 1.0f;
 
     const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(in + (size_t)b * Cin * chan), 0, (int)min((long long)Cin * (long long)chan * 4, 0x7fffffffLL), 0x00020000);
@@ -124,6 +131,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restr
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        float row_unscale = 1.0f;
+        if constexpr (F16) {
+            float m = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[ks][j]));
+            const int e = max((int)(wave_max_bits(__float_as_uint(m)) >> 23), E_MIN);       // wave-uniform; inf / NaN: 255
+            const float in_scale = __uint_as_float((unsigned)(127 + E_ONE - e) << 23);
+            row_unscale = __uint_as_float((unsigned)(127 - E_ONE + e) << 23) * w_unscale;     // powers of two: exact
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                unsigned bh[4], bl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split2_pk_f16(x[ks][2 * j] * in_scale, x[ks][2 * j + 1] * in_scale, bh[j], bl[j]);
+                const f16x8 h8 = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                const f16x8 l8 = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks][0]), l8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks][1]), h8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks][0]), h8, acc, 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {                   // (rows outside the volume were read as zeros)
             unsigned bh[4], bm[4], bl[4];
@@ -144,7 +173,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_head_bf16s(const float* __restr
         // kw = 0 comes from the column to the left, kw = 2 from the column to the right
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            const float sv = ss::add_rn(ss::add_rn(from_lane_below(acc[3 * q]), acc[3 * q + 1]), from_lane_above(acc[3 * q + 2]));
+            float sv = ss::add_rn(ss::add_rn(from_lane_below(acc[3 * q]), acc[3 * q + 1]), from_lane_above(acc[3 * q + 2]));
+            if (F16) sv *= row_unscale;
             if (half == 0 || q < 4) S[((half ? 5 + q : q) * NR + r) * 32 + l31] = sv;
         }
     };
@@ -194,6 +224,34 @@ __global__ void pack_head_weights_kernel(const float* __restrict__ w, unsigned s
     wsplit[i] = (unsigned short)((term == 0 ? h : (term == 1 ? m : l)) & 0xffffu);
 }
 
+// the two-term fp16 form: [Cin/16][2 terms][2 k-halves][32 rows][8] fp16 of w * 2^k, k from max |w| (into [2^14, 2^15)), then one
+// float 2^-k.  One workgroup: the weights are 27 * Cin <= 1728 values.
+__global__ __launch_bounds__(256) void pack_head_weights_f16s_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit,
+                                                                      int Cin, int total) {
+    __shared__ unsigned wmax[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < Cin * 27; i += 256) m = fmaxf(m, fabsf(w[i]));
+    const unsigned wm = wave_max_bits(__float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = wm;
+    __syncthreads();
+    const int e = max((int)(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])) >> 23), E_MIN);
+    const float unscale = __uint_as_float((unsigned)(127 - E_ONE + e) << 23);
+    if (threadIdx.x == 0) *reinterpret_cast<float*>(wsplit + total) = unscale;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int j = i % 8;
+        int r = i / 8;
+        const int row = r % 32; r /= 32;
+        const int hk = r % 2; r /= 2;
+        const int term = r % 2;
+        const int ks = r / 2;
+        const int tap = head_row_tap(row), c = ks * 16 + 8 * hk + j;
+        const float x = (tap >= 0 && c < Cin) ? w[(size_t)c * 27 + tap] / unscale : 0.f;         // exact: a power of two
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
+    }
+}
+
 template <int TD, int TH, int KS, int NTERMS, bool CL>
 int launch_head(const float* in, const void* wsplit, const float* scale, const float* shift, float* out, int B, int D,
                 int H, int W, int relu, hipStream_t st) {
@@ -230,18 +288,27 @@ extern "C" int ss_pack_conv3d_head_weights_bf16s(const float* w, void* wsplit, i
     return ss::check_launch();
 }
 
+extern "C" int ss_pack_conv3d_head_weights_f16s(const float* w, void* wsplit, int Cin, ss_stream_t stream) {
+    SS_REQUIRE(w && wsplit && Cin > 0 && Cin % 16 == 0);
+    const int total = (Cin / 16) * 2 * 2 * 32 * 8;
+    hipLaunchKernelGGL(pack_head_weights_f16s_kernel, dim3(1), dim3(256), 0, ss::as_stream(stream), w,
+                       reinterpret_cast<unsigned short*>(wsplit), Cin, total);
+    return ss::check_launch();
+}
+
 extern "C" int ss_conv3d_head_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                                         float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
                                         ss_stream_t stream) {
     SS_REQUIRE(in && wsplit && out);
-    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && (nterms == 3 || nterms == 6 || nterms == F16X3));
     SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
     if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;     // 32-bit buffer offsets per pair
     hipStream_t st = ss::as_stream(stream);
 #define SS_HEAD(KSV)                                                                                                  \
     if (Cin == 16 * KSV)                                                                                              \
         return nterms == 6 ? launch_head_tile<KSV, 6>(in, wsplit, scale, shift, out, B, D, H, W, relu, st)            \
-                           : launch_head_tile<KSV, 3>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
+             : nterms == 3 ? launch_head_tile<KSV, 3>(in, wsplit, scale, shift, out, B, D, H, W, relu, st)            \
+                           : launch_head_tile<KSV, F16X3>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
     SS_HEAD(1)
     SS_HEAD(2)
     SS_HEAD(4)
@@ -420,12 +487,13 @@ extern "C" int ss_conv3d_head_bf16s_cl_fwd(const float* in, const void* wsplit, 
                                            float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
                                            ss_stream_t stream) {
     SS_REQUIRE(in && wsplit && out);
-    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && (nterms == 3 || nterms == 6));
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && (nterms == 3 || nterms == 6 || nterms == F16X3));
     SS_REQUIRE(((reinterpret_cast<uintptr_t>(wsplit) | reinterpret_cast<uintptr_t>(in)) & 15) == 0);
     if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     hipStream_t st = ss::as_stream(stream);
     if (Cin == 32)
         return nterms == 6 ? launch_head_tile<2, 6, true>(in, wsplit, scale, shift, out, B, D, H, W, relu, st)
-                           : launch_head_tile<2, 3, true>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
+             : nterms == 3 ? launch_head_tile<2, 3, true>(in, wsplit, scale, shift, out, B, D, H, W, relu, st)
+                           : launch_head_tile<2, F16X3, true>(in, wsplit, scale, shift, out, B, D, H, W, relu, st);
     return SS_ERR_UNSUPPORTED;
 }

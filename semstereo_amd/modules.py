@@ -352,16 +352,31 @@ def run_conv2d(owner, key, conv, bn, x, relu):
     return conv2d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms)
 
 
-def pack_head_weight_bf16s(w):
-    """[1,Cin,3,3,3] fp32 -> split-bf16 fragments (taps as matrix rows) for ss_conv3d_head_bf16s_fwd."""
+def pack_head_weight_bf16s(w, nterms=6):
+    """[1,Cin,3,3,3] fp32 -> split fragments (taps as matrix rows) for ss_conv3d_head_bf16s_fwd: three bf16 terms (nterms 6 / 3)
+    or two scaled fp16 terms + the inverse scale (nterms 19)."""
     w = w.detach().float().contiguous()
     _lib.require_device(w)
     Cin = w.shape[1]
     assert w.shape[0] == 1 and tuple(w.shape[2:]) == (3, 3, 3) and Cin % 16 == 0
-    out = torch.empty((Cin // 16) * 3 * 2 * 32 * 8, dtype=torch.int16, device=w.device)
     with torch.cuda.device(w.device):
-        call("ss_pack_conv3d_head_weights_bf16s", ptr(w), ptr(out), Cin)
+        if nterms == 19:
+            out = torch.empty((Cin // 16) * 2 * 2 * 32 * 8 + 8, dtype=torch.int16, device=w.device)
+            call("ss_pack_conv3d_head_weights_f16s", ptr(w), ptr(out), Cin)
+        else:
+            out = torch.empty((Cin // 16) * 3 * 2 * 32 * 8, dtype=torch.int16, device=w.device)
+            call("ss_pack_conv3d_head_weights_bf16s", ptr(w), ptr(out), Cin)
     return out
+
+
+#: SS_HEAD_F16=1: the 32 -> 1 classifier heads on two fp16 terms (3 products, a block exponent per input row) instead of three
+#: bf16 terms (6 products).  Off by default: since the channels-last hand-off (r02) the head is bound by its loads, not by its
+#: matrix work -- measured r03_i: 51.1 vs 52.7 us alone, 462.0 vs 461.6 pairs/s for the step (`profiles/r03_i_*`)
+HEAD_F16 = os.environ.get("SS_HEAD_F16", "0") != "0"
+
+
+def _head_nterms():
+    return 19 if (CONV_ENGINE == "f16x3" and HEAD_F16) else _aux_nterms()
 
 
 def conv3d_head_bf16s_hip(x, wsplit, scale, shift, relu, nterms):
@@ -434,13 +449,13 @@ def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
         return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual, gate, stride=s)
     if (CONV_ENGINE != "f32" and k == 3 and s == 1 and conv.out_channels == 1 and conv.in_channels in (16, 32, 64)
             and residual is None and gate is None):
-        nterms = _aux_nterms()
+        nterms = _head_nterms()
         srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
         def build_head():
             sc, sh = fold_bn(bn) if bn is not None else (None, None)
-            return pack_head_weight_bf16s(conv.weight), sc, sh
-        ws, scale, shift = _cache(owner).get(key + "/head_bf16s", srcs, build_head)
+            return pack_head_weight_bf16s(conv.weight, nterms), sc, sh
+        ws, scale, shift = _cache(owner).get(key + "/head_%d" % nterms, srcs, build_head)
         return conv3d_head_bf16s_hip(x, ws, scale, shift, relu, nterms)
     wp, scale, shift = _convbn_params(owner, key, conv, bn)
     return conv3d_hip(x, wp, scale, shift, k, s, relu, residual, gate)
@@ -470,7 +485,7 @@ def conv3d_wgrad_hip(grad_out, x, Cout, Cin, stride):
 def _conv_k3_forward(x, w, stride):
     """Conv3d(k3, p1, stride, no bias) on the selected engine, weights packed on the fly (they change every step)."""
     if CONV_ENGINE != "f32" and w.shape[0] == 1 and stride == 1 and w.shape[1] in (16, 32, 64):
-        return conv3d_head_bf16s_hip(x, pack_head_weight_bf16s(w), None, None, False, _aux_nterms())      # the 32 -> 1 classifier heads
+        return conv3d_head_bf16s_hip(x, pack_head_weight_bf16s(w, _head_nterms()), None, None, False, _head_nterms())      # the 32 -> 1 classifier heads
     if CONV_ENGINE == "f32":
         return conv3d_hip(x, pack_conv_weight(w), None, None, 3, stride, False)
     nterms = _tiled_nterms()
@@ -1002,11 +1017,11 @@ class Classifier(nn.Sequential):
             c0, bn0, c2 = self[0][0], self[0][1], self[2]
             if (CLASSIFIER_CL and CONV_ENGINE != "f32" and c0.in_channels == c0.out_channels == c2.in_channels == 32
                     and _conv_geometry(c0) == (3, 1) and _conv_geometry(c2) == (3, 1) and c2.out_channels == 1):
-                nt0, nt2 = _tiled_nterms(), _aux_nterms()
+                nt0, nt2 = _tiled_nterms(), _head_nterms()
 
                 def build():
                     sc, sh = fold_bn(bn0)
-                    return pack_conv_weight_bf16s(c0.weight, nt0), sc, sh, pack_head_weight_bf16s(c2.weight)
+                    return pack_conv_weight_bf16s(c0.weight, nt0), sc, sh, pack_head_weight_bf16s(c2.weight, nt2)
                 srcs = [c0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, c2.weight]
                 ws0, sc, sh, ws2 = _cache(self).get("cl/%d/%d" % (nt0, nt2), srcs, build)
                 return classifier_cl_hip(x, ws0, sc, sh, nt0, ws2, nt2)

@@ -571,11 +571,12 @@ HEAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("nterms", [6, 3])
+@pytest.mark.parametrize("nterms", [6, 3, 19])
 @pytest.mark.parametrize("case", HEAD_CASES)
 def test_conv3d_head_split_bf16(sa, case, nterms):
     """classif.2 / classif_att_.2 (models/SemStereo.py:228-234) with the taps as matrix rows: as close to the
-    float64 result as the exact-fp32 kernel (6 products), within 4e-5 absolute (3 products)."""
+    float64 result as the exact-fp32 kernel (6 bf16 products, or the two-term fp16 form: nterms 19), within 4e-5
+    absolute (3 bf16 products)."""
     import torch.nn.functional as F
     from oracle import detdata as dd
     B, Cin, D, H, W, relu = case
@@ -585,17 +586,28 @@ def test_conv3d_head_split_bf16(sa, case, nterms):
     ref = F.conv3d(x.double(), w.double(), None, 1, 1) * scale.double() + shift.double()
     if relu:
         ref = F.relu(ref)
-    y = sa.modules.conv3d_head_bf16s_hip(dev(x), sa.modules.pack_head_weight_bf16s(dev(w)), dev(scale), dev(shift), relu, nterms)
+    y = sa.modules.conv3d_head_bf16s_hip(dev(x), sa.modules.pack_head_weight_bf16s(dev(w), nterms), dev(scale), dev(shift), relu, nterms)
     y32 = sa.modules.conv3d_hip(dev(x), sa.modules.pack_conv_weight(dev(w)), dev(scale), dev(shift), 3, 1, relu)
     e_split = float((y.double().cpu() - ref).abs().max())
     e_f32 = float((y32.double().cpu() - ref).abs().max())
     REPORT[f"conv3d_head_bf16x{nterms}/{case}"] = e_split
     REPORT[f"conv3d_head_f32_vs_f64/{case}"] = e_f32
-    tol = 1.5 * e_f32 + 1e-6 if nterms == 6 else 4e-5        # 3 products: ~1e-5 relative, absolute bound on O(1) outputs
+    tol = 1.5 * e_f32 + 1e-6 if nterms in (6, 19) else 4e-5        # 3 bf16 products: ~1e-5 relative, absolute bound on O(1) outputs
     assert e_split <= tol, (e_split, e_f32)
-    yn = sa.modules.conv3d_head_bf16s_hip(dev(x), sa.modules.pack_head_weight_bf16s(dev(w)), None, None, False, nterms)
+    yn = sa.modules.conv3d_head_bf16s_hip(dev(x), sa.modules.pack_head_weight_bf16s(dev(w), nterms), None, None, False, nterms)
     refn = F.conv3d(x.double(), w.double(), None, 1, 1)
-    assert float((yn.double().cpu() - refn).abs().max()) <= (4e-6 if nterms == 6 else 4e-5)
+    assert float((yn.double().cpu() - refn).abs().max()) <= (4e-6 if nterms in (6, 19) else 4e-5)
+    if nterms == 19:        # block floating point: rows 12 decades apart in either order keep the fp32 kernel's relative accuracy
+        ramp = torch.logspace(-6, 6, H).reshape(1, 1, 1, H, 1)
+        for rr in (ramp, ramp.flip(3)):
+            xs = x * rr
+            want = F.conv3d(xs.double(), w.double(), None, 1, 1)
+            got = sa.modules.conv3d_head_bf16s_hip(dev(xs), sa.modules.pack_head_weight_bf16s(dev(w), 19), None, None, False, 19)
+            g32 = sa.modules.conv3d_hip(dev(xs), sa.modules.pack_conv_weight(dev(w)), None, None, 3, 1, False)
+            loc = torch.nn.functional.max_pool3d(xs.abs().amax(dim=1, keepdim=True), 3, 1, 1).double() + 1e-30     # the scale of each output's inputs
+            e19 = float(((got.double().cpu() - want).abs() / loc).max())
+            e32 = float(((g32.double().cpu() - want).abs() / loc).max())
+            assert e19 <= 2.0 * e32 + 1e-7, (e19, e32)
 
 @pytest.mark.parametrize("shape", [(2, 5, 9, 37), (1, 8, 24, 64), (1, 4, 70, 95), (1, 1, 1, 1), (1, 24, 64, 96)])
 def test_classifier_channels_last_handoff_is_bit_identical(sa, shape, monkeypatch):

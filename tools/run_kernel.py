@@ -94,10 +94,11 @@ elif name in ("conv_mid", "conv_low"):   # hourglass2.conv2: 64 -> 64 at [12,128
     nbytes = 4.0 * B * 2 * c * d * hw * hw
 elif name == "head_cl":          # classif.2 reading the channels-last intermediate of its classifier
     xcl = torch.relu(R(B, 24, 256, 256, 32))
-    ws = M.pack_head_weight_bf16s(R(1, 32, 3, 3, 3))
+    hnt = int(os.environ.get("SS_TOOL_HEAD_NTERMS", str(M._head_nterms())))
+    ws = M.pack_head_weight_bf16s(R(1, 32, 3, 3, 3), hnt)
     outh = torch.empty(B, 1, 24, 256, 256, device=dev)
     lib = sa._lib
-    fn = lambda: lib.call("ss_conv3d_head_bf16s_cl_fwd", lib.ptr(xcl), lib.ptr(ws), None, None, lib.ptr(outh), B, 32, 24, 256, 256, 0, 6)   # noqa: E731
+    fn = lambda: lib.call("ss_conv3d_head_bf16s_cl_fwd", lib.ptr(xcl), lib.ptr(ws), None, None, lib.ptr(outh), B, 32, 24, 256, 256, 0, hnt)   # noqa: E731
     nbytes = 4.0 * B * 33 * 24 * 256 * 256
 elif name == "conv_s1_cl":       # the stride-1 32 -> 32 conv with channels-last output (16-byte stores)
     x = torch.relu(R(B, 32, 24, 256, 256))
