@@ -580,6 +580,10 @@ def main():
         res["hbm_copy_torch_gbs"] = 2.0 * nbc / (mst * 1e-3) / 1e9
         res["roofline_cost_volume_b8"]["frac_of_measured_copy"] = res["roofline_cost_volume_b8"]["achieved"] / copy_gbs
         res["roofline_cost_volume_b8"]["frac_cold_of_measured_copy"] = nb8 / (ms8_cold * 1e-3) / 1e9 / copy_gbs
+        res["roofline_cost_volume_b8"]["frac_of_measured_copy_note"] = (
+            "above 1 because the two streams differ: the volume kernel writes two bytes per byte it reads (268 MB in, 537 MB out), "
+            "the copy one per one, and nontemporal HBM writes stream faster than reads on this chip; replayed on ONE input set "
+            "(frac_of_measured_copy) part of the reads additionally come from the Infinity Cache")
         del src, dst
         # the fused form of the step (volume -> patch -> gate in one launch) at the same batch 8
         if semstereo_amd.ops.gwc_patch_gate_applies(sets[0][0], m8, 32):
