@@ -1658,8 +1658,15 @@ def test_hot_segment_whu_vs_reference_fixture(sa, golden, name, fused):
     seg = seg.cuda().eval()
     seg.FUSED = fused
     fl4, fr4, fl8, fr8, _ = cases.segment_inputs(name)
+    from semstereo_amd import deferred as dfr
+    dfr.STATS["fused"].clear()
     with torch.no_grad():
         r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
+    if not fused:
+        # the statement-by-statement form: the deferred handles recognise the WHU variant's text too (:279 maxdisp//4 planes,
+        # :305 no offset -> candidates are the plane indices) and run the same fused kernels on the unsigned ranges
+        assert set(dfr.STATS["fused"]) == {"gwc_patch_gate", "upsample_softmax_regression", "sample_strength", "topk_candidates",
+                                            "stem_by_halves"}, dfr.STATS
     g = golden["segment_whu"]
     assert float(r["samples"].min()) >= 0 and float(r["samples"].max()) < maxdisp // 4
     check(f"whu/{name}/{fused}/pred_att0", r["pred_att0"], g[f"{name}/pred_att0"], 1e-3)
