@@ -780,7 +780,16 @@ def main():
                 for k_ in ("epe_vs_reference_px", "epe_vs_reference_fullres_px", "pixels_with_other_candidates"):
                     res[k_] = pv[k_]
                 if "reference_picks_restored" in pv:
-                    res["epe_vs_reference_fullres_px_reference_picks_restored"] = pv["reference_picks_restored"]["epe_vs_reference_fullres_px"]
+                    rp = pv["reference_picks_restored"]
+                    res["epe_vs_reference_fullres_px_reference_picks_restored"] = rp["epe_vs_reference_fullres_px"]
+                    dp = rp.get("differing_pixels") or {}
+                    res["epe_vs_reference_note"] = (
+                        f"plain run: {pv['pixels_with_other_candidates']} of {pv['pixels']} pixels pick other top-24 candidates than the reference "
+                        f"(its own margins there: {dp.get('reference_margin_rel')}; of these the HIP pick equals the float64 evaluation's on "
+                        f"{dp.get('hip_pick_equals_float64_truth')}, the reference's on {dp.get('reference_pick_equals_float64_truth')}); with calibrated "
+                        "BatchNorm one such pick moves ~10^3 pixels of pred by up to tens of px, which is all of the plain-run EPE above "
+                        "the restored figure; max error off the reference's own cost ties after restoring: "
+                        f"{rp['max_err_off_ties_px']:.2e} px (1/4 scale), pixels beyond 1e-3: {rp['pixels_beyond_1e-3']}")
             except Exception as e:       # noqa: BLE001
                 res["parity_vs_reference"] = {"error": repr(e)}
         res["parity_vs_oracle"] = par
