@@ -81,7 +81,8 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsig
 
 // KD: kernel depth, 3 (3x3x3) or 1 (3x3 over [B,C,H,W] maps seen as depth-1 volumes: 9 taps, 5 K-steps)
 // WSL: 16-byte LDS slots of a chunk's weight fragments (0: every wave fetches its own)
-template <int S, int NT, int TD, int TH, int KD = 3, int LT = 3, int WSL = 0>      // LT: operand terms kept in LDS
+// MS: waves that share a row group and split the workgroup's output channels (1: every wave owns NT rows of all of them)
+template <int S, int NT, int TD, int TH, int KD = 3, int LT = 3, int WSL = 0, int MS = 1>      // LT: operand terms kept in LDS
 struct BCfg {
     static constexpr int KT = KD * 9, KSTEPS = (KT + 1) / 2;
     static constexpr int ID = (TD - 1) * S + KD, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
@@ -91,7 +92,7 @@ struct BCfg {
     // + one all-zero slot (the 28th half-step) + the waves' maxima (f16 form) + the affine of the workgroup's (<= 64) channels
     static constexpr int SLOTS = LT * CS + 2 + 48 + WSL;
     static constexpr size_t LDS_BYTES = (size_t)SLOTS * 16;
-    static_assert(TD * TH == 4 * NT && TH % NT == 0, "4 waves x NT rows tile TD x TH");
+    static_assert(TD * TH * MS == 4 * NT && TH % NT == 0 && (MS == 1 || MS == 2), "4 / MS wave groups x NT rows tile TD x TH");
 };
 
 constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
@@ -104,7 +105,11 @@ constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
 // layers, whose staging is 8x dearer per MFMA and whose 2-4 output tiles would otherwise each stage the same input)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
+// MS = 2 (stride-2 layers): the four waves are 2 row groups x 2 halves of the workgroup's 64 * MT output channels.  A wave then
+// fetches the weight fragments of ITS channels only (the vector L1 carried every fragment four times per workgroup: 32 KB
+// per K-step and CU beside 8 KB of activations, 640 clocks at its 64 B/clk for 384 clocks of MFMA issue -- tools/wg_phases_s2.py)
+// and reads the activation fragments of two rows from LDS instead of one.
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1>
 __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
@@ -119,7 +124,8 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // (14 steps x 2 terms, 28 KB) are then brought into LDS once per workgroup by LDS-DMA loads (no registers) and read
     // from there by the four waves (deconv3d_bf16s.hip has the measurement: -11 %).
     constexpr bool WLDS = wlds_form(S, NT, NTERMS, MT, KD);
-    using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? BCfg<S, NT, TD, TH, KD>::KSTEPS * 2 * 64 : 0>;
+    static_assert(!WLDS || MS == 1, "the LDS copy of the weights is one channel tile's");
+    using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS>;
     constexpr int WL = NC * C::CS + 2 + 48;                    // first slot of the weight fragments
     constexpr int KSTEPS = C::KSTEPS;                          // shadows the 3-D constant
     constexpr int ZSLOT = NC * C::CS;                          // the all-zero slot; ZSLOT + 1: the four waves' maxima
@@ -133,9 +139,11 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // FIRST chunk of the next tile, so only the very first tile of a workgroup pays the exposed round trip to HBM that used
     // to open every workgroup's life (12 k of ~100 k cycles, tools/wg_phases.py); the epilogue's stores then drain under the
     // next tile's first K-steps.
-    const int co0 = blockIdx.y * 32 * MT;
+    const int co0 = blockIdx.y * 32 * MT * MS;                  // the workgroup's first channel
+    const int wrow = wave / MS;                                 // row group of this wave
+    const int cow = co0 + (wave % MS) * 32 * MT;                // this wave's first channel
     const int b = blockIdx.z;
-    const int dzw = (wave * NT) / TH, hy0 = (wave * NT) % TH;
+    const int dzw = (wrow * NT) / TH, hy0 = (wrow * NT) % TH;
     const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + l31 * S;     // slot of this lane's first row, tap (0,0,0)
     auto tile_origin = [&](int tile, int& ow0, int& oh0, int& od0) {
         int t = tile;
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         }
     };
     // this lane's channel of fragment register r of output tile mt: cbase(mt, r) + 4 * half
-    auto cbase = [&](int mt, int r) { return co0 + mt * 32 + (r & 3) + 8 * (r >> 2); };
+    auto cbase = [&](int mt, int r) { return cow + mt * 32 + (r & 3) + 8 * (r >> 2); };
     f32x16 acc[MT * NT];                  // index mt * NT + row
 
     const size_t in_plane = (size_t)H * W, chan = (size_t)D * in_plane;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // per-channel epilogue constants, fetched now and parked in LDS: read after the K loop they cost two exposed round
     // trips to L2/HBM per workgroup (tools/wg_phases.py).  aff[c] = scale, aff[64 + c] = shift, aff[128 + c] = 2^-(weight scale)
     float* aff = reinterpret_cast<float*>(&lds[ZSLOT + 2]);
-    if (tid < 32 * MT) {
+    if (tid < 32 * MT * MS) {
         const int co = min(co0 + tid, Cout - 1);
         aff[tid] = scale ? scale[co] : 1.0f;
         aff[64 + tid] = shift ? shift[co] : 0.0f;
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // scalar offset + one 32-bit per-lane offset, so no 64-bit per-lane addresses are kept live.
     int wlane[MT];                                                            // byte offset of this lane's column, per output tile
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) wlane[mt] = (half * Cout + min(co0 + mt * 32 + l31, Cout - 1)) * 16;
+    for (int mt = 0; mt < MT; ++mt) wlane[mt] = (half * Cout + min(cow + mt * 32 + l31, Cout - 1)) * 16;
     const int wstep = NCW * 2 * Cout * 16;                                    // bytes per K-step
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(wsplit), 0, (int)min((long long)((Cin + 7) / 8) * KSTEPS * wstep, 0x7fffffffLL), 0x00020000);
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         }
     }
     };
-    if (co0 + 32 * MT <= Cout) epilogue(std::true_type{});
+    if (co0 + 32 * MT * MS <= Cout) epilogue(std::true_type{});
     else epilogue(std::false_type{});
     SS_STAMP(3);
     }       // tiles of this workgroup (the next one's first chunk is already in the prefetch registers)
@@ -612,26 +620,25 @@ __global__ void pack_weights_f16s_kernel(const float* __restrict__ w, unsigned s
     wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
 }
 
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3>
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1>
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
-    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2,
-                   wlds_form(S, NT, NTERMS, MT, KD) ? BCfg<S, NT, TD, TH, KD>::KSTEPS * 2 * 64 : 0>;
+    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2, wlds_form(S, NT, NTERMS, MT, KD) ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS>;
     const int Do = (D + 2 * (KD / 2) - KD) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD>;
+    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD, MS>;
     if (C::LDS_BYTES > 64 * 1024) {
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
     // persistent workgroups: as many as the chip holds at once (2 - 4 per CU depending on the tile), each walking an equal
     // share of the tiles
-    const int groups = ss::ceil_div(Cout, 32 * MT) * B;
+    const int groups = ss::ceil_div(Cout, 32 * MT * MS) * B;
     const long long cap = std::max<long long>(1, ss::resident_workgroups(reinterpret_cast<const void*>(kern), 256, (int)C::LDS_BYTES) / groups);
     const long long rounds = ss::ceil_div_ll(nt, cap);
     const long long gx = ss::ceil_div_ll(nt, rounds);
-    dim3 grid((unsigned)gx, ss::ceil_div(Cout, 32 * MT), B);
+    dim3 grid((unsigned)gx, ss::ceil_div(Cout, 32 * MT * MS), B);
     // (Workgroups of equal duration that all start together stay in lock-step -- every CU stages, multiplies and stores at
     // the same time.  Starting the first round's workgroups spread over 0.5-1.5 estimated lifetimes, in 2-16 groups, was
     // measured: no gain, -0 .. -8 %.)
@@ -647,7 +654,13 @@ int launch_bg(const float* in, const void* wsplit, const float* scale, const flo
     // unless that leaves fewer workgroups than CUs (57 vs 41 us on the smallest)
     const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const long long wg2 = (long long)ss::ceil_div(Wo, 32) * ss::ceil_div(Ho, TH) * ss::ceil_div(Do, TD) * ss::ceil_div(Cout, 64) * B;
-    if (S == 2 && Cout > 32 && wg2 >= 256 && ss::tuning().conv_s2_mt1 < 0)
+    // ... and, since r03, the 64 channels split over the waves (MS = 2: wave = (row pair, 32 channels)) instead of two channel
+    // tiles per wave: the same MFMAs and staging with half the weight-fragment fetches (SS_CONV_S2_MT1=0: the r02 form)
+    if constexpr (S == 2 && NT == 1 && TD * TH == 4 && !GATED) {      // (no layer gates a stride-2 conv; its MS form would spill)
+        if (Cout > 32 && wg2 >= 256 && ss::tuning().conv_s2_mt1 < 0)
+            return launch_bgm<S, 2, TD, TH, NTERMS, GATED, 1, 3, 2>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
+    }
+    if (S == 2 && Cout > 32 && wg2 >= 256 && ss::tuning().conv_s2_mt1 <= 0)
         return launch_bgm<S, NT, TD, TH, NTERMS, GATED, (S == 2) ? 2 : 1>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W,
                                                                           Cout, relu, st);
     return launch_bgm<S, NT, TD, TH, NTERMS, GATED, 1>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);

@@ -633,7 +633,9 @@ def test_classifier_channels_last_handoff_is_bit_identical(sa, shape, monkeypatc
 
 
 @pytest.mark.parametrize("nterms", [6, 19])
-@pytest.mark.parametrize("case", [(64, 128, 4, 7, 40), (32, 64, 6, 10, 34), (20, 40, 3, 5, 9), (64, 128, 16, 64, 64)])
+@pytest.mark.parametrize("case", [(64, 128, 4, 7, 40), (32, 64, 6, 10, 34), (20, 40, 3, 5, 9), (64, 128, 16, 64, 64),
+                                  # >= 256 workgroups: the form whose waves split the 64 channels of a workgroup (ragged channel groups, odd sizes)
+                                  (20, 72, 12, 100, 200), (33, 64, 13, 95, 129)])
 def test_conv3d_split_bf16_stride2(sa, case, nterms):
     """the stride-2 instantiation of the split-bf16 conv (odd sizes, ragged channels) against float64 and the exact-fp32 kernel"""
     import torch.nn.functional as F

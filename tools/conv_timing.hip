@@ -8,6 +8,11 @@ __device__ long long ss_dbg_steps_scratch;
 extern "C" int ss_debug_read(unsigned long long* dst, int n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ss_dbg_t), (size_t)n * 8) == hipSuccess ? 0 : -1;
 }
+extern "C" int ss_debug_reset() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ss_dbg_t)) != hipSuccess) return -1;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 8 * 16384) == hipSuccess ? 0 : -1;
+}
 #define SS_STAMP_ON (threadIdx.x == 0 && blockIdx.x < 16384 && blockIdx.y == 0 && blockIdx.z == 0)
 #define SS_STAMP(k) do { if (SS_STAMP_ON) ss_dbg_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #define SS_STAMP_STEPS_BEGIN() const long long ss_tk0 = __builtin_readcyclecounter()
