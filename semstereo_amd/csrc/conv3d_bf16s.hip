@@ -44,6 +44,15 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;
 constexpr int KSTEPS = 14;        // ceil(27 taps / 2): the 3-D kernels (BCfg::KSTEPS is the general form)
 // measured-best settings (each was swept on the bench shapes)
 constexpr int SS_IN_STEPS = 10;   // K-steps over which the next chunk's input loads are issued
+#ifndef SS_IN_STEPS_S2
+#define SS_IN_STEPS_S2 10         // ... in the stride-2 form (tools/build_variant.sh sweeps: 5: 94.0, 7: 89.1, 10: 87.9, 14: 86.5 us)
+#endif
+#ifndef SS_A_AHEAD_S2
+#define SS_A_AHEAD_S2 2           // SS_A_AHEAD / SS_ROW_PAIR of the stride-2 form (3, 4 steps ahead / row pairs: all within +-1.5 us of 90)
+#endif
+#ifndef SS_ROW_PAIR_S2
+#define SS_ROW_PAIR_S2 1
+#endif
 constexpr int SS_IN_AUX = 0;      // cache policy bits of the activation loads (buffer_load aux: 1 = sc0, 2 = nt)
 constexpr int SS_ROW_PAIR = 1;    // rows whose MFMAs alternate; 2 measured 1 % slower: the other wave of the SIMD already fills the gaps
 constexpr int SS_A_AHEAD = 2;     // K-steps between the load of a weight fragment and its MFMAs
@@ -144,6 +153,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const int cow = co0 + (wave % MS) * 32 * MT;                // this wave's first channel
     const int b = blockIdx.z;
     const int dzw = (wrow * NT) / TH, hy0 = (wrow * NT) % TH;
+    // (Stride 2: the 32 lanes of a fragment read are 32 bytes apart, a 2-way bank conflict per ds_read_b128 lane group.  Rows stored
+    // even columns first, then odd -- conflict-free reads, 2-way writes -- measured 88.7 / 89.6 us against 89.0 / 86.4: LDS is not
+    // what the stride-2 layers wait for (wait_inst_lds 1.9 % of wave cycles, profiles/r03_k_pmc_sq_conv_s2.txt); not kept.)
     const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + l31 * S;     // slot of this lane's first row, tap (0,0,0)
     auto tile_origin = [&](int tile, int& ow0, int& oh0, int& od0) {
         int t = tile;
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     constexpr int NQ = 8 * C::NPOS;
     // ... all of them within the first SS_IN_STEPS steps: the split phase at the end of the chunk waits
     // for the youngest slice, which needs a few K-steps (HBM latency) to land
-    constexpr int IN_STEPS = (SS_IN_STEPS < KSTEPS) ? SS_IN_STEPS : KSTEPS;
+    constexpr int IN_STEPS = ((S == 2 ? SS_IN_STEPS_S2 : SS_IN_STEPS) < KSTEPS) ? (S == 2 ? SS_IN_STEPS_S2 : SS_IN_STEPS) : KSTEPS;
     constexpr int QS = (NQ + IN_STEPS - 1) / IN_STEPS;
     float rin[NQ];
     int nlive = min(8, Cin), nlive_next = 8;                 // channels that exist in the staged / prefetched chunk
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const int G = ((Cin + 7) / 8) * KSTEPS;
     // Ring of weight fragments, AP steps ahead: vmcnt retires in order, so a wait for a fragment also
     // waits for every input (HBM) load issued before it -- the distance must cover HBM latency, not L2's.
-    constexpr int AP = SS_A_AHEAD, AR = AP + 1;
+    constexpr int AP = (S == 2) ? SS_A_AHEAD_S2 : SS_A_AHEAD, AR = AP + 1;
     uint4 aq[AR][MT][NC];                                      // aq[s % AR] = fragments of step s of the chunk
     if (!WLDS) {
 #pragma unroll
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 
         // B fragments are read one row GROUP ahead of their MFMAs.  With RP = 2 the MFMAs of two rows
         // alternate so that no two consecutive ones share an accumulator (SS_ROW_PAIR; no gain measured).
-        constexpr int RP = (NT >= 2) ? SS_ROW_PAIR : 1;
+        constexpr int RP = (NT >= 2) ? ((S == 2) ? SS_ROW_PAIR_S2 : SS_ROW_PAIR) : 1;
         static_assert(NT % RP == 0, "rows are processed in whole groups");
         uint4 bcur[RP][NC], bnxt[RP][NC];
         auto read_b = [&](uint4 (&dst)[NC], int s, int i) {
