@@ -130,11 +130,6 @@ int ss_stem_left_fwd(const float* q, const float* att, float* out, int B, int Co
  * row pair*64 + tap*2 + c is (scale *) W[2*pair + c, :C, tap] (rows 54-63 of every pair zero). */
 int ss_stem_left_fused_fwd(const float* left, const void* wsplit, const float* att, float* out, int B, int C,
                            int Cout, int nd, int H, int W, int nterms, ss_stream_t stream);
-/* The same result (bit-identical) with the projection of output channel c + 1 issued on the matrix core between the
- * multiply-adds of channel c (two Q buffers in LDS, one barrier per channel): wsplit = ss_pack_pointwise_weights_bf16s of
- * the [Cout * 32, C] matrix whose row co*32 + tap is (scale *) W[co, :C, tap] (rows 27-31 of every channel zero); any Cout. */
-int ss_stem_left_overlap_fwd(const float* left, const void* wsplit, const float* att, float* out, int B, int C,
-                             int Cout, int nd, int H, int W, int nterms, ss_stream_t stream);
 /* Fused form of models/SemStereo.py:291-292: mean over channels of left * warp(right):
  * x,y [B,C,H,W], disp [B,nd,H,W] -> [B,nd,H,W] */
 int ss_warp_correlation_fwd(const float* x, const float* y, const float* disp, float* out,

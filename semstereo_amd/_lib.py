@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 10
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -31,7 +31,6 @@ _SIGNATURES = {
     "ss_conv3d_presplit_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_stem_left_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_stem_left_fused_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "ss_stem_left_overlap_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_warp_correlation_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_disparity_regression_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ss_disparity_regression_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],

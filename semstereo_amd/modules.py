@@ -708,9 +708,6 @@ class ConcatFeature(nn.Sequential):
 
 
 STEM_LEFT_FUSED = os.environ.get("SS_STEM_LEFT_FUSED", "1") != "0"     # Q of the broadcast half on the fly (one launch) or through HBM (two)
-#: the fused launch with the projection of channel c + 1 issued between the multiply-adds of channel c (ss_stem_left_overlap_fwd;
-#: "0": the two-phase kernel, ss_stem_left_fused_fwd -- same bits)
-STEM_LEFT_OVERLAP = os.environ.get("SS_STEM_LEFT_OVERLAP", "1") != "0"
 
 
 def _stem_halves_params(stem, C):
@@ -727,12 +724,8 @@ def _stem_halves_params(stem, C):
         # fused form: per pair of output channels 64 rows, row tap*2 + c = channel 2*pair + c, rows 54-63 zero
         wf = torch.zeros(Cout // 2, 64, C, dtype=w.dtype, device=w.device)
         wf[:, :54] = wl.reshape(Cout // 2, 2, C, 27).permute(0, 3, 1, 2).reshape(Cout // 2, 54, C)
-        # overlapped form: per output channel 32 rows, row = tap, rows 27-31 zero
-        wo = torch.zeros(Cout, 32, C, dtype=w.dtype, device=w.device)
-        wo[:, :27] = wl.permute(0, 2, 1)
         return (pack_pointwise_weight_bf16s(wq), pack_pointwise_weight_bf16s(wf.reshape(Cout // 2 * 64, C)),
-                pack_conv_weight_bf16s(w[:, C:].contiguous(), _tiled_nterms()), sc, sh,
-                pack_pointwise_weight_bf16s(wo.reshape(Cout * 32, C)))
+                pack_conv_weight_bf16s(w[:, C:].contiguous(), _tiled_nterms()), sc, sh)
     return _cache(stem).get("bc/halves/" + CONV_ENGINE, srcs, build)
 
 
@@ -743,10 +736,8 @@ def stem_broadcast_half(stem, left, att):
     assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, left, att)
     C, Cout = left.shape[1], stem.conv.out_channels
     nterms = _aux_nterms()
-    wq, wf, _, _, _, wo = _stem_halves_params(stem, C)
+    wq, wf, _, _, _ = _stem_halves_params(stem, C)
     PATH_COUNTS["hip"] += 1
-    if C == 32 and STEM_LEFT_FUSED and STEM_LEFT_OVERLAP and Cout * att[0].numel() * 4 < 0x7fffffff:      # (32-bit offsets into one pair's output)
-        return ops.stem_left_overlap(left, wo, att, Cout, nterms)
     if C == 32 and Cout % 2 == 0 and STEM_LEFT_FUSED:
         return ops.stem_left_fused(left, wf, att, Cout, nterms)
     q = conv3d_pointwise_bf16s_hip(left, wq, 27 * Cout, None, None, False, nterms)               # [B, 27*Cout, H, W]
@@ -758,7 +749,7 @@ def stem_volume_half(stem, right_vol, partial, gate=None):
     and the optional channelAtt gate (`gate` [B,Cout,H,W]: the SIGMOID of the gate's logits) on the total."""
     assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, right_vol, partial, gate)
     nterms = _tiled_nterms()
-    _, _, wr, scale, shift, _ = _stem_halves_params(stem, right_vol.shape[1])
+    _, _, wr, scale, shift = _stem_halves_params(stem, right_vol.shape[1])
     g = None if gate is None else gate.contiguous()
     return conv3d_bf16s_hip(right_vol, wr, stem.conv.out_channels, scale, shift, bool(stem.relu), nterms, None, g, partial=partial)
 
@@ -780,7 +771,7 @@ def stem_volume_half_presplit(stem, xs, xexp, partial, gate=None):
     """stem_volume_half on the pre-split warped half (xs, xexp of ops.concat_volume_sampled_presplit)."""
     assert stem.is_3d and not stem.deconv and CONV_ENGINE == "f16x3" and _inference(stem, partial, gate)
     B, nchunks, _, D, H, W, _ = xs.shape
-    _, _, wr, scale, shift, _ = _stem_halves_params(stem, nchunks * 8)
+    _, _, wr, scale, shift = _stem_halves_params(stem, nchunks * 8)
     Cout = stem.conv.out_channels
     g = None if gate is None else gate.contiguous()
     dev = _lib.require_device(partial, scale, shift, g)

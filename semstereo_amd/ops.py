@@ -495,19 +495,6 @@ def stem_left_fused(left, wsplit, att, Cout, nterms=6):
     return out
 
 
-def stem_left_overlap(left, wsplit, att, Cout, nterms=6):
-    """stem_left_fused with the two phases overlapped (ss_stem_left_overlap_fwd): wsplit = the channel-major packed left-half
-    weights (32 rows per output channel, modules._stem_halves_params)."""
-    left = _c(left)
-    att = _c(att.reshape(att.shape[0], att.shape[-3], att.shape[-2], att.shape[-1]))
-    dev = _lib.require_device(left, att)
-    B, nd, H, W = att.shape
-    out = torch.empty((B, Cout, nd, H, W), dtype=left.dtype, device=left.device)
-    with torch.cuda.device(dev):
-        call("ss_stem_left_overlap_fwd", ptr(left), ptr(wsplit), ptr(att), ptr(out), B, left.shape[1], Cout, nd, H, W, int(nterms))
-    return out
-
-
 def warp_correlation(x, y, disparity_samples):
     """Fused models/SemStereo.py:291-292: mean over channels of x * warp(y) -> [B, nd, H, W].
     Inference only."""

@@ -504,18 +504,6 @@ def test_stem_by_halves_equals_the_full_convolution(sa, shape):
             assert float((yy.double().cpu() - ref).abs().max()) <= 2.0 * e_full + 1e-6, flag
     finally:
         sa.modules.STEM_LEFT_FUSED = old
-    # the overlapped launch (projection of channel c + 1 between the multiply-adds of channel c) and the two-phase launch: same bits
-    outs = []
-    old = sa.modules.STEM_LEFT_OVERLAP
-    try:
-        for flag in (True, False):
-            sa.modules.STEM_LEFT_OVERLAP = flag
-            with torch.no_grad():
-                outs.append(sa.modules.stem_broadcast_half(stem, dev(left), dev(att)))
-    finally:
-        sa.modules.STEM_LEFT_OVERLAP = old
-    assert torch.equal(outs[0], outs[1])
-    assert float((outs[0].double().cpu() - want).abs().max()) <= 2e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 24, 9, 37), (1, 32, 6, 5, 70), (1, 32, 32, 3, 3), (1, 32, 24, 40, 96), (1, 32, 6, 13, 65)])
