@@ -28,7 +28,7 @@ inline hipStream_t as_stream(ss_stream_t s) { return reinterpret_cast<hipStream_
 // runs -- and again only when ss_reload_tuning() is called.  -1 = not set (the measured-best automatic choice).
 struct Tuning {
     int conv_tile;        // SS_CONV_TILE   0..2: force a tile candidate of the conv kernels
-    int conv_s2_mt1;      // SS_CONV_S2_MT1 set: stride-2 convs with one output tile per wave
+    int conv_s2_mt1;      // SS_CONV_S2_MT1 (tuning aid): unset = the waves of a workgroup split its 64 channels; 0 = two channel tiles per wave (r02); 1 = one
     int gwc_stream;       // SS_GWC_STREAM  0/1: plain / nontemporal stores of the gwc volume
     int warp_stream;      // SS_WARP_STREAM 0/1
     int warp_vec4;        // SS_WARP_VEC=4
