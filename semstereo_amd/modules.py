@@ -234,9 +234,11 @@ DECONV_F16 = os.environ.get("SS_DECONV_F16", "1") != "0"        # f16x3 engine: 
 
 def _deconv_nterms():
     return _NTERMS_TILED[CONV_ENGINE] if DECONV_F16 else _NTERMS_AUX[CONV_ENGINE]
-#: transposed convs with fewer workgroups than this run on the exact-fp32 kernel, whose even/odd-plane split doubles them
-#: (bf16x6 at 128 workgroups: 88 vs 67 us; the fp16 form: 66 vs 72 us -- 6 us, not worth trading an exact layer for)
-DECONV_MIN_WORKGROUPS = int(os.environ.get("SS_DECONV_MIN_WGS", "256"))
+#: transposed convs with fewer workgroups than this run on the exact-fp32 kernel, whose even/odd-plane split doubles them.
+#: 0 since r03: on the one layer of the bench shape below 256 workgroups (hourglass_att.conv5, 128) the split engine's kernel has
+#: overtaken it (step 2.117 -> 2.093 ms, 2.119 -> 2.085 on a second box), and the engine of a layer no longer depends on the
+#: batch size (r01: bf16x6 at 128 workgroups 88 vs 67 us, the fp16 form 66 vs 72 us)
+DECONV_MIN_WORKGROUPS = int(os.environ.get("SS_DECONV_MIN_WGS", "0"))
 DECONV_BF16S = os.environ.get("SS_DECONV_BF16S", "1") != "0"     # transposed convs on the split engine too (else exact fp32 MFMA)
 
 
