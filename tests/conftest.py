@@ -34,3 +34,12 @@ def tuning_env(monkeypatch):
     yield setenv
     monkeypatch.undo()
     lib.ss_reload_tuning()
+
+
+@pytest.fixture
+def deferral_on(monkeypatch):
+    """Tests ABOUT the deferred handles (which rules fire under an untouched forward()) switch them on for their duration,
+    whatever SS_DEFER says: the rest of the suite honours the switch."""
+    from semstereo_amd import deferred as dfr
+    monkeypatch.setattr(dfr, "ENABLED", True)
+    return dfr

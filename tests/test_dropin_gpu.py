@@ -42,7 +42,7 @@ def _images(B=1, H=128, W=160):
 
 
 @pytest.mark.parametrize("att_only", [False, True])
-def test_fused_forward_equals_untouched_forward(sa, att_only):
+def test_fused_forward_equals_untouched_forward(sa, att_only, deferral_on):
     net, module = _build(sa, att_weights_only=att_only)
     left, right = _images()
     previous = sa.install(module)
@@ -132,7 +132,7 @@ def test_data_parallel_replicas_run_their_own_forward_in_two_threads(sa):
     sa.restore_forward(net)
 
 
-def test_data_parallel_replicas_with_the_untouched_forward(sa):
+def test_data_parallel_replicas_with_the_untouched_forward(sa, deferral_on):
     """The reference's own multi-GPU form (nn.DataParallel, test_us3d.py:58) on a model that was only install()ed and
     accelerate()d -- forward() untouched, no fuse_forward: each replica's thread builds its own deferred handles (they are
     per-call objects; deferral state is thread-local), every fused rule fires once per replica and call, the replicas pack
