@@ -2,7 +2,7 @@
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
 usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low attn attn_att warp ssr ssr2048 strength topk
-                                                               catt8 catt4 upsoft stem_left stem conv_s1 conv_s2 deconv"""
+                                                               catt8 catt4 upsoft stem_left stem conv_s1 conv_s2 conv_s2_att deconv"""
 import os
 import sys
 import time
@@ -115,6 +115,12 @@ elif name == "stem":             # the dominant launch: concat_stem on the warpe
     sc, sh = torch.rand(32, device=dev) + 0.5, R(32) * 0.1
     fn = lambda: M.conv3d_bf16s_hip(x, ws, 32, sc, sh, True, 19, None, gate, partial=part)       # noqa: E731
     nbytes = 4.0 * B * (3 * 32 * 24 + 32) * 256 * 256
+elif name == "conv_s2_att":      # hourglass_att.conv3: 64 -> 128 stride 2 on [16,64,64] (256 workgroups: the one-tile-per-wave form)
+    x = torch.relu(R(B, 64, 16, 64, 64))
+    ws = M.pack_conv_weight_bf16s(R(128, 64, 3, 3, 3) * 0.03, 19)
+    sc, sh = torch.rand(128, device=dev) + 0.5, R(128) * 0.1
+    fn = lambda: M.conv3d_bf16s_hip(x, ws, 128, sc, sh, True, 19, stride=2)       # noqa: E731
+    nbytes = 4.0 * B * (64 * 16 * 64 * 64 + 128 * 8 * 32 * 32)
 elif name in ("conv_s2", "conv_s1", "deconv"):
     if name == "deconv":            # hourglass2.conv6: 64 -> 32 to [24,256,256] with the 1x1x1 skip projection of a 32-channel volume
         hg = M.hourglass2(32).to(dev).eval()
