@@ -50,6 +50,9 @@ constexpr int SS_IN_STEPS = 10;   // K-steps over which the next chunk's input l
 #ifndef SS_A_AHEAD_S2
 #define SS_A_AHEAD_S2 2           // SS_A_AHEAD / SS_ROW_PAIR of the stride-2 form (3, 4 steps ahead / row pairs: all within +-1.5 us of 90)
 #endif
+#ifndef SS_S2_MS_MIN_WGS
+#define SS_S2_MS_MIN_WGS 256      // stride 2: fewest 64-channel workgroups for which the waves split the channels (below: one 32-channel tile per workgroup; 128 on the 128-workgroup layer: 29.5 vs 26.4 us)
+#endif
 #ifndef SS_ROW_PAIR_S2
 #define SS_ROW_PAIR_S2 1
 #endif
@@ -669,7 +672,7 @@ int launch_bg(const float* in, const void* wsplit, const float* scale, const flo
     // ... and, since r03, the 64 channels split over the waves (MS = 2: wave = (row pair, 32 channels)) instead of two channel
     // tiles per wave: the same MFMAs and staging with half the weight-fragment fetches (SS_CONV_S2_MT1=0: the r02 form)
     if constexpr (S == 2 && NT == 1 && TD * TH == 4 && !GATED) {      // (no layer gates a stride-2 conv; its MS form would spill)
-        if (Cout > 32 && wg2 >= 256 && ss::tuning().conv_s2_mt1 < 0)
+        if (Cout > 32 && wg2 >= SS_S2_MS_MIN_WGS && ss::tuning().conv_s2_mt1 < 0)
             return launch_bgm<S, 2, TD, TH, NTERMS, GATED, 1, 3, 2>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
     }
     if (S == 2 && Cout > 32 && wg2 >= 256 && ss::tuning().conv_s2_mt1 <= 0)
