@@ -57,6 +57,9 @@ constexpr int SS_IN_STEPS = 10;   // K-steps over which the next chunk's input l
 #define SS_ROW_PAIR_S2 1
 #endif
 constexpr int SS_IN_AUX = 0;      // cache policy bits of the activation loads (buffer_load aux: 1 = sc0, 2 = nt)
+#ifndef SS_IN_AUX_GATED
+#define SS_IN_AUX_GATED 0         // ... of the gated launch (concat_stem), whose inputs -- warped half, partial sum -- are dead after it (nt / sc0+nt measured on the whole step: 479.5 / 476 against 489.6 pairs/s on one box: the launch itself 284 -> 334 / 344 us)
+#endif
 constexpr int SS_ROW_PAIR = 1;    // rows whose MFMAs alternate; 2 measured 1 % slower: the other wave of the SIMD already fills the gaps
 constexpr int SS_A_AHEAD = 2;     // K-steps between the load of a weight fragment and its MFMAs
 constexpr int SS_F16_WGS = 2;     // workgroups per CU the fp16 form is compiled for (3 = 168 VGPRs: spills, +29 %)
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, wlane[mt], g * wstep + c * 2 * Cout * 16, 0));
     };
     auto load_in = [&](int ch, int i) {                                       // channel ch (absolute), position slot i
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, SS_IN_AUX));
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)poff[i], ch * chan_b, GATED ? SS_IN_AUX_GATED : SS_IN_AUX));
     };
     const int G = ((Cin + 7) / 8) * KSTEPS;
     // Ring of weight fragments, AP steps ahead: vmcnt retires in order, so a wait for a fragment also
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
             for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q)
                 rin[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                       ires, (int)(poff[q % C::NPOS] | nomore), (ch_next + min(q / C::NPOS, max(nlive_next, 1) - 1)) * chan_b, SS_IN_AUX));
+                                                       ires, (int)(poff[q % C::NPOS] | nomore), (ch_next + min(q / C::NPOS, max(nlive_next, 1) - 1)) * chan_b, GATED ? SS_IN_AUX_GATED : SS_IN_AUX));
             uint4 a[MT][NC];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
                     rv[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                             rres, (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, 0));
+                                                             rres, (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, GATED ? SS_IN_AUX_GATED : 0));
             }
         } else {
 #pragma unroll
