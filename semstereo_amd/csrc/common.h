@@ -59,8 +59,24 @@ __host__ __device__ inline long long ceil_div_ll(long long a, long long b) { ret
 
 // Unfused multiply / add (the reference materialises the product tensor, i.e. rounds it,
 // before reducing; keeping the two roundings makes several kernels bit-identical to it).
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+// hipcc's __fmul_rn / __fadd_rn are plain `a * b` / `a + b` (clang's __clang_hip_math.h without OCML_BASIC_ROUNDED_OPERATIONS)
+// and HIP compiles with -ffp-contract=fast-honor-pragmas: through them a product was still fused into the add or subtract
+// that consumed it (found r04 in the ISA of the warp kernels: `ix - floor(ix)` became fma(t, half_w, -floor(ix)) on the
+// UNROUNDED product, which moved the bilinear weights by ~1e-5 at W = 256 and put the HIP path 2-3x further from the float64
+// answer than the reference's own CPU arithmetic).  The contract(off) pragma takes the `contract` flag off these two
+// instructions, so neither can become half of an fma after inlining.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
 // exp(x) for finite x <= ~88 to ~1.5 ulp in 6 VALU ops: 2^(x*log2e) on the hardware exp2 (v_exp_f32, 1 ulp),
 // with the rounding error of the product and the low bits of log2(e) carried as a first-order correction
 // (a plain __expf loses |x| * 6e-8 relative there).  Not for x = -inf (use expf).

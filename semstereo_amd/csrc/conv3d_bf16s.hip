@@ -368,6 +368,16 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         const int ch_next = more ? ci0 + 8 : 0;
         const unsigned nomore = (more || has_next) ? 0u : 0x80000000u;
         SS_STAMP_STEPS_BEGIN();
+#ifdef SS_ACC_BLOCKED
+        f32x16 tacc[MT * NT];
+#pragma unroll
+        for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tacc[i][r] = 0.f;
+#define SS_ACC tacc
+#else
+#define SS_ACC acc
+#endif
 
         // B fragments are read one row GROUP ahead of their MFMAs.  With RP = 2 the MFMAs of two rows
         // alternate so that no two consecutive ones share an accumulator (SS_ROW_PAIR; no gain measured).
@@ -433,13 +443,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
                         for (int r = 0; r < RP; ++r) {
                             if (F16)
-                                acc[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                SS_ACC[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                     __builtin_bit_cast(f16x8, a[mt][pa[p]]), __builtin_bit_cast(f16x8, bcur[r][pb[p]]),
-                                    acc[mt * NT + i0 + r], 0, 0, 0);
+                                    SS_ACC[mt * NT + i0 + r], 0, 0, 0);
                             else
-                                acc[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                SS_ACC[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                     __builtin_bit_cast(bf16x8, a[mt][pa[p]]), __builtin_bit_cast(bf16x8, bcur[r][pb[p]]),
-                                    acc[mt * NT + i0 + r], 0, 0, 0);
+                                    SS_ACC[mt * NT + i0 + r], 0, 0, 0);
                         }
 #pragma unroll
                 for (int r = 0; r < RP; ++r)
@@ -469,6 +479,12 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
                     for (int c = 0; c < NC; ++c) aq[k][mt][c] = tq[k][mt][c];
         }
+#ifdef SS_ACC_BLOCKED
+#pragma unroll
+        for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] += tacc[i][r];
+#endif
         nlive = nlive_next;
         SS_STAMP_STEPS_END();
         if (F16 && (more || has_next)) publish_max(0.f);       // of the chunk staged next (its loads were issued >= 4 K-steps ago)

@@ -11,6 +11,9 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from semstereo_amd import _lib  # noqa: E402
+if os.environ.get("SS_TOOL_LIB"):          # experimental builds of the library (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["SS_TOOL_LIB"])
 from semstereo_amd import modules as M  # noqa: E402
 
 small = len(sys.argv) > 1 and sys.argv[1] == "small"

@@ -12,6 +12,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+from semstereo_amd import _lib  # noqa: E402
+if os.environ.get("SS_TOOL_LIB"):          # experimental builds of the library (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["SS_TOOL_LIB"])
 import semstereo_amd as sa  # noqa: E402
 from semstereo_amd import deferred as _dfr  # noqa: E402
 _dfr.ENABLED = False
