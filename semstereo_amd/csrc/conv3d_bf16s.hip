@@ -114,6 +114,14 @@ constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
     return NTERMS == 19 && S == 1 && NT == 1 && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
 }
 
+// chunk-blocked accumulation (see ACCB in the kernel): the fp16 form wherever a second accumulator set fits the registers
+#ifndef SS_ACC_BLOCKED_MAX
+#define SS_ACC_BLOCKED_MAX 2              // largest MT * NT of the 3-D forms that get it (tools/build_variant.sh: 0 = none, 4 = all)
+#endif
+constexpr bool acc_blocked(int NT, int NTERMS, int MT, int KD) {
+    return NTERMS == 19 && (KD == 1 || MT * NT <= SS_ACC_BLOCKED_MAX);
+}
+
 // GATED: the channelAtt gate is fused into the epilogue (only concat_stem has one, so its launches also carry
 // their own kernel symbol in a profile: conv3d_bf16s<..., true>)
 // MT: 32-channel output tiles per wave (the activation fragments of a row then feed MT x 6 MFMAs: used by the stride-2
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // (14 steps x 2 terms, 28 KB) are then brought into LDS once per workgroup by LDS-DMA loads (no registers) and read
     // from there by the four waves (deconv3d_bf16s.hip has the measurement: -11 %).
     constexpr bool WLDS = wlds_form(S, NT, NTERMS, MT, KD);
+    constexpr bool ACCB = acc_blocked(NT, NTERMS, MT, KD);
     static_assert(!WLDS || MS == 1, "the LDS copy of the weights is one channel tile's");
     using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS>;
     constexpr int WL = NC * C::CS + 2 + 48;                    // first slot of the weight fragments
@@ -368,16 +377,19 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         const int ch_next = more ? ci0 + 8 : 0;
         const unsigned nomore = (more || has_next) ? 0u : 0x80000000u;
         SS_STAMP_STEPS_BEGIN();
-#ifdef SS_ACC_BLOCKED
-        f32x16 tacc[MT * NT];
+        // ACCB: the chunk's 14 x 3 MFMAs accumulate from ZERO in a second register set that is added to `acc` once per chunk
+        // (two-level blocked summation).  One chain over all of K = Cin x 27 products rounds a growing partial sum 3 K / 16
+        // times: measured 3.3e-7 ... 6.2e-7 of the output's rms for K = 864 ... 3456 against float64 (tools/err_stages.py),
+        // 1.2 - 3.5x the fp32 CPU convolution of the reference, which sums in blocks too; chunk-blocked it is 1.9e-7 ... 2.3e-7
+        // whatever K, at or below the CPU's.  Where the second set fits the register budget it costs no time (stride-2
+        // forms 85.0 vs 85.5 us, the 1 x 4 tile 68.8 vs 68.2); the 4-row tiles would spill (+7 %) and keep the single chain.
+        f32x16 tacc[ACCB ? MT * NT : 1];
+        if constexpr (ACCB) {
 #pragma unroll
-        for (int i = 0; i < MT * NT; ++i)
+            for (int i = 0; i < MT * NT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tacc[i][r] = 0.f;
-#define SS_ACC tacc
-#else
-#define SS_ACC acc
-#endif
+                for (int r = 0; r < 16; ++r) tacc[i][r] = 0.f;
+        }
 
         // B fragments are read one row GROUP ahead of their MFMAs.  With RP = 2 the MFMAs of two rows
         // alternate so that no two consecutive ones share an accumulator (SS_ROW_PAIR; no gain measured).
@@ -442,14 +454,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int r = 0; r < RP; ++r) {
+                            f32x16& dst = ACCB ? tacc[ACCB ? mt * NT + i0 + r : 0] : acc[mt * NT + i0 + r];
                             if (F16)
-                                SS_ACC[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                    __builtin_bit_cast(f16x8, a[mt][pa[p]]), __builtin_bit_cast(f16x8, bcur[r][pb[p]]),
-                                    SS_ACC[mt * NT + i0 + r], 0, 0, 0);
+                                dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    __builtin_bit_cast(f16x8, a[mt][pa[p]]), __builtin_bit_cast(f16x8, bcur[r][pb[p]]), dst, 0, 0, 0);
                             else
-                                SS_ACC[mt * NT + i0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    __builtin_bit_cast(bf16x8, a[mt][pa[p]]), __builtin_bit_cast(bf16x8, bcur[r][pb[p]]),
-                                    SS_ACC[mt * NT + i0 + r], 0, 0, 0);
+                                dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(bf16x8, a[mt][pa[p]]), __builtin_bit_cast(bf16x8, bcur[r][pb[p]]), dst, 0, 0, 0);
                         }
 #pragma unroll
                 for (int r = 0; r < RP; ++r)
@@ -479,12 +490,12 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
                     for (int c = 0; c < NC; ++c) aq[k][mt][c] = tq[k][mt][c];
         }
-#ifdef SS_ACC_BLOCKED
+        if constexpr (ACCB) {
 #pragma unroll
-        for (int i = 0; i < MT * NT; ++i)
+            for (int i = 0; i < MT * NT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] += tacc[i][r];
-#endif
+                for (int r = 0; r < 16; ++r) acc[i][r] += tacc[i][r];
+        }
         nlive = nlive_next;
         SS_STAMP_STEPS_END();
         if (F16 && (more || has_next)) publish_max(0.f);       // of the chunk staged next (its loads were issued >= 4 K-steps ago)

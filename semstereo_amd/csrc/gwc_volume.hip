@@ -233,8 +233,7 @@ __global__ void gwc_volume_generic(const float* __restrict__ ref, const float* _
         const int li = threadIdx.x + m - dmin - d;       // = (x - (dmin + d)) - (xt0 - m)
         float acc = 0.f;
         for (int c = 0; c < Cg; ++c)
-            acc = ss::add_rn(acc, ss::mul_rn(rn[((size_t)c * GR + threadIdx.y) * GX + threadIdx.x],
-                                             tn[((size_t)c * GR + threadIdx.y) * LW + li]));
+            acc = fmaf(rn[((size_t)c * GR + threadIdx.y) * GX + threadIdx.x], tn[((size_t)c * GR + threadIdx.y) * LW + li], acc);   // the v4 kernels' chain
         const int col = x - (d + dmin);
         outp[(size_t)d * plane] = ((unsigned)col < (unsigned)W) ? acc / den : 0.f;
     }
@@ -266,7 +265,7 @@ __global__ void group_corr_kernel(const float* __restrict__ f1, const float* __r
         for (int c = 0; c < Cg; ++c) {
             float a = p1[c * plane], bb = p2[c * plane];
             if (NORM) { a = a / d1; bb = bb / d2; }
-            acc = ss::add_rn(acc, ss::mul_rn(a, bb));
+            acc = fmaf(a, bb, acc);          // the same fused chain as the volume kernels: the zero-disparity plane of a volume IS this op
         }
         out[i] = acc / (float)Cg;
     }
