@@ -15,6 +15,9 @@ from . import ops, stack
 TOPK = 24  # models/SemStereo.py:301
 
 
+GWC_CLOSED_FORM = False      # True: ops.build_gwc_volume_norm_closed_form (bit-identical, 200x faster on the CPU) at :273
+
+
 def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None, unsigned=False):
     """models/SemStereo.py:273-310.  Returns (att_topk [B,1,k,H4,W4],
     disparity_sample_topk [B,k,H4,W4], pred_att [B,H4,W4]).
@@ -35,7 +38,8 @@ def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None, unsigned=False):
         pred0 = uops.disparity_regression(prob0, m4)
         var = uops.disparity_variance(prob0, m4, pred0.unsqueeze(1))
         return _attention_tail(P, fl4, fr4, att_weights, pred0, var, 0, out, corr, cost_att)
-    corr = ops.build_gwc_volume_norm(fl8, fr8, maxdisp // 8, C8 // 8)                  # :273
+    gwc = ops.build_gwc_volume_norm_closed_form if GWC_CLOSED_FORM else ops.build_gwc_volume_norm
+    corr = gwc(fl8, fr8, maxdisp // 8, C8 // 8)                                        # :273
     corr = stack.patch_conv(P, corr)                                                   # :274
     cost_att = stack.channel_att(P, "corr_feature_att_8", corr, fl8)                   # :276
     cost_att = stack.hourglass(P, "hourglass_att", cost_att, (4, 4, 4))                # :277

@@ -64,6 +64,21 @@ def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups):
     return _gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups, groupwise_correlation_norm)
 
 
+def build_gwc_volume_norm_closed_form(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """The same volume as build_gwc_volume_norm with both maps normalised ONCE (the slice loop of models/submodule.py:224-238
+    re-normalises the same pixels 2 * maxdisp times: 7 s of its 9 s on the bench shape).  Every operation is per pixel, so the
+    result is bit-identical (tests/test_oracle_golden.py pins that on the fixtures' shapes); used where many pairs are evaluated
+    (bench.py's seeded-pairs parity leg) -- the timed CPU baseline keeps the reference's own loop."""
+    B, C, H, W = refimg_fea.shape
+    assert C % num_groups == 0
+    cg = C // num_groups
+
+    def unit(f):
+        v = f.reshape(B, num_groups, cg, H, W)
+        return (v / (torch.linalg.vector_norm(v, 2, dim=2, keepdim=True) + 1e-05)).reshape(B, C, H, W)
+    return _gwc_volume(unit(refimg_fea), unit(targetimg_fea), maxdisp, num_groups, groupwise_correlation)
+
+
 def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
     """models/submodule.py:173-187: channels [0,C) = left feature, [C,2C) =
     right feature shifted by d; BOTH halves are zero where x-d is outside."""

@@ -114,13 +114,16 @@ constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
     return NTERMS == 19 && S == 1 && NT == 1 && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
 }
 
-// chunk-blocked accumulation (see ACCB in the kernel): the fp16 form wherever a second accumulator set fits the registers
-#ifndef SS_ACC_BLOCKED_MAX
-#define SS_ACC_BLOCKED_MAX 2              // largest MT * NT of the 3-D forms that get it (tools/build_variant.sh: 0 = none, 4 = all)
+// Chunk-blocked accumulation (ACCB of the kernel) is a property of the LAYER, never of the tile a launch happens to get: the
+// tile candidates depend on the batch size, and a pair must get the same bits alone and in a batch
+// (test_hot_segment_batch_invariance_at_the_sharded_batch_sizes).  fp16 form only.  It is on for every stride-2 layer, every
+// 2-D layer, and the stride-1 3-D layers that at batch 1 are too small for the 4-row tile -- the deep, narrow layers with the
+// longest K (conv2 / conv4 of the hourglasses: K = 1728 / 3456): there the second accumulator set fits the registers of the 1- and
+// 2-row tiles they run on at small batch; when a larger batch moves them onto the 4-row tile that variant spills 16 registers
+// (+7 %, measured on the stem shape).  The big 4-row layers (concat_stem, classif.0, hourglass2.conv2) keep the single chain.
+#ifndef SS_ACC_BLOCKED
+#define SS_ACC_BLOCKED 1                  // 0: single chains everywhere (tools/build_variant.sh, for A/B measurements)
 #endif
-constexpr bool acc_blocked(int NT, int NTERMS, int MT, int KD) {
-    return NTERMS == 19 && (KD == 1 || MT * NT <= SS_ACC_BLOCKED_MAX);
-}
 
 // GATED: the channelAtt gate is fused into the epilogue (only concat_stem has one, so its launches also carry
 // their own kernel symbol in a profile: conv3d_bf16s<..., true>)
@@ -132,7 +135,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // fetches the weight fragments of ITS channels only (the vector L1 carried every fragment four times per workgroup: 32 KB
 // per K-step and CU beside 8 KB of activations, 640 clocks at its 64 B/clk for 384 clocks of MFMA issue -- tools/wg_phases_s2.py)
 // and reads the activation fragments of two rows from LDS instead of one.
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1>
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false>
 __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // (14 steps x 2 terms, 28 KB) are then brought into LDS once per workgroup by LDS-DMA loads (no registers) and read
     // from there by the four waves (deconv3d_bf16s.hip has the measurement: -11 %).
     constexpr bool WLDS = wlds_form(S, NT, NTERMS, MT, KD);
-    constexpr bool ACCB = acc_blocked(NT, NTERMS, MT, KD);
+    static_assert(!ACCB || NTERMS == F16X3, "chunk-blocked accumulation: fp16 form only");
     static_assert(!WLDS || MS == 1, "the LDS copy of the weights is one channel tile's");
     using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS>;
     constexpr int WL = NC * C::CS + 2 + 48;                    // first slot of the weight fragments
@@ -665,7 +668,7 @@ __global__ void pack_weights_f16s_kernel(const float* __restrict__ w, unsigned s
     wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
 }
 
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1>
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false>
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
     using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2, wlds_form(S, NT, NTERMS, MT, KD) ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS>;
@@ -673,7 +676,7 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD, MS>;
+    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD, MS, ACCB>;
     if (C::LDS_BYTES > 64 * 1024) {
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
@@ -692,7 +695,7 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
     return ss::check_launch();
 }
 
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED>
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, bool ACCB>
 int launch_bg(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
     // stride 2: two output tiles per wave (the activation staging is then shared: 154 vs 191 us on the largest layer)
@@ -703,20 +706,27 @@ int launch_bg(const float* in, const void* wsplit, const float* scale, const flo
     // tiles per wave: the same MFMAs and staging with half the weight-fragment fetches (SS_CONV_S2_MT1=0: the r02 form)
     if constexpr (S == 2 && NT == 1 && TD * TH == 4 && !GATED) {      // (no layer gates a stride-2 conv; its MS form would spill)
         if (Cout > 32 && wg2 >= SS_S2_MS_MIN_WGS && ss::tuning().conv_s2_mt1 < 0)
-            return launch_bgm<S, 2, TD, TH, NTERMS, GATED, 1, 3, 2>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
+            return launch_bgm<S, 2, TD, TH, NTERMS, GATED, 1, 3, 2, ACCB>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
     }
     if (S == 2 && Cout > 32 && wg2 >= 256 && ss::tuning().conv_s2_mt1 <= 0)
-        return launch_bgm<S, NT, TD, TH, NTERMS, GATED, (S == 2) ? 2 : 1>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W,
-                                                                          Cout, relu, st);
-    return launch_bgm<S, NT, TD, TH, NTERMS, GATED, 1>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
+        return launch_bgm<S, NT, TD, TH, NTERMS, GATED, (S == 2) ? 2 : 1, 3, 1, ACCB>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W,
+                                                                                      Cout, relu, st);
+    return launch_bgm<S, NT, TD, TH, NTERMS, GATED, 1, 3, 1, ACCB>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
 }
 
 template <int S, int NT, int TD, int TH, int NTERMS>
 int launch_b(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
-             const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
+             const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, bool accb, hipStream_t st) {
+    if constexpr (NTERMS == F16X3) {
+        if (accb) {
+            if (gate != nullptr)
+                return launch_bg<S, NT, TD, TH, NTERMS, true, true>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
+            return launch_bg<S, NT, TD, TH, NTERMS, false, true>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
+        }
+    }
     if (gate != nullptr)
-        return launch_bg<S, NT, TD, TH, NTERMS, true>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
-    return launch_bg<S, NT, TD, TH, NTERMS, false>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
+        return launch_bg<S, NT, TD, TH, NTERMS, true, false>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
+    return launch_bg<S, NT, TD, TH, NTERMS, false, false>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
 }
 
 }  // namespace
@@ -765,10 +775,13 @@ static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* s
     const int forced = ss::tuning().conv_tile;
     int tile = (blocks(2, 8) >= 512) ? 0 : ((blocks(1, 8) >= 512) ? 1 : 2);
     if (forced >= 0 && forced <= 2) tile = forced;
+    // chunk-blocked accumulation: decided by the LAYER (what ONE pair of it offers the chip), not by this launch's batch or tile
+    const bool small_layer = blocks(2, 8) / B < 512;
+    const bool accb = SS_ACC_BLOCKED && nterms == F16X3 && (stride == 2 || small_layer);
 #define SS_B(S, NT, TD, TH)                                                                                              \
-    return (nterms == 6) ? launch_b<S, NT, TD, TH, 6>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st) \
-         : (nterms == 3) ? launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st) \
-                         : launch_b<S, NT, TD, TH, F16X3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st)
+    return (nterms == 6) ? launch_b<S, NT, TD, TH, 6>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, accb, st) \
+         : (nterms == 3) ? launch_b<S, NT, TD, TH, 3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, accb, st) \
+                         : launch_b<S, NT, TD, TH, F16X3>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, accb, st)
     // stride 2 needs a 65-column halo tile per row.  A 1 x 4 output tile is 84 KB of split operands: one workgroup per
     // CU, slower than the exact-fp32 kernel (283 vs 229 us on the largest layer).  A 2 x 2 tile is 78 KB: two
     // workgroups per CU, faster on every stride-2 layer of the model (190 / 95 / 68 / 41 us vs 229 / 122 / 81 / 62).
@@ -834,7 +847,7 @@ extern "C" int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const fl
 #define SS_B2(NT, TH)                                                                                                      \
     return (nterms == 6) ? launch_bgm<1, NT, 1, TH, 6, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st) \
          : (nterms == 3) ? launch_bgm<1, NT, 1, TH, 3, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st) \
-                         : launch_bgm<1, NT, 1, TH, F16X3, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st)
+                         : launch_bgm<1, NT, 1, TH, F16X3, false, 1, 1, 1, SS_ACC_BLOCKED != 0>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st)
     if (blocks(16) >= 512) { SS_B2(4, 16); }
     if (blocks(8) >= 512) { SS_B2(2, 8); }
     SS_B2(1, 4);

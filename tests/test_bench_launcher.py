@@ -32,6 +32,13 @@ def test_self_launch_two_ranks_prints_one_json_line():
     assert res["n_gpus"] == 2 and res["steps"] == 4 and res["warmup"] == 1 and res["dry_launch"] is True
     assert res["pairs_counted"] == 2 * 4 * 4            # SUM over both ranks of batch x steps
     assert res["ms_per_step"] > 0
+    # what makes a SCALE run self-verifying: the group's size as torch.distributed reports it, every rank's own
+    # rate, and the bytes of the one collective that follows the forward
+    d = res["dist"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo"
+    assert len(d["per_rank_pairs_per_s"]) == 2 and all(r > 0 for r in d["per_rank_pairs_per_s"])
+    assert d["all_gather_payload_bytes"] > 0 and d["all_gather_shape"][0] == 2 * 4
+    assert res["steady_state"]["steps"] >= 4 and res["steady_state"]["pairs_per_s"] > 0
 
 
 def test_self_launch_fails_when_a_rank_fails():

@@ -277,16 +277,16 @@ def test_hot_segment_full_size_vs_reference_checksums(sa, golden, name):
     assert not bool(bad.any()), f"{int(bad.sum())} pixel(s) select other candidates where the reference's margin is >= {DELTA24_REL}"
     bad = (err_att > 1e-3) & ~differs
     assert not bool(bad.any()), f"pred_att off by up to {float(err_att[bad].max()):.2e} on {int(bad.sum())} pixel(s) with the reference's candidates"
-    # (ii) pred: outside the receptive field of a differing pixel and away from ties of the reference's costs, no pixel may
-    # show a wrong pick (a whole-candidate move: >= 0.1 px) and the mean must be far inside the 1e-3 px target.  The per-pixel
-    # bound is the soft-argmax's own conditioning: with calibrated statistics the two kept costs differ by O(1) and their
-    # candidates by up to D4 - 1 disparities, so a cost error of 3e-5 (fp32 accumulation over K = 864 products, 13 layers)
-    # moves `pred` by up to 3e-5 * (D4 - 1) / 4 * ... : 1e-3 px at D4 = 64, 3e-3 px at D4 = 96 (measured 5.5e-4 / 1.6e-3)
-    bound = 1e-3 if 2 * m4 <= 64 else 3e-3
+    # (ii) pred: outside the receptive field of a differing pixel and away from ties of the reference's costs, every pixel
+    # within 1e-3 px at BOTH sizes and the mean far inside it.  (Until r04 the bound was 3e-3 at D4 = 96 and the measured worst
+    # pixel 1.6e-3: that was the warp kernels' contracted coordinate arithmetic, not the soft-argmax's conditioning -- with it
+    # fixed the default engine measures 1.1e-4 / 1.9e-4 at 1024^2 / 2048^2.)
+    default_engine = sa.modules.CONV_ENGINE == "f16x3"
+    bound = 5e-4 if default_engine else 1e-3
     bad = (err > bound) & clean
     assert not bool(bad.any()), (f"pred off by up to {float(err[bad].max()):.2e} px on {int(bad.sum())} pixel(s) with no tie in the "
                                  f"reference's costs and no differing candidate set within {RF_RADIUS} px")
-    assert float(err[clean].mean()) <= 1e-4 and float(err.median()) <= 1e-4
+    assert float(err[clean].mean()) <= (3e-5 if default_engine else 1e-4) and float(err.median()) <= 1e-4
 
 
 @pytest.mark.parametrize("name", sorted(cases.SEGMENT_FULL))
@@ -319,10 +319,20 @@ def test_hot_segment_full_size_strict_on_the_reference_picks(sa, golden, name):
     before = dict(sa.modules.PATH_COUNTS)
     rep, v, pred, differs, unexplained = strict.run_strict(seg, g, name)
     assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "a PyTorch fallback ran"
-    ref_self = rep["reference_vs_truth_max_off_ties_px"]
-    bound_truth = max(1e-3, 2.0 * ref_self)              # HIP vs the exact answer
-    bound = max(1e-3, 3.0 * ref_self)                    # HIP vs the reference: its distance from the truth + the reference's own
+    ref_self = rep["reference_vs_truth_max_off_ties_px"]     # the REFERENCE's own fp32 evaluation against the float64 truth, worst pixel
+    ref_mean = rep["reference_vs_truth_epe_off_ties_px"]     # ... and on average
+    default_engine = sa.modules.CONV_ENGINE == "f16x3"
+    # Round 4: with the warp kernels following the reference's coordinate arithmetic operation by operation and
+    # the chunk-blocked accumulation of the small-tile convolutions, the default engine is as close to the float64 answer as the
+    # reference's own CPU arithmetic (measured: 1.015x / 1.017x its mean distance at 1024^2 / 2048^2, 0.98x / 1.03x on the worst
+    # pixel; r03: 3x / 1.9x).  Bounds: worst pixel <= 1.25x the reference's, mean <= 1.3x, and against the REFERENCE itself every
+    # pixel off its own cost ties within 5e-4 px at both sizes (r03: max(1e-3, 3 r) = 2.4e-3 at 2048^2; measured 7.6e-5 / 1.6e-4).
+    # The other engines (single accumulation chains everywhere) keep r03's bounds.
+    bound_truth = 1.25 * ref_self if default_engine else max(1e-3, 2.0 * ref_self)
+    bound = 5e-4 if default_engine else max(1e-3, 3.0 * ref_self)
     rep["bound_px"], rep["bound_vs_truth_px"] = bound, bound_truth
+    rep["mean_ratio_to_reference"] = rep["hip_vs_truth_epe_off_ties_px"] / ref_mean
+    rep["max_ratio_to_reference"] = rep["hip_vs_truth_max_off_ties_px"] / ref_self
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/fullsize_strict_{name}.json", "w") as f:
         json.dump(rep, f, indent=1)
@@ -331,10 +341,9 @@ def test_hot_segment_full_size_strict_on_the_reference_picks(sa, golden, name):
     assert bound <= 3e-3, rep
     assert rep["max_err_off_ties_px"] <= bound, rep                         # EVERY pixel away from the reference's own cost ties
     assert rep["hip_vs_truth_max_off_ties_px"] <= bound_truth, rep
-    ref_mean = rep["reference_vs_truth_epe_off_ties_px"]
-    assert rep["hip_vs_truth_epe_off_ties_px"] <= max(1e-4, 4.0 * ref_mean), rep
-    assert rep["epe_vs_reference_off_ties_px"] <= max(1e-4, 5.0 * ref_mean) and rep["median_abs_err_px"] <= 1e-4, rep
-    if 2 * (maxdisp // 4) <= 64:
-        # the north star's size: whole map INCLUDING the reference's own cost ties (where a top-2 flip moves a pixel by whole
-        # candidates), full-resolution EPE (x4) < 1e-3
+    assert rep["hip_vs_truth_epe_off_ties_px"] <= (1.3 * ref_mean if default_engine else max(1e-4, 4.0 * ref_mean)), rep
+    assert rep["epe_vs_reference_off_ties_px"] <= (1.5 * ref_mean if default_engine else max(1e-4, 5.0 * ref_mean)) and rep["median_abs_err_px"] <= 1e-4, rep
+    if 2 * (maxdisp // 4) <= 64 or default_engine:
+        # whole map INCLUDING the reference's own cost ties (where a top-2 flip moves a pixel by whole candidates), full-resolution
+        # EPE (x4) < 1e-3: the north star's figure at the size it is stated for -- and, since r04, at 2048^2 / 192 too
         assert rep["epe_vs_reference_fullres_px"] <= 1e-3, rep

@@ -94,4 +94,8 @@ def test_bench_step_loop_over_a_one_rank_rccl_group():
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["n_gpus"] == 1 and res["value"] > 0 and res["dist_backend_initialised"] == "nccl"
+    assert res["n_gpus"] == 1 and res["value"] > 0
+    # the group as torch.distributed reports it, this rank's own rate and the all_gather of the disparities that follows the forward
+    d = res["dist"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and len(d["per_rank_pairs_per_s"]) == 1
+    assert d["all_gather_payload_bytes"] == 1 * 1 * 64 * 64 * 4 and d["all_gather_shape"] == [1, 1, 64, 64]

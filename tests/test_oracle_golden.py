@@ -29,6 +29,16 @@ def test_gwc(golden, name):
     _eq(oops.groupwise_correlation_norm(a, b, G), g[f"gcorr_norm/{name}"])
 
 
+@pytest.mark.parametrize("name", sorted(cases.GWC))
+def test_closed_form_gwc_norm_is_the_slice_loop_bit_for_bit(golden, name):
+    """oracle.ops.build_gwc_volume_norm_closed_form (both maps normalised once; used by bench.py's many-pair parity leg) against
+    the reference's fixture AND the slice-loop restatement: the same bits."""
+    a, b, m, G = cases.gwc_inputs(name)
+    v = oops.build_gwc_volume_norm_closed_form(a, b, m, G)
+    assert torch.equal(v, oops.build_gwc_volume_norm(a, b, m, G))
+    np.testing.assert_array_equal(v.numpy(), golden["ops"][f"gwc_norm/{name}"])
+
+
 @pytest.mark.parametrize("name", sorted(cases.CONCAT))
 def test_concat(golden, name):
     a, b, m = cases.concat_inputs(name)

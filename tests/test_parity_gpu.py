@@ -188,9 +188,9 @@ def test_warp_right_half_fast_path(sa, shape, gated):
     # the same launch through the generic kernel: feed a left half and drop it
     both = sa.ops.concat_volume_sampled(dev(torch.zeros_like(y)), dev(y), dev(disp), None if att is None else dev(att))
     assert torch.equal(out, both[:, C:])
-    # vs the oracle: the fp32 coordinate round trip (w - d)/((W-1)/2) - 1 -> * (W-1)/2 leaves |d| * 2^-24 in the bilinear
-    # weights of fractional disparities (here |d| up to 1.5 W; ATen's CPU kernel orders the same sums differently)
-    check(f"concat_sampled_right/{shape}/{gated}", out, ref, 5e-5)
+    # vs the oracle: the same fp32 coordinate round trip, operation by operation (r04: the products are really unfused now);
+    # what is left is ATen's fused multiply-adds in the four-tap sum: one ulp of an O(1) value
+    check(f"concat_sampled_right/{shape}/{gated}", out, ref, 2e-6)
 
 
 def test_warp_float4_form_identical(sa, tuning_env):
@@ -206,7 +206,44 @@ def test_warp_float4_form_identical(sa, tuning_env):
         outs.append(sa.ops.concat_volume_sampled(dev(x), dev(y), dev(disp), dev(att)).cpu())
     assert torch.equal(outs[0], outs[1])
     yw, xw = oops.SpatialTransformer_grid(x, y, disp)
-    check("concat_sampled_fractional", outs[0], att * torch.cat((xw, yw), dim=1), 2e-5)
+    check("concat_sampled_fractional", outs[0], att * torch.cat((xw, yw), dim=1), 2e-6)
+
+
+@pytest.mark.parametrize("W", [256, 512])
+def test_warp_follows_grid_sample_at_the_bench_widths(sa, W):
+    """Round 4.  The reference's coordinate round trip leaves ix = (w - d) + delta with |delta| up to ~W * 1e-7, and the last
+    rounding of that arithmetic snaps most ix back onto the integer.  Until r04 the `unfused` helpers of the kernels were still
+    contracted by hipcc (`ix - floor(ix)` became an fma on the UNROUNDED product): invisible at the fixtures' W = 16, it moved
+    the bilinear weights by up to 4e-5 at W = 256 (8e-5 at 512), made only 7 % of the warped values bit-equal to
+    F.grid_sample's and put the whole HIP path 3x further from the float64 answer than the reference itself.  Held here at the
+    quarter-resolution widths of the bench shapes: integer candidates (the live :316 call) and fractional ones (:291), the
+    generic kernel, the live right-half kernel and the 5-candidate probe."""
+    g = torch.Generator().manual_seed(W)
+    B, C, H, nd, m4 = 1, 8, 6, 24, W // 8
+    x, y = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    smp = torch.stack([torch.randperm(2 * m4, generator=g)[:nd].sort()[0].float() - m4 for _ in range(H * W)], 1).reshape(B, nd, H, W)
+    att = torch.rand(B, 1, nd, H, W, generator=g)
+    yw, xw = oops.SpatialTransformer_grid(x, y, smp)
+    yw64, _ = oops.SpatialTransformer_grid(x.double(), y.double(), smp.double())
+    got, _ = sa.ops.SpatialTransformer_grid(dev(x), dev(y), dev(smp))
+    got = got.cpu()
+    same = float((got == yw).float().mean())
+    REPORT[f"warp_bitwise_equal_fraction/W{W}"] = same
+    assert same >= 0.85, f"only {same:.3f} of the warped values equal F.grid_sample's bit for bit"
+    check(f"warp_bench_width/W{W}", got, yw, 6e-7)
+    # ... and therefore exactly as far from the exact gather (float64 coordinates) as the reference's own arithmetic
+    e_hip, e_ref = (got.double() - yw64).pow(2).mean().sqrt().item(), (yw.double() - yw64).pow(2).mean().sqrt().item()
+    assert e_hip <= 1.02 * e_ref + 1e-9, (e_hip, e_ref)
+    right = sa.ops.concat_volume_sampled(None, dev(y), dev(smp), dev(att))
+    check(f"warp_right_gated_bench_width/W{W}", right, att * yw, 6e-7)
+    # the probe of :291-293: fractional candidates around a regressed disparity
+    pred0 = (torch.rand(B, H, W, generator=g) - 0.5) * 2 * m4
+    var = torch.rand(B, 1, H, W, generator=g) * 30
+    gamma, beta = torch.tensor([0.25]), torch.tensor([2.0])
+    rw, lb = oops.SpatialTransformer_grid(x, y, oops.propagation(pred0.unsqueeze(1)))
+    strength = torch.softmax((lb * rw).mean(dim=1) * oops.propagation(torch.sigmoid(beta + gamma * var)), dim=1)
+    check(f"sample_strength_bench_width/W{W}", sa.ops.sample_strength(dev(x), dev(y), dev(pred0), dev(var), dev(gamma), dev(beta)),
+          strength, 1e-6)
 
 
 @pytest.mark.parametrize("name", sorted(cases.TOPK))
@@ -558,7 +595,9 @@ def test_stem_on_the_presplit_warped_half(sa, shape, gated):
         ref = gate.double().unsqueeze(2) * ref
     e_pre, e_f32 = float((y_pre.double().cpu() - ref).abs().max()), float((y_f32.double().cpu() - ref).abs().max())
     REPORT[f"stem_presplit/{shape}/{gated}"] = e_pre
-    assert e_pre <= 2.0 * e_f32 + 1e-6, (e_pre, e_f32)
+    # (r04: the fp32-volume form of these small shapes runs the chunk-blocked accumulation now and is ~3x closer to float64 than
+    # a single chain; the pre-split option keeps the chain)
+    assert e_pre <= max(2.0 * e_f32 + 1e-6, 8e-6), (e_pre, e_f32)
 
 
 HEAD_CASES = [
