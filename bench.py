@@ -291,7 +291,7 @@ def seeded_pairs_parity(seg, M, engines, n_pairs, H, W, maxdisp, device, threads
     P64 = {k_: (v.double() if v.is_floating_point() else v) for k_, v in P.items()}
     torch.set_num_threads(threads)
     rows, secs = {e: [] for e in list(engines) + ["oracle_fp32"]}, []
-    keep, keep_cf = M.CONV_ENGINE, oseg.GWC_CLOSED_FORM
+    keep, keep_cf = semstereo_amd.engine.CONV_ENGINE, oseg.GWC_CLOSED_FORM
     oseg.GWC_CLOSED_FORM = True             # bit-identical to the slice loop (tests/test_oracle_golden.py), 7 s less per pair
     for i in range(n_pairs):
         fl8, fr8 = synth_features(1, 256, H // 8, W // 8, 6, 300 + 2 * i, device)
@@ -304,7 +304,7 @@ def seeded_pairs_parity(seg, M, engines, n_pairs, H, W, maxdisp, device, threads
         secs.append(time.perf_counter() - t0)
         rows["oracle_fp32"].append({"picks_differing_from_float64": int((ref["samples"] != smp64).any(dim=1).sum())})
         for e in engines:
-            M.CONV_ENGINE = e
+            semstereo_amd.engine.CONV_ENGINE = e
             with torch.no_grad():
                 o = seg(fl4, fr4, fl8, fr8)
             err = (o["pred"].cpu() - ref["pred"]).abs()
@@ -313,7 +313,7 @@ def seeded_pairs_parity(seg, M, engines, n_pairs, H, W, maxdisp, device, threads
                             "pixels_with_other_candidates": int((smp != ref["samples"]).any(dim=1).sum()),
                             "picks_differing_from_float64": int((smp != smp64).any(dim=1).sum()),
                             "median_abs_err_px": float(err.median())})
-    M.CONV_ENGINE, oseg.GWC_CLOSED_FORM = keep, keep_cf
+    semstereo_amd.engine.CONV_ENGINE, oseg.GWC_CLOSED_FORM = keep, keep_cf
 
     def ms(vals):
         t = torch.tensor(vals, dtype=torch.float64)
@@ -550,10 +550,10 @@ def main():
         device = torch.device("cuda", local)
         sync = torch.cuda.synchronize
         semstereo_amd._lib.load()
-    M = semstereo_amd.modules
+    M, E = semstereo_amd.modules, semstereo_amd.engine
     if args.engine:
-        M.CONV_ENGINE = args.engine
-    engine = M.CONV_ENGINE
+        E.CONV_ENGINE = args.engine
+    engine = E.CONV_ENGINE
 
     H, W, maxdisp, B = args.height, args.width, args.maxdisp, args.batch
     nsets = max(1, args.input_sets)
@@ -575,11 +575,11 @@ def main():
 
     timer = KernelTimer()
     if not args.no_kernel_timers and not dry:
-        if M.CONV_ENGINE == "f32":
+        if E.CONV_ENGINE == "f32":
             seg.concat_stem.forward = timer.wrap("concat_stem", seg.concat_stem.forward)
         else:       # the gated launch of the split-bf16 conv is concat_stem's (the right half of the volume)
-            plain, timed = M.conv3d_bf16s_hip, timer.wrap("concat_stem", M.conv3d_bf16s_hip)
-            M.conv3d_bf16s_hip = lambda *a, **k: (timed if (k.get("gate") is not None or (len(a) > 8 and a[8] is not None))
+            plain, timed = E.conv3d_bf16s_hip, timer.wrap("concat_stem", E.conv3d_bf16s_hip)
+            E.conv3d_bf16s_hip = lambda *a, **k: (timed if (k.get("gate") is not None or (len(a) > 8 and a[8] is not None))
                                                   else plain)(*a, **k)
             M.stem_volume_half_presplit = timer.wrap("concat_stem_presplit", M.stem_volume_half_presplit)
         # the cost-volume kernel of the step: build_gwc_volume_norm fused with `patch` and the channelAtt gate
@@ -662,10 +662,10 @@ def main():
     if not dry and not args.no_other_engines:
         for e in ("f32", "bf16x6", "bf16x3", "f16x3"):
             if e != engine:
-                M.CONV_ENGINE = e
+                E.CONV_ENGINE = e
                 o, p_, t_, _ = timed_run(max(3, args.steps // 2), 2)
                 by_engine[e], outs[e] = p_ / t_, o
-        M.CONV_ENGINE = engine
+        E.CONV_ENGINE = engine
         # what install() + accelerate() give a reference model whose forward() is left untouched: the reference's
         # statements one by one, in its order (HotSegment's FUSED = False composition), on the reference-named ops and the
         # twins -- which in inference hand out deferred handles, so that the same fused kernels run (semstereo_amd/deferred.py);

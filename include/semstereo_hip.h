@@ -34,7 +34,8 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (8): bumped on any signature change or new entry point the Python binding requires. */
+/* ABI version (10 since round 3; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+ * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
  * measurement aids) are read from the environment ONCE per process; call this after changing

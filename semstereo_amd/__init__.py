@@ -9,7 +9,7 @@
 The compute lives in csrc/libsemstereo_hip.so behind the C ABI of include/semstereo_hip.h.
 Nothing here falls back to the CPU or to the test oracle.
 """
-from . import _lib, dist, modules, ops, ops_unsigned, segment  # noqa: F401
+from . import _lib, dist, engine, modules, ops, ops_unsigned, segment, train_layers  # noqa: F401
 from .install import accelerate, install, restore_forward, uninstall  # noqa: F401
 from .segment import GraphedSegment, HotSegment  # noqa: F401
 

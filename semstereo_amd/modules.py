@@ -17,571 +17,25 @@ layers on the GPU -- the HIP stack is an inference path; PATH_COUNTS records whi
 `X.adopt(ref_module)` wraps an instance built by the REFERENCE's own classes, sharing its
 parameters (this is what `semstereo_amd.install.accelerate` uses).
 """
-import os
-import weakref
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, ops
 from . import deferred as dfr
+from . import engine as E
 from . import train as T
 from ._lib import call, ptr
-
-PATH_COUNTS = {"hip": 0, "torch": 0}
-
-
-def _inference(module, *tensors):
-    """True when the folded-BN HIP path is valid: eval mode and nothing needs autograd."""
-    if module.training:
-        return False
-    if torch.is_grad_enabled():
-        if any(t is not None and t.requires_grad for t in tensors):
-            return False
-        if any(p.requires_grad for p in module.parameters()):
-            return False
-        if module.__dict__.get("_is_replica", False):
-            # an nn.DataParallel replica holds its weights as plain attributes (parameters() is empty);
-            # torch/nn/parallel/replicate.py keeps them reachable in _former_parameters
-            for m in module.modules():
-                if any(p is not None and p.requires_grad for p in getattr(m, "_former_parameters", {}).values()):
-                    return False
-    return True
-
-
-class _ParamCache:
-    """Derived device tensors (packed weights, folded affines), rebuilt when a source tensor changes."""
-
-    def __init__(self):
-        self._store = {}
-        self.owner = None                    # weakref to the module the cache belongs to (set by _cache)
-
-    def get(self, key, sources, build):
-        stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in sources)
-        hit = self._store.get(key)
-        if hit is None or hit[0] != stamp:
-            with torch.no_grad():
-                hit = (stamp, build())
-            self._store[key] = hit
-        return hit[1]
-
-
-class _ReplicaCache:
-    """The cache view of an nn.DataParallel replica: entries live on the ORIGINAL module (whose `_ss_cache` object the
-    replica's shallow-copied __dict__ shares), keyed by the replica's device, and are valid while the original's
-    parameters and buffers are unchanged -- the replica's own tensors are fresh broadcast copies on every forward that
-    the caching allocator tends to hand the same address with version 0, so their (data_ptr, version) says nothing.
-    Packed weights are built from the replica's device-local copies, once per device and weight update instead of once per
-    forward (~50 pack launches per GPU and step)."""
-
-    def __init__(self, shared, owner, device):
-        self.shared, self.owner, self.device = shared, owner, str(device)
-
-    def get(self, key, sources, build):
-        stamp = tuple((t.data_ptr(), t._version) for t in list(self.owner.parameters()) + list(self.owner.buffers()))
-        k = ("replica", self.device, key)
-        hit = self.shared._store.get(k)
-        if hit is None or hit[0] != stamp:
-            with torch.no_grad():
-                hit = (stamp, build())
-            self.shared._store[k] = hit
-        return hit[1]
-
-
-def _cache(module):
-    """Per-module cache of derived tensors (packed weights, folded affines)."""
-    c = module.__dict__.get("_ss_cache")
-    if module.__dict__.get("_is_replica", False):
-        owner = c.owner() if c is not None and c.owner is not None else None
-        if owner is None:
-            return _ParamCache()              # a replica of a module that never ran on its own: nothing to validate against
-        dev_ = next((t.device for t in list(module.__dict__.get("_former_parameters", {}).values()) + list(module.buffers()) if t is not None), "?")
-        for m in module.modules():
-            fp = [t for t in getattr(m, "_former_parameters", {}).values() if t is not None]
-            if fp:
-                dev_ = fp[0].device
-                break
-        return _ReplicaCache(c, owner, dev_)
-    if c is None:
-        c = module.__dict__["_ss_cache"] = _ParamCache()
-        c.owner = weakref.ref(module)
-    return c
-
-
-def fold_bn(bn):
-    """eval-mode BatchNorm as y = x*scale + shift (the same two-step form ATen's inference path uses)."""
-    invstd = 1.0 / torch.sqrt(bn.running_var + bn.eps)
-    scale = (bn.weight * invstd) if bn.weight is not None else invstd
-    shift = (bn.bias if bn.bias is not None else 0.0) - bn.running_mean * scale
-    return scale.float().contiguous(), shift.float().contiguous()
-
-
-def pack_conv_weight(w, transposed=False):
-    """[Cout,Cin,k,k,k] (or ConvTranspose3d's [Cin,Cout,k,k,k]) -> [Cin][k^3][Cout] on the device."""
-    w = w.detach().float().contiguous()
-    _lib.require_device(w)
-    if transposed:
-        Cin, Cout, k = w.shape[0], w.shape[1], w.shape[2]
-    else:
-        Cout, Cin, k = w.shape[0], w.shape[1], w.shape[2]
-    assert w.shape[2] == w.shape[3] == w.shape[4], "cubic kernels only"
-    out = torch.empty((Cin, k * k * k, Cout), dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
-        call("ss_pack_conv3d_weights", ptr(w), ptr(out), Cout, Cin, k, int(transposed))
-    return out
-
-
-def conv3d_hip(x, wpack, scale, shift, k, stride, relu, residual=None, gate=None):
-    """Conv3d(bias=False, pad=k//2) + per-channel affine + optional residual + optional ReLU + optional
-    channelAtt gate (sigmoid(gate[b,co,h,w]) broadcast over D)."""
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, wpack, scale, shift, residual, gate)
-    B, Cin, D, H, W = x.shape
-    assert wpack.shape[0] == Cin and wpack.shape[1] == k ** 3
-    Cout = wpack.shape[2]
-    pad = k // 2
-    Do, Ho, Wo = [(n + 2 * pad - k) // stride + 1 for n in (D, H, W)]
-    out = torch.empty((B, Cout, Do, Ho, Wo), dtype=x.dtype, device=x.device)
-    if residual is not None:
-        assert residual.shape == out.shape and residual.is_contiguous()
-    if gate is not None:
-        assert gate.shape == (B, Cout, Ho, Wo) and gate.is_contiguous()
-    with torch.cuda.device(dev):
-        call("ss_conv3d_fwd", ptr(x), ptr(wpack), ptr(scale), ptr(shift), ptr(residual), ptr(gate), ptr(out),
-             B, Cin, D, H, W, Cout, k, stride, int(relu))
-    return out
-
-
-def deconv3d_hip(x, wpack, shift, relu, skip=None, skip_wpack=None):
-    """ConvTranspose3d(k3,s2,p1,op1) [+ 1x1x1 projection of `skip`] + shift + optional ReLU.
-    Per-branch BN scales are expected to be folded into the packed weights already."""
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, wpack, shift, skip, skip_wpack)
-    B, Cin, D, H, W = x.shape
-    Cout = wpack.shape[2]
-    out = torch.empty((B, Cout, 2 * D, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
-    Cs = 0
-    if skip is not None:
-        skip = skip if skip.is_contiguous() else skip.contiguous()
-        Cs = skip.shape[1]
-        assert skip.shape == (B, Cs, 2 * D, 2 * H, 2 * W) and skip_wpack.shape == (Cs, Cout)
-    with torch.cuda.device(dev):
-        call("ss_deconv3d_fwd", ptr(x), ptr(wpack), None, ptr(shift), ptr(skip), ptr(skip_wpack), None, None,
-             ptr(out), B, Cin, D, H, W, Cout, Cs, int(relu))
-    return out
-
-
-def pack_deconv_weight_bf16s(wpack, nterms=6):
-    """fp32 pack [Cin][ntaps][Cout] (ntaps 27: transposed conv, BN scale folded; or [Cs][Cout]: the skip projection)
-    -> split fragments for ss_deconv3d_bf16s_fwd: three bf16 terms, or (nterms 19, main weights only) two scaled fp16
-    terms + the per-channel inverse scales."""
-    wpack = wpack.detach().float().contiguous()
-    _lib.require_device(wpack)
-    Cin, Cout = wpack.shape[0], wpack.shape[-1]
-    ntaps = 1 if wpack.dim() == 2 else wpack.shape[1]
-    with torch.cuda.device(wpack.device):
-        if nterms == 19:
-            assert ntaps == 27
-            out = torch.empty(((Cin + 15) // 16) * 27 * 2 * 2 * Cout * 8 + 2 * Cout, dtype=torch.int16, device=wpack.device)
-            call("ss_pack_deconv3d_weights_f16s", ptr(wpack), ptr(out), Cin, Cout)
-        else:
-            out = torch.empty(((Cin + 15) // 16) * ntaps * 3 * 2 * Cout * 8, dtype=torch.int16, device=wpack.device)
-            call("ss_pack_deconv3d_weights_bf16s", ptr(wpack), ptr(out), Cin, Cout, ntaps)
-    return out
-
-
-def deconv3d_bf16s_hip(x, wsplit, Cout, shift, relu, nterms, skip=None, skip_wsplit=None):
-    """deconv3d_hip on the split-bf16 engine."""
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, shift, skip)
-    B, Cin, D, H, W = x.shape
-    out = torch.empty((B, Cout, 2 * D, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
-    Cs = 0
-    if skip is not None:
-        skip = skip if skip.is_contiguous() else skip.contiguous()
-        Cs = skip.shape[1]
-        assert skip.shape == (B, Cs, 2 * D, 2 * H, 2 * W)
-    with torch.cuda.device(dev):
-        call("ss_deconv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(shift), ptr(skip), ptr(skip_wsplit), ptr(out),
-             B, Cin, D, H, W, Cout, Cs, int(relu), int(nterms))
-    return out
-
-
-#: matrix-core engine of the 3x3x3 stride-1 convolutions: "f32" = exact-fp32 MFMA (conv3d.hip);
-#: "bf16x6" / "bf16x3" = split-bf16 (conv3d_bf16s.hip, fp32 operands as 3 bf16 terms, 6 or 3 cross
-#: products) for every 3x3x3 conv (stride 1 and 2), the transposed convs, the 32 -> 1 heads and the 1x1x1
-#: projections of the attention blocks.
-#: Default bf16x6: its measured error against fp64 is BELOW the exact-fp32 MFMA's (1.1e-7 vs 1.8e-7 of
-#: sum|a*b|, tools/exp_split_bf16.hip) at ~1.5x its speed; SS_CONV_ENGINE=f32 selects the exact engine.
-#: "f16x3": the tiled 3x3x3 convs (stride 1 and 2) on TWO fp16 terms and three products with block-floating operands
-#: (same accuracy class as bf16x6, half its matrix-core time: conv3d_bf16s.hip); the other kernels stay on bf16x6.
-CONV_ENGINE = os.environ.get("SS_CONV_ENGINE", "f16x3")
-_NTERMS_TILED = {"bf16x6": 6, "bf16x3": 3, "f16x3": 19}          # `nterms` codes of ss_conv3d_bf16s_fwd
-_NTERMS_AUX = {"bf16x6": 6, "bf16x3": 3, "f16x3": 6, "f32": 6}   # kernels without an fp16 form (f32: unused)
-
-
-def _tiled_nterms():
-    return _NTERMS_TILED[CONV_ENGINE]
-
-
-def _aux_nterms():
-    return _NTERMS_AUX[CONV_ENGINE]
-
-
-DECONV_F16 = os.environ.get("SS_DECONV_F16", "1") != "0"        # f16x3 engine: the transposed convs' main loop on fp16 terms too
-
-
-def _deconv_nterms():
-    return _NTERMS_TILED[CONV_ENGINE] if DECONV_F16 else _NTERMS_AUX[CONV_ENGINE]
-#: transposed convs with fewer workgroups than this run on the exact-fp32 kernel, whose even/odd-plane split doubles them.
-#: 0 since r03: on the one layer of the bench shape below 256 workgroups (hourglass_att.conv5, 128) the split engine's kernel has
-#: overtaken it (step 2.117 -> 2.093 ms, 2.119 -> 2.085 on a second box), and the engine of a layer no longer depends on the
-#: batch size (r01: bf16x6 at 128 workgroups 88 vs 67 us, the fp16 form 66 vs 72 us)
-DECONV_MIN_WORKGROUPS = int(os.environ.get("SS_DECONV_MIN_WGS", "0"))
-DECONV_BF16S = os.environ.get("SS_DECONV_BF16S", "1") != "0"     # transposed convs on the split engine too (else exact fp32 MFMA)
-
-
-def pack_conv_weight_bf16s(w, nterms=6):
-    """[Cout,Cin,3,3,3] fp32 -> split fragments for ss_conv3d_bf16s_fwd (int16 tensor, 16-B aligned): three bf16 terms
-    (nterms 6 / 3) or two scaled fp16 terms + the per-channel inverse scales (nterms 19)."""
-    w = w.detach().float().contiguous()
-    _lib.require_device(w)
-    Cout, Cin = w.shape[0], w.shape[1]
-    assert tuple(w.shape[2:]) == (3, 3, 3)
-    with torch.cuda.device(w.device):
-        if nterms == 19:
-            out = torch.empty(((Cin + 7) // 8) * 14 * 2 * 2 * Cout * 8 + 2 * Cout, dtype=torch.int16, device=w.device)
-            call("ss_pack_conv3d_weights_f16s", ptr(w), ptr(out), Cout, Cin)
-        else:
-            out = torch.empty(((Cin + 7) // 8) * 14 * 3 * 2 * Cout * 8, dtype=torch.int16, device=w.device)
-            call("ss_pack_conv3d_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
-    return out
-
-
-def conv3d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None, gate=None, partial=None, stride=1):
-    """3x3x3 Conv3d (stride 1 or 2) + affine + optional residual / ReLU on the split-bf16 engine.  `partial`
-    [B,Cout,D,H,W]: a partial sum of the same convolution (other input channels), added BEFORE the affine."""
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, scale, shift, residual, gate, partial)
-    B, Cin, D, H, W = x.shape
-    Do, Ho, Wo = [(n - 1) // stride + 1 for n in (D, H, W)]
-    out = torch.empty((B, Cout, Do, Ho, Wo), dtype=x.dtype, device=x.device)
-    if gate is not None:
-        assert gate.shape == (B, Cout, Ho, Wo) and gate.is_contiguous()
-    with torch.cuda.device(dev):
-        if partial is not None:
-            assert residual is None and stride == 1 and partial.shape == out.shape and partial.is_contiguous()
-            call("ss_conv3d_bf16s_partial_fwd", ptr(x), ptr(wsplit), ptr(partial), ptr(scale), ptr(shift), ptr(gate), ptr(out),
-                 B, Cin, D, H, W, Cout, int(relu), int(nterms))
-        else:
-            call("ss_conv3d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(gate), ptr(out),
-                 B, Cin, D, H, W, Cout, int(stride), int(relu), int(nterms))
-    return out
-
-
-def classifier_cl_hip(x, ws0, scale0, shift0, nterms0, ws2, nterms2):
-    """nn.Sequential(convbn_3d(C,C,3,1,1), ReLU, Conv3d(C,1,3,p1)) (models/SemStereo.py:228-234) as two launches whose
-    intermediate is channels-last [B,D,H,W,C] (private to the pair: 16-byte stores in the first, 16-byte loads in the head)."""
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, scale0, shift0)
-    B, C, D, H, W = x.shape
-    mid = torch.empty((B, D, H, W, C), dtype=x.dtype, device=x.device)
-    out = torch.empty((B, 1, D, H, W), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(dev):
-        call("ss_conv3d_bf16s_cl_fwd", ptr(x), ptr(ws0), ptr(scale0), ptr(shift0), ptr(mid), B, C, D, H, W, C, 1, int(nterms0))
-        call("ss_conv3d_head_bf16s_cl_fwd", ptr(mid), ptr(ws2), None, None, ptr(out), B, C, D, H, W, 0, int(nterms2))
-    return out
-
-
-def pack_conv2d_weight_bf16s(w, nterms=6):
-    """[Cout,Cin,3,3] fp32 -> split fragments for ss_conv2d_bf16s_fwd (three bf16 terms, or two scaled fp16 terms: nterms 19)."""
-    w = w.detach().float().contiguous()
-    _lib.require_device(w)
-    Cout, Cin = w.shape[0], w.shape[1]
-    assert tuple(w.shape[2:]) == (3, 3)
-    with torch.cuda.device(w.device):
-        if nterms == 19:
-            out = torch.empty(((Cin + 7) // 8) * 5 * 2 * 2 * Cout * 8 + 2 * Cout, dtype=torch.int16, device=w.device)
-            call("ss_pack_conv2d_weights_f16s", ptr(w), ptr(out), Cout, Cin)
-        else:
-            out = torch.empty(((Cin + 7) // 8) * 5 * 3 * 2 * Cout * 8, dtype=torch.int16, device=w.device)
-            call("ss_pack_conv2d_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
-    return out
-
-
-def conv2d_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms, residual=None):
-    """Conv2d(k3, s1, p1, bias=False) + affine + optional residual / ReLU on the split-bf16 engine."""
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, scale, shift, residual)
-    B, Cin, H, W = x.shape
-    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(dev):
-        call("ss_conv2d_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(residual), ptr(out), B, Cin, H, W, Cout,
-             int(relu), int(nterms))
-    return out
-
-
-def _is_plain_3x3(conv):
-    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
-            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros")
-
-
-#: concat_feature's 3x3 2-D convs on the split engine instead of MIOpen (which also takes MIOpen's per-box algorithm choice
-#: out of the matching branch).  They run on the second stream UNDER the attention branch and compete with it for the
-#: matrix pipe: with three-term bf16 operands (110 + 38 us against 170 + 58 us of Winograd + BatchNorm + clamp) the step
-#: was 1 % slower at batch 1, with the fp16 form (half the matrix-core time again) it is 2.2 % faster at batch 1 and 4.
-#: "auto": on for the f16x3 engine; SS_CONV2D_HIP=0 / 1 forces it.
-_c2d = os.environ.get("SS_CONV2D_HIP", "auto")
-CONV2D_HIP = "auto" if _c2d == "auto" else (_c2d != "0")
-
-
-def _conv2d_hip_on():
-    return CONV_ENGINE == "f16x3" if CONV2D_HIP == "auto" else bool(CONV2D_HIP)
-
-
-def run_conv2d(owner, key, conv, bn, x, relu):
-    """Conv2d(3x3, s1, p1, no bias) [+ BN(eval)] [+ ReLU] of a 2-D map on the split-bf16 engine; None when it does not apply."""
-    if not (_conv2d_hip_on() and CONV_ENGINE != "f32" and _is_plain_3x3(conv) and x.is_cuda):
-        return None
-    nterms = _tiled_nterms()
-    srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-
-    def build():
-        sc, sh = fold_bn(bn) if bn is not None else (None, None)
-        return pack_conv2d_weight_bf16s(conv.weight, nterms), sc, sh
-    ws, scale, shift = _cache(owner).get(key + "/2d_" + CONV_ENGINE, srcs, build)
-    return conv2d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms)
-
-
-def pack_head_weight_bf16s(w, nterms=6):
-    """[1,Cin,3,3,3] fp32 -> split fragments (taps as matrix rows) for ss_conv3d_head_bf16s_fwd: three bf16 terms (nterms 6 / 3)
-    or two scaled fp16 terms + the inverse scale (nterms 19)."""
-    w = w.detach().float().contiguous()
-    _lib.require_device(w)
-    Cin = w.shape[1]
-    assert w.shape[0] == 1 and tuple(w.shape[2:]) == (3, 3, 3) and Cin % 16 == 0
-    with torch.cuda.device(w.device):
-        if nterms == 19:
-            out = torch.empty((Cin // 16) * 2 * 2 * 32 * 8 + 8, dtype=torch.int16, device=w.device)
-            call("ss_pack_conv3d_head_weights_f16s", ptr(w), ptr(out), Cin)
-        else:
-            out = torch.empty((Cin // 16) * 3 * 2 * 32 * 8, dtype=torch.int16, device=w.device)
-            call("ss_pack_conv3d_head_weights_bf16s", ptr(w), ptr(out), Cin)
-    return out
-
-
-#: SS_HEAD_F16=1: the 32 -> 1 classifier heads on two fp16 terms (3 products, a block exponent per input row) instead of three
-#: bf16 terms (6 products).  Off by default: since the channels-last hand-off (r02) the head is bound by its loads, not by its
-#: matrix work -- measured r03_i: 51.1 vs 52.7 us alone, 462.0 vs 461.6 pairs/s for the step (`profiles/r03_i_*`)
-HEAD_F16 = os.environ.get("SS_HEAD_F16", "0") != "0"
-
-
-def _head_nterms():
-    return 19 if (CONV_ENGINE == "f16x3" and HEAD_F16) else _aux_nterms()
-
-
-def conv3d_head_bf16s_hip(x, wsplit, scale, shift, relu, nterms):
-    """Conv3d(C, 1, 3, padding=1) + affine (+ReLU) on the split-bf16 engine (conv3d_head.hip)."""
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, scale, shift)
-    B, Cin, D, H, W = x.shape
-    out = torch.empty((B, 1, D, H, W), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(dev):
-        call("ss_conv3d_head_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(out), B, Cin, D, H, W,
-             int(relu), int(nterms))
-    return out
-
-
-def pack_pointwise_weight_bf16s(w):
-    """[Cout,Cin] (or [Cout,Cin,1,1,1]) fp32 -> split-bf16 fragments for ss_conv3d_pointwise_bf16s_fwd."""
-    w = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
-    _lib.require_device(w)
-    Cout, Cin = w.shape
-    assert Cin % 16 == 0
-    out = torch.empty(((Cout + 31) // 32) * (Cin // 16) * 3 * 2 * 32 * 8, dtype=torch.int16, device=w.device)
-    with torch.cuda.device(w.device):
-        call("ss_pack_pointwise_weights_bf16s", ptr(w), ptr(out), Cout, Cin)
-    return out
-
-
-def conv3d_pointwise_bf16s_hip(x, wsplit, Cout, scale, shift, relu, nterms):
-    """1x1x1 Conv3d / Linear over channels + affine (+ReLU) on the split-bf16 engine; x [B,Cin,*spatial]."""
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(x, scale, shift)
-    B, Cin = x.shape[0], x.shape[1]
-    out = torch.empty((B, Cout) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(dev):
-        call("ss_conv3d_pointwise_bf16s_fwd", ptr(x), ptr(wsplit), ptr(scale), ptr(shift), ptr(out), B, Cin, Cout,
-             x[0, 0].numel(), int(relu), int(nterms))
-    return out
-
-
-def _convbn_params(owner, key, conv, bn):
-    """(wpack, scale, shift) of a Conv3d(+BN) pair, cached on `owner`."""
-    srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-
-    def build():
-        wp = pack_conv_weight(conv.weight)
-        if bn is None:
-            return wp, None, None
-        s, b = fold_bn(bn)
-        return wp, s, b
-    return _cache(owner).get(key, srcs, build)
-
-
-def _conv_geometry(conv):
-    k, s, p = conv.kernel_size, conv.stride, conv.padding
-    assert k[0] == k[1] == k[2] and s[0] == s[1] == s[2] and p[0] == p[1] == p[2] == k[0] // 2
-    assert conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1, 1)
-    return k[0], s[0]
-
-
-def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
-    """Fused Conv3d -> BN(eval) [-> +residual] [-> ReLU] [-> * sigmoid(gate)] on the selected engine."""
-    k, s = _conv_geometry(conv)
-    if CONV_ENGINE != "f32" and k == 3 and s in (1, 2) and conv.out_channels > 1:
-        nterms = _tiled_nterms()
-        srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-
-        def build():
-            sc, sh = fold_bn(bn) if bn is not None else (None, None)
-            return pack_conv_weight_bf16s(conv.weight, nterms), sc, sh
-        ws, scale, shift = _cache(owner).get(key + ("/f16s" if nterms == 19 else "/bf16s"), srcs, build)
-        return conv3d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms, residual, gate, stride=s)
-    if (CONV_ENGINE != "f32" and k == 3 and s == 1 and conv.out_channels == 1 and conv.in_channels in (16, 32, 64)
-            and residual is None and gate is None):
-        nterms = _head_nterms()
-        srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-
-        def build_head():
-            sc, sh = fold_bn(bn) if bn is not None else (None, None)
-            return pack_head_weight_bf16s(conv.weight, nterms), sc, sh
-        ws, scale, shift = _cache(owner).get(key + "/head_%d" % nterms, srcs, build_head)
-        return conv3d_head_bf16s_hip(x, ws, scale, shift, relu, nterms)
-    wp, scale, shift = _convbn_params(owner, key, conv, bn)
-    return conv3d_hip(x, wp, scale, shift, k, s, relu, residual, gate)
-
-
-# --------------------------------------------------------------------------------------
-# training: 3x3x3 Conv3d / ConvTranspose3d with HIP forward, data gradient and weight gradient
-# (main_us3d.py:186-222 back-propagates through the whole stack; BatchNorm with batch statistics and ReLU stay PyTorch)
-# --------------------------------------------------------------------------------------
-
-CLASSIFIER_CL = os.environ.get("SS_CLASSIFIER_CL", "1") != "0"    # 0: plain-layout intermediate inside the classifiers (two generic launches)
-TRAIN_HIP = os.environ.get("SS_TRAIN_HIP", "1") != "0"      # 0: the stock PyTorch layers whenever autograd / batch statistics are needed
-
-
-def conv3d_wgrad_hip(grad_out, x, Cout, Cin, stride):
-    """dW [Cout,Cin,3,3,3] of a 3x3x3, padding-1 Conv3d: grad_out [B,Cout,Do,Ho,Wo], x [B,Cin,D,H,W] (conv3d_wgrad.hip)."""
-    grad_out = grad_out if grad_out.is_contiguous() else grad_out.contiguous()
-    x = x if x.is_contiguous() else x.contiguous()
-    dev = _lib.require_device(grad_out, x)
-    B, _, D, H, W = x.shape
-    gw = torch.empty((Cout, Cin, 3, 3, 3), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(dev):
-        call("ss_conv3d_wgrad_fwd", ptr(grad_out), ptr(x), ptr(gw), B, Cin, D, H, W, Cout, int(stride))
-    return gw
-
-
-def _conv_k3_forward(x, w, stride):
-    """Conv3d(k3, p1, stride, no bias) on the selected engine, weights packed on the fly (they change every step)."""
-    if CONV_ENGINE != "f32" and w.shape[0] == 1 and stride == 1 and w.shape[1] in (16, 32, 64):
-        return conv3d_head_bf16s_hip(x, pack_head_weight_bf16s(w, _head_nterms()), None, None, False, _head_nterms())      # the 32 -> 1 classifier heads
-    if CONV_ENGINE == "f32":
-        return conv3d_hip(x, pack_conv_weight(w), None, None, 3, stride, False)
-    nterms = _tiled_nterms()
-    return conv3d_bf16s_hip(x, pack_conv_weight_bf16s(w, nterms), w.shape[0], None, None, False, nterms, stride=stride)
-
-
-def _deconv_k3_forward(x, w):
-    """ConvTranspose3d(k3, s2, p1, op1, no bias), weight [Cin,Cout,3,3,3]."""
-    wp = pack_conv_weight(w, transposed=True)
-    zero = torch.zeros(w.shape[1], dtype=x.dtype, device=x.device)
-    B, _, D, H, W = x.shape
-    workgroups = B * D * ((H + 3) // 4) * ((W + 31) // 32) * ((w.shape[1] + 31) // 32)
-    if CONV_ENGINE != "f32" and DECONV_BF16S and workgroups >= DECONV_MIN_WORKGROUPS:
-        return deconv3d_bf16s_hip(x, pack_deconv_weight_bf16s(wp, _deconv_nterms()), w.shape[1], zero, False, _deconv_nterms())
-    return deconv3d_hip(x, wp, zero, relu=False)
-
-
-class _Conv3dK3(torch.autograd.Function):
-    """y = conv3d(x, w, stride, padding=1).  dx: stride 1 = the same convolution with the taps flipped and the channel axes
-    swapped; stride 2 = the transposed convolution (the deconv kernels).  dw: conv3d_wgrad.hip."""
-
-    @staticmethod
-    def forward(ctx, x, w, stride):
-        x = x if x.is_contiguous() else x.contiguous()
-        ctx.save_for_backward(x, w)
-        ctx.stride = stride
-        return _conv_k3_forward(x, w.detach(), stride)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        g = g if g.is_contiguous() else g.contiguous()
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            if ctx.stride == 1:
-                gx = _conv_k3_forward(g, w.detach().transpose(0, 1).flip(2, 3, 4).contiguous(), 1)
-            else:
-                gx = _deconv_k3_forward(g, w.detach())          # w [Cout,Cin,...] read as ConvTranspose3d's [in,out,...]
-        if ctx.needs_input_grad[1]:
-            gw = conv3d_wgrad_hip(g, x, w.shape[0], w.shape[1], ctx.stride)
-        return gx, gw, None
-
-
-class _Deconv3dK3(torch.autograd.Function):
-    """y = conv_transpose3d(x, w, stride 2, padding 1, output_padding 1), w [Cin,Cout,3,3,3].  dx = the stride-2 convolution of
-    the output gradient with the same tensor read as a Conv3d weight [out=Cin, in=Cout]; dw = the stride-2 weight gradient
-    with the roles of input and output gradient swapped."""
-
-    @staticmethod
-    def forward(ctx, x, w):
-        x = x if x.is_contiguous() else x.contiguous()
-        ctx.save_for_backward(x, w)
-        return _deconv_k3_forward(x, w.detach())
-
-    @staticmethod
-    def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        g = g if g.is_contiguous() else g.contiguous()
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = _conv_k3_forward(g, w.detach(), 2)
-        if ctx.needs_input_grad[1]:
-            gw = conv3d_wgrad_hip(x, g, w.shape[0], w.shape[1], 2)
-        return gx, gw
-
-
-def _is_k3(conv, stride_ok=(1, 2)):
-    return (conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1) and conv.stride[0] == conv.stride[1] == conv.stride[2]
-            and conv.stride[0] in stride_ok and conv.dilation == (1, 1, 1) and conv.groups == 1 and conv.bias is None
-            and conv.padding_mode == "zeros")
-
-
-def conv3d_train(conv, x):
-    """nn.Conv3d's forward for the training path: the HIP autograd function for 3x3x3 layers on the GPU (stride 2 needs even
-    sizes: its data gradient is the k3-s2-p1-op1 transposed convolution), the stock layer otherwise."""
-    if (TRAIN_HIP and x.is_cuda and x.dtype == torch.float32 and isinstance(conv, nn.Conv3d) and _is_k3(conv)
-            and (conv.stride[0] == 1 or all(n % 2 == 0 for n in x.shape[2:]))):
-        PATH_COUNTS["hip_train"] = PATH_COUNTS.get("hip_train", 0) + 1
-        return _Conv3dK3.apply(x, conv.weight, conv.stride[0])
-    if isinstance(conv, (nn.Conv3d, nn.Conv2d)) and T.is_k1(conv):
-        return T.conv_k1(x, conv.weight, conv.bias)                       # redir1 / redir2, channelAtt.im_att (counts its own path)
-    PATH_COUNTS["torch"] += 1
-    return conv(x)
-
-
-def deconv3d_train(deconv, x):
-    if (TRAIN_HIP and x.is_cuda and x.dtype == torch.float32 and isinstance(deconv, nn.ConvTranspose3d) and deconv.kernel_size == (3, 3, 3)
-            and deconv.stride == (2, 2, 2) and deconv.padding == (1, 1, 1) and deconv.output_padding == (1, 1, 1)
-            and deconv.dilation == (1, 1, 1) and deconv.groups == 1 and deconv.bias is None):
-        PATH_COUNTS["hip_train"] = PATH_COUNTS.get("hip_train", 0) + 1
-        return _Deconv3dK3.apply(x, deconv.weight)
-    PATH_COUNTS["torch"] += 1
-    return deconv(x)
-
+# the functional layer (engine.py) and the training convolutions (train_layers.py) under their historical names: `modules.X`
+# keeps resolving for every function; the SWITCHES are engine.py's (see __getattr__ at the end of this file)
+from .engine import (PATH_COUNTS, _cache, _conv_geometry, _inference, _is_plain_3x3, _ParamCache, _ReplicaCache,  # noqa: F401
+                     classifier_cl_hip, conv2d_bf16s_hip, conv3d_bf16s_hip, conv3d_head_bf16s_hip, conv3d_hip,
+                     conv3d_pointwise_bf16s_hip, deconv3d_bf16s_hip, deconv3d_hip, fold_bn, pack_conv2d_weight_bf16s,
+                     pack_conv_weight, pack_conv_weight_bf16s, pack_deconv_weight_bf16s, pack_head_weight_bf16s,
+                     pack_pointwise_weight_bf16s, run_conv2d, run_convbn, stem_broadcast_half, stem_of_broadcast_and_volume,
+                     stem_presplit_applies, stem_volume_half, stem_volume_half_presplit, _aux_nterms, _deconv_nterms,
+                     _head_nterms, _tiled_nterms)
+from .train_layers import (_conv_k3_forward, _deconv_k3_forward, conv3d_train, conv3d_wgrad_hip, deconv3d_train)  # noqa: F401
 
 # --------------------------------------------------------------------------------------
 # building blocks with the reference's names
@@ -709,93 +163,6 @@ class ConcatFeature(nn.Sequential):
         return T.conv2d_k3(b, a(x))                               # training: BasicConv's own training path, then the 3x3 Conv2d
 
 
-STEM_LEFT_FUSED = os.environ.get("SS_STEM_LEFT_FUSED", "1") != "0"     # Q of the broadcast half on the fly (one launch) or through HBM (two)
-
-
-def _stem_halves_params(stem, C):
-    conv, bn = stem.conv, stem.bn if stem.use_bn else None
-    Cout = conv.out_channels
-    assert conv.in_channels == 2 * C and _conv_geometry(conv) == (3, 1)
-    srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-
-    def build():
-        sc, sh = fold_bn(bn) if bn is not None else (None, None)
-        w = conv.weight.detach().float()
-        wl = w[:, :C].reshape(Cout, C, 27)           # the left half's weights, unscaled: its sum joins the accumulator
-        wq = wl.permute(2, 0, 1).reshape(27 * Cout, C)                           # row tap*Cout + co (two-launch form)
-        # fused form: per pair of output channels 64 rows, row tap*2 + c = channel 2*pair + c, rows 54-63 zero
-        wf = torch.zeros(Cout // 2, 64, C, dtype=w.dtype, device=w.device)
-        wf[:, :54] = wl.reshape(Cout // 2, 2, C, 27).permute(0, 3, 1, 2).reshape(Cout // 2, 54, C)
-        return (pack_pointwise_weight_bf16s(wq), pack_pointwise_weight_bf16s(wf.reshape(Cout // 2 * 64, C)),
-                pack_conv_weight_bf16s(w[:, C:].contiguous(), _tiled_nterms()), sc, sh)
-    return _cache(stem).get("bc/halves/" + CONV_ENGINE, srcs, build)
-
-
-def stem_broadcast_half(stem, left, att):
-    """Partial sum of `stem` over its first C input channels when they are att * (the 2-D map `left` [B,C,H,W]
-    broadcast over the candidates): sum_tap att[pos+tap] * Q[tap](pos+tap), Q = a 1x1 projection of `left`
-    (3.6 instead of 87 GFLOP on the bench shape).  -> [B,Cout,nd,H,W], no BatchNorm / ReLU applied."""
-    assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, left, att)
-    C, Cout = left.shape[1], stem.conv.out_channels
-    nterms = _aux_nterms()
-    wq, wf, _, _, _ = _stem_halves_params(stem, C)
-    PATH_COUNTS["hip"] += 1
-    if C == 32 and Cout % 2 == 0 and STEM_LEFT_FUSED:
-        return ops.stem_left_fused(left, wf, att, Cout, nterms)
-    q = conv3d_pointwise_bf16s_hip(left, wq, 27 * Cout, None, None, False, nterms)               # [B, 27*Cout, H, W]
-    return ops.stem_left(q, att)
-
-
-def stem_volume_half(stem, right_vol, partial, gate=None):
-    """`stem` over its last C input channels (`right_vol` [B,C,nd,H,W]) continuing `partial`, then BatchNorm, ReLU
-    and the optional channelAtt gate (`gate` [B,Cout,H,W]: the SIGMOID of the gate's logits) on the total."""
-    assert stem.is_3d and not stem.deconv and CONV_ENGINE != "f32" and _inference(stem, right_vol, partial, gate)
-    nterms = _tiled_nterms()
-    _, _, wr, scale, shift = _stem_halves_params(stem, right_vol.shape[1])
-    g = None if gate is None else gate.contiguous()
-    return conv3d_bf16s_hip(right_vol, wr, stem.conv.out_channels, scale, shift, bool(stem.relu), nterms, None, g, partial=partial)
-
-
-#: SS_STEM_PRESPLIT=1: the warped half handed to the stem PRE-SPLIT (ss_concat_sampled_presplit_fwd -> ss_conv3d_presplit_fwd:
-#: LDS-DMA staging, no conversion, no per-chunk maximum in the conv; f16x3 engine only).  OFF by default: measured r03_d / r03_e
-#: (profiles/r03_e_bench_b1*.json) the stem launch takes 313-317 us in that form against 297-298 us with the fp32 volume and the
-#: on-the-fly split, the step 442.9 vs 452.3 pairs/s -- removing ALL staging arithmetic beside the matrix pipe does not speed
-#: the kernel up (nor did removing 16 % of it: 4.2 -> 3.55 VALU per MFMA at unchanged time, profiles/r03_b_pmc_conv_stem.txt)
-STEM_PRESPLIT = os.environ.get("SS_STEM_PRESPLIT", "0") != "0"
-
-
-def stem_presplit_applies(stem, right):
-    return (STEM_PRESPLIT and CONV_ENGINE == "f16x3" and right.shape[1] % 8 == 0 and stem.conv.in_channels == 2 * right.shape[1]
-            and _conv_geometry(stem.conv) == (3, 1))
-
-
-def stem_volume_half_presplit(stem, xs, xexp, partial, gate=None):
-    """stem_volume_half on the pre-split warped half (xs, xexp of ops.concat_volume_sampled_presplit)."""
-    assert stem.is_3d and not stem.deconv and CONV_ENGINE == "f16x3" and _inference(stem, partial, gate)
-    B, nchunks, _, D, H, W, _ = xs.shape
-    _, _, wr, scale, shift = _stem_halves_params(stem, nchunks * 8)
-    Cout = stem.conv.out_channels
-    g = None if gate is None else gate.contiguous()
-    dev = _lib.require_device(partial, scale, shift, g)
-    out = torch.empty((B, Cout, D, H, W), dtype=torch.float32, device=xs.device)
-    if partial is not None:
-        assert partial.shape == out.shape and partial.is_contiguous()
-    with torch.cuda.device(dev if dev is not None else xs.device):
-        call("ss_conv3d_presplit_fwd", ptr(xs), ptr(xexp), ptr(wr), ptr(partial), ptr(scale), ptr(shift), ptr(g), ptr(out),
-             B, nchunks * 8, D, H, W, Cout, int(bool(stem.relu)))
-    return out
-
-
-def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate=None):
-    """`stem` (a 3x3x3 stride-1 BasicConv with 2C input channels) applied to cat(att * left broadcast over the
-    candidates, right_vol) WITHOUT building the left half of that volume or convolving it: by linearity its
-    contribution (stem_broadcast_half) initialises the accumulators of the right half's convolution
-    (stem_volume_half) (models/SemStereo.py:241-244, 316-320).  Split-bf16 engines, inference only."""
-    return stem_volume_half(stem, right_vol, stem_broadcast_half(stem, left, att), gate)
-
-
-ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launches) | "fused" (one kernel per window)
-
 
 class attention_block(nn.Module):
     """Windowed multi-head self-attention + 1x1x1 conv; keys `qkv_3d.*`, `final1x1.*`."""
@@ -832,7 +199,7 @@ class attention_block(nn.Module):
     def _params_split(self):
         srcs = [self.qkv_3d.weight, self.qkv_3d.bias, self.final1x1.weight, self.final1x1.bias]
 
-        bf = CONV_ENGINE != "f32" and self.dim_3d in (32, 64, 128)
+        bf = E.CONV_ENGINE != "f32" and self.dim_3d in (32, 64, 128)
 
         def build():
             C = self.dim_3d
@@ -859,7 +226,7 @@ class attention_block(nn.Module):
             dev = _lib.require_device(x)
             B, C, D, H, W = x.shape
             assert C == self.dim_3d and D % self.block[0] == 0
-            if ATTENTION_FORM == "split":
+            if E.ATTENTION_FORM == "split":
                 # projection -> per-(window, 4 heads) attention -> projection: three launches that each fill
                 # the chip at batch 1 (the fused kernel has one workgroup per window)
                 wq, bq, wo, bo, bf = self._params_split()
@@ -952,16 +319,16 @@ class hourglass(nn.Module):
             wd = pack_conv_weight(dc.weight, transposed=True) * ds.reshape(1, 1, -1)
             wr = pack_conv_weight(rc.weight).reshape(rc.weight.shape[1], rc.weight.shape[0]) * rs.reshape(1, -1)
             wd, wr = wd.contiguous(), wr.contiguous()
-            return (wd, wr, (db + rb).contiguous(), pack_deconv_weight_bf16s(wd, _deconv_nterms()) if CONV_ENGINE != "f32" else None,
-                    pack_deconv_weight_bf16s(wr) if CONV_ENGINE != "f32" else None)
-        return _cache(self).get(key + "/" + CONV_ENGINE, srcs, build)
+            return (wd, wr, (db + rb).contiguous(), pack_deconv_weight_bf16s(wd, _deconv_nterms()) if E.CONV_ENGINE != "f32" else None,
+                    pack_deconv_weight_bf16s(wr) if E.CONV_ENGINE != "f32" else None)
+        return _cache(self).get(key + "/" + E.CONV_ENGINE, srcs, build)
 
     def _up(self, key, deconv_seq, redir_seq, x, skip):
         wd, wr, shift, wds, wrs = self._up_params(key, deconv_seq, redir_seq)
         B, _, D, H, W = x.shape
         workgroups = B * D * ((H + 3) // 4) * ((W + 31) // 32) * ((wd.shape[2] + 31) // 32)
         # layers with few workgroups: the exact-fp32 kernel's even/odd-plane split doubles them (see DECONV_MIN_WORKGROUPS)
-        if CONV_ENGINE != "f32" and DECONV_BF16S and workgroups >= DECONV_MIN_WORKGROUPS:
+        if E.CONV_ENGINE != "f32" and E.DECONV_BF16S and workgroups >= E.DECONV_MIN_WORKGROUPS:
             return deconv3d_bf16s_hip(x, wds, wd.shape[2], shift, True, _deconv_nterms(), skip, wrs)
         return deconv3d_hip(x, wd, shift, relu=True, skip=skip, skip_wpack=wr)
 
@@ -1017,7 +384,7 @@ class Classifier(nn.Sequential):
         if _inference(self, x):
             PATH_COUNTS["hip"] += 1
             c0, bn0, c2 = self[0][0], self[0][1], self[2]
-            if (CLASSIFIER_CL and CONV_ENGINE != "f32" and c0.in_channels == c0.out_channels == c2.in_channels == 32
+            if (E.CLASSIFIER_CL and E.CONV_ENGINE != "f32" and c0.in_channels == c0.out_channels == c2.in_channels == 32
                     and _conv_geometry(c0) == (3, 1) and _conv_geometry(c2) == (3, 1) and c2.out_channels == 1):
                 nt0, nt2 = _tiled_nterms(), _head_nterms()
 
@@ -1256,3 +623,23 @@ class SSR_upsample(nn.Module):
         prob = torch.sigmoid(self.conv1(pred_label * weights))
         prob = torch.sigmoid(self.conv2(prob * weights))
         return (depth_ + self.conv3(depth * prob)).squeeze(1)
+
+
+def __getattr__(name):
+    """`modules.CONV_ENGINE` and the other switches are engine.py's attributes: reads are forwarded (SET them on
+    semstereo_amd.engine -- an assignment to `modules.X` would only create a dead attribute here, so __init__ refuses it)."""
+    if name in E.SWITCHES:
+        return getattr(E, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+class _TwinsModule(__import__("types").ModuleType):
+    """An assignment `modules.CONV_ENGINE = ...` would create an attribute nothing reads: refuse it loudly."""
+
+    def __setattr__(self, name, value):
+        if name in E.SWITCHES:
+            raise AttributeError(f"set semstereo_amd.engine.{name}, not semstereo_amd.modules.{name} (the switches live in engine.py)")
+        super().__setattr__(name, value)
+
+
+__import__("sys").modules[__name__].__class__ = _TwinsModule

@@ -324,13 +324,6 @@ def upsample_softmax_regression_applies(coarse, maxdisp, H, W, _range=None):
             and W % 2 == 0 and nd <= 128)
 
 
-def _topk_reference_math(cost, disparity_samples, k):
-    _, ind = cost.sort(dim=1, descending=True, stable=True)
-    pool = ind[:, :k]
-    prob = F.softmax(torch.gather(cost, 1, pool), 1)
-    return torch.sum(torch.gather(disparity_samples, 1, pool) * prob, dim=1, keepdim=True)
-
-
 class _RegressionTopk(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cost, samples, k):
@@ -371,19 +364,6 @@ def regression_topk(cost, disparity_samples, k):
 # --------------------------------------------------------------------------------------
 # candidate warping
 # --------------------------------------------------------------------------------------
-
-def _warp_reference_math(x, y, disp):
-    """The reference's composition (meshgrid -> normalise -> grid_sample), used for BACKWARD only."""
-    B, C, H, W = y.shape
-    nd = disp.shape[1]
-    rows = torch.arange(H, dtype=x.dtype, device=x.device).reshape(1, 1, H, 1).expand(B, nd, H, W)
-    cols = torch.arange(W, dtype=x.dtype, device=x.device).reshape(1, 1, 1, W).expand(B, nd, H, W)
-    gx = (cols - disp) / ((W - 1.0) / 2.0) - 1.0
-    gy = rows / ((H - 1.0) / 2.0) - 1.0
-    grid = torch.stack([gx, gy], dim=4).reshape(B, nd * H, W, 2)
-    yw = F.grid_sample(y, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
-    return yw.reshape(B, C, nd, H, W)
-
 
 class _WarpSampled(torch.autograd.Function):
     @staticmethod

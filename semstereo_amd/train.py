@@ -11,7 +11,7 @@ kernels, for what the 3x3x3 conv / transposed-conv functions of modules.py (`_Co
   window_attention     the windowed attention core                                models/submodule_other.py:805-834
 
 Each falls back to the stock PyTorch layer (and counts it in modules.PATH_COUNTS["torch"]) for shapes the kernels are not
-built for.  `modules.TRAIN_HIP = False` (SS_TRAIN_HIP=0) sends everything to PyTorch.
+built for.  `engine.TRAIN_HIP = False` (SS_TRAIN_HIP=0) sends everything to PyTorch.
 """
 import torch
 import torch.nn as nn

@@ -19,7 +19,7 @@ def _cpu_fused_kernels(monkeypatch):
     M, ops = sa.modules, sa.ops
     monkeypatch.setattr(dfr, "on", lambda module, *ts: dfr.ENABLED and not getattr(dfr._TLS, "depth", 0))
     monkeypatch.setattr(M, "_inference", lambda module, *ts: False)
-    monkeypatch.setattr(M, "CONV_ENGINE", "f32")                 # stem_of: volume kernel + concat_stem(volume, gate) form
+    monkeypatch.setattr(sa.engine, "CONV_ENGINE", "f32")                 # stem_of: volume kernel + concat_stem(volume, gate) form
 
     def gwc_patch_gate(fl, fr, maxdisp, groups, patch_weight, gate_logits=None, normalize=True, _range=None):
         assert _range == (-maxdisp, 2 * maxdisp)

@@ -462,10 +462,10 @@ def test_attention_block_forms_agree(sa, shape):
     try:
         with torch.no_grad():
             for form in ("split", "fused"):
-                sa.modules.ATTENTION_FORM = form
+                sa.engine.ATTENTION_FORM = form
                 outs[form] = mod(x)
     finally:
-        sa.modules.ATTENTION_FORM = old
+        sa.engine.ATTENTION_FORM = old
     # the reference: the ORACLE's restatement of the block (oracle/stack.py, pinned to the reference's fixtures attn_pad /
     # attn_pad_w), not the module's own PyTorch path
     P = {"ab." + k: v.detach().cpu() for k, v in mod.state_dict().items()}
@@ -535,12 +535,12 @@ def test_stem_by_halves_equals_the_full_convolution(sa, shape):
     old = sa.modules.STEM_LEFT_FUSED
     try:
         for flag in (False, True):
-            sa.modules.STEM_LEFT_FUSED = flag
+            sa.engine.STEM_LEFT_FUSED = flag
             with torch.no_grad():
                 yy = sa.modules.stem_of_broadcast_and_volume(stem, dev(left), dev(att), dev(right), torch.sigmoid(dev(gate)))
             assert float((yy.double().cpu() - ref).abs().max()) <= 2.0 * e_full + 1e-6, flag
     finally:
-        sa.modules.STEM_LEFT_FUSED = old
+        sa.engine.STEM_LEFT_FUSED = old
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 24, 9, 37), (1, 32, 6, 5, 70), (1, 32, 32, 3, 3), (1, 32, 24, 40, 96), (1, 32, 6, 13, 65)])
@@ -664,7 +664,7 @@ def test_classifier_channels_last_handoff_is_bit_identical(sa, shape, monkeypatc
     x = dev(dd.t_normalish((B, 32, D, H, W), 912))
     outs = []
     for flag in (True, False):
-        monkeypatch.setattr(sa.modules, "CLASSIFIER_CL", flag)
+        monkeypatch.setattr(sa.engine, "CLASSIFIER_CL", flag)
         with torch.no_grad():
             outs.append(m(x))
     assert outs[0].shape == (B, 1, D, H, W)
@@ -766,14 +766,14 @@ def test_conv3d_split_bf16_engine(sa, case, nterms):
 def test_hot_segment_on_each_conv_engine(sa, golden, engine):
     name = "s128"
     old = sa.modules.CONV_ENGINE
-    sa.modules.CONV_ENGINE = engine
+    sa.engine.CONV_ENGINE = engine
     try:
         seg, P = _segment(sa, cases.SEGMENT[name][3])
         fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
         with torch.no_grad():
             r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
     finally:
-        sa.modules.CONV_ENGINE = old
+        sa.engine.CONV_ENGINE = old
     g = golden["segment"]
     same = (r["samples"].cpu().numpy().astype(np.int16) == g[f"{name}/samples"]).mean()
     REPORT[f"segment_{engine}/samples_equal_fraction"] = float(same)
@@ -791,19 +791,66 @@ def test_hot_segment_on_each_conv_engine(sa, golden, engine):
         assert float(err.median()) <= 1e-5 and int((err > 1e-3).sum()) <= 1, float(err.max())      # see the fixture test
 
 
+_NON_DEFAULT = {
+    # name: (object path, attribute, value) -- every switch of DESIGN.md section 5 whose non-default side is a different code path
+    "SS_DEFER=0": ("deferred", "ENABLED", False),
+    "SS_OVERLAP=0": ("segment.HotSegment", "OVERLAP", False),
+    "SS_OVERLAP=1": ("segment.HotSegment", "OVERLAP", True),
+    "SS_FUSED=0": ("segment.HotSegment", "FUSED", False),
+    "SS_GWC_PATCH_FUSED=0": ("segment.HotSegment", "GWC_PATCH_FUSED", False),
+    "SS_STEM_HALVES=0": ("segment.HotSegment", "STEM_BY_HALVES", False),
+    "SS_STEM_LEFT_FUSED=0": ("engine", "STEM_LEFT_FUSED", False),
+    "SS_STEM_PRESPLIT=1": ("engine", "STEM_PRESPLIT", True),
+    "SS_ATTENTION=fused": ("engine", "ATTENTION_FORM", "fused"),
+    "SS_HEAD_F16=1": ("engine", "HEAD_F16", True),
+    "SS_DECONV_F16=0": ("engine", "DECONV_F16", False),
+    "SS_DECONV_MIN_WGS=256": ("engine", "DECONV_MIN_WORKGROUPS", 256),
+    "SS_CLASSIFIER_CL=0": ("engine", "CLASSIFIER_CL", False),
+    "SS_CONV2D_HIP=0": ("engine", "CONV2D_HIP", False),
+}
+
+
+@pytest.mark.parametrize("setting", sorted(_NON_DEFAULT))
+def test_hot_segment_under_every_non_default_switch(sa, golden, setting, monkeypatch):
+    """the driver only ever runs the defaults, so the other side of every switch gets its own run of the hot
+    segment here, against the reference's fixture: identical candidates, pred_att within 1e-3 px, at most an isolated top-2 flip
+    in pred (the criterion of test_hot_segment_on_each_conv_engine)."""
+    path, attr, value = _NON_DEFAULT[setting]
+    obj = sa
+    for part in path.split("."):
+        obj = getattr(obj, part)
+    monkeypatch.setattr(obj, attr, value)
+    name = "s128"
+    seg, P = _segment(sa, cases.SEGMENT[name][3])
+    fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
+    before = dict(sa.modules.PATH_COUNTS)
+    with torch.no_grad():
+        r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
+    r = {k: sa.deferred.real(v) for k, v in r.items()}
+    # (SS_CONV2D_HIP=0 hands concat_feature to MIOpen by design -- counted; nothing else may leave the HIP path)
+    if setting != "SS_CONV2D_HIP=0":
+        assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "a PyTorch fallback ran"
+    g = golden["segment"]
+    assert (r["samples"].cpu().numpy().astype(np.int16) == g[f"{name}/samples"]).all(), setting
+    check(f"switch/{setting}/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)
+    err = (r["pred"].cpu() - torch.as_tensor(g[f"{name}/pred"])).abs()
+    REPORT[f"switch/{setting}/pred"] = float(err.max())
+    assert float(err.median()) <= 1e-5 and int((err > 1e-3).sum()) <= 1, (setting, float(err.max()))
+
+
 @pytest.mark.parametrize("hip2d", [True, False])
 def test_hot_segment_with_hip_2d_convs(sa, golden, hip2d):
     """SS_CONV2D_HIP: concat_feature's two 3x3 2-D convs on the split engine (default with f16x3) or on MIOpen."""
     name = "s128"
     old = sa.modules.CONV2D_HIP
-    sa.modules.CONV2D_HIP = hip2d
+    sa.engine.CONV2D_HIP = hip2d
     try:
         seg, P = _segment(sa, cases.SEGMENT[name][3])
         fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
         with torch.no_grad():
             r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
     finally:
-        sa.modules.CONV2D_HIP = old
+        sa.engine.CONV2D_HIP = old
     g = golden["segment"]
     assert (r["samples"].cpu().numpy().astype(np.int16) == g[f"{name}/samples"]).all()
     check("segment_conv2d_hip/pred_att", r["pred_att"], g[f"{name}/pred_att"], 1e-3)

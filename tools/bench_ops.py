@@ -17,6 +17,7 @@ import semstereo_amd as sa  # noqa: E402
 from semstereo_amd import deferred as _dfr  # noqa: E402
 _dfr.ENABLED = False          # these tools time / inspect each op by itself: no deferred handles
 from semstereo_amd import modules as M  # noqa: E402
+from semstereo_amd import engine as sa_engine  # noqa: E402
 
 PEAK_TF, PEAK_GBS = 157.3, 8000.0
 
@@ -50,7 +51,7 @@ def main():
     args = ap.parse_args()
     B, S, md = args.batch, args.size, args.maxdisp
     if args.engine:
-        M.CONV_ENGINE = args.engine
+        sa_engine.CONV_ENGINE = args.engine
     dev = torch.device("cuda")
     rows = []
 

@@ -19,12 +19,13 @@ import semstereo_amd as sa  # noqa: E402
 from semstereo_amd import deferred as _dfr  # noqa: E402
 _dfr.ENABLED = False
 from semstereo_amd import modules as M  # noqa: E402
+from semstereo_amd import engine as sa_engine  # noqa: E402
 from golden import cases  # noqa: E402
 from oracle import hot_segment as oseg  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "s256_md128_cal"
 if len(sys.argv) > 2:
-    M.CONV_ENGINE = sys.argv[2]
+    sa_engine.CONV_ENGINE = sys.argv[2]
 full = name in cases.SEGMENT_FULL
 g = np.load(os.path.join(ROOT, "tests", "golden", "segment_full.npz" if full else "segment.npz"))
 B, H, W, maxdisp = cases.segment_shape(name)

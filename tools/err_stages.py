@@ -22,13 +22,14 @@ import semstereo_amd as sa  # noqa: E402
 from semstereo_amd import deferred as _dfr  # noqa: E402
 _dfr.ENABLED = False
 from semstereo_amd import modules as M  # noqa: E402
+from semstereo_amd import engine as sa_engine  # noqa: E402
 from semstereo_amd import ops  # noqa: E402
 from golden import cases  # noqa: E402
 from oracle import hot_segment as oseg, ops as oops, stack  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "s256_md128_cal"
 if len(sys.argv) > 2:
-    M.CONV_ENGINE = sys.argv[2]
+    sa_engine.CONV_ENGINE = sys.argv[2]
 g = np.load(os.path.join(ROOT, "tests", "golden", "segment.npz"))
 B, H, W, maxdisp = cases.segment_shape(name)
 m4, m8 = maxdisp // 4, maxdisp // 8
@@ -86,7 +87,7 @@ with torch.no_grad():
     part_h = M.stem_broadcast_half(seg.concat_stem, cu(cl64), att.cuda())
     report("stem broadcast half (partial sum)", part_h, F.conv3d(att * f32(lb64), P["concat_stem.conv.weight"][:, :32], None, 1, 1), left64)
     right_h = ops.concat_volume_sampled(None, cu(cr64), smp.cuda(), att.cuda())
-    report("warped half x att", right_h, att * f32(rw64), att.double() * rw64)
+    report("warped half x att", right_h, att * oops.SpatialTransformer_grid(f32(cl64), f32(cr64), smp)[0], att.double() * rw64)
     vol64 = att.double() * torch.cat((lb64, rw64), dim=1)
     stem64 = stack.channel_att(P64, "concat_feature_att_4", stack.basic_conv(P64, "concat_stem", vol64, is_3d=True), fl4.double())
     stem_h = M.stem_volume_half(seg.concat_stem, cu(att.double() * rw64), cu(left64), cu(gate64))

@@ -13,13 +13,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import semstereo_amd as sa  # noqa: E402
 from semstereo_amd import modules as M  # noqa: E402
+from semstereo_amd import engine as sa_engine  # noqa: E402
 from semstereo_amd import ops  # noqa: E402
 from oracle import hot_segment as oseg  # noqa: E402
 
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 maxdisp = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 if len(sys.argv) > 3:
-    M.CONV_ENGINE = sys.argv[3]
+    sa_engine.CONV_ENGINE = sys.argv[3]
 dev = torch.device("cuda")
 seg = sa.HotSegment(maxdisp).to(dev).eval()
 bench.init_unit_gain(seg, 1234)

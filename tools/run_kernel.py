@@ -39,7 +39,7 @@ elif name in ("head", "head_att"):
     fn = lambda: M.conv3d_head_bf16s_hip(x, ws, None, None, False, 6)          # noqa: E731
     nbytes = 4.0 * B * 33 * D * H * H
 elif name in ("classif", "classif_plain"):                # the whole classifier: conv 32->32 + BN + ReLU, then the 32->1 head
-    M.CLASSIFIER_CL = name == "classif"
+    sa.engine.CLASSIFIER_CL = name == "classif"
     cl = M.Classifier(32).to(dev).eval()
     x = torch.relu(R(B, 32, 24, 256, 256))
     fn = lambda: cl(x)                                                         # noqa: E731
