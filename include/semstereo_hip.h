@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (10 since round 3; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (11 since round 4; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -372,6 +372,15 @@ int ss_batchnorm_train_fwd(const float* x, const float* weight, const float* bia
 int ss_batchnorm_train_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
                            const float* weight, float* grad_x, double* work, int B, int C, long long N, int relu,
                            ss_stream_t stream);
+/* The same pair with a residual joining behind the normalisation and before the ReLU: y = relu(bn(x) + residual) -- the
+ * `F.relu(self.conv5(conv4) + self.redir2(conv2))` of hourglass.forward in train() (models/SemStereo.py:141-142) in one pass;
+ * backward: also grad_residual [B,C,N] = grad_y behind the ReLU mask. */
+int ss_batchnorm_train_res_fwd(const float* x, const float* residual, const float* weight, const float* bias, float* y, float* mean,
+                               float* invstd, float* var_unbiased, double* work, int B, int C, long long N, float eps, int relu,
+                               ss_stream_t stream);
+int ss_batchnorm_train_res_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                               const float* weight, float* grad_x, float* grad_residual, double* work, int B, int C, long long N,
+                               int relu, ss_stream_t stream);
 /* Weight gradient of the 1x1(x1) convolutions (redir1 / redir2 `models/SemStereo.py:131-132`, attention_block.qkv_3d /
  * final1x1 `models/submodule_other.py:799-800`, channelAtt.im_att `models/SemStereo.py:92-95`):
  * grad_out [B,Cout,npos], in [B,Cin,npos] -> grad_w [Cout,Cin]. */
@@ -392,6 +401,29 @@ int ss_channel_gate_bwd_logits(const float* grad_out, const float* cv, const flo
  * the window (no pad tokens): qkv [B,3C,D,H,W], grad_y [B,C,D,H,W] -> grad_qkv [B,3C,D,H,W]. */
 int ss_window_attention_core_bwd(const float* qkv, const float* grad_y, float* grad_qkv, int B, int C, int D, int H, int W,
                                  int heads, int bd, int bh, int bw, ss_stream_t stream);
+/* ... for any H, W (r04): the reference zero-pads the volume BEFORE the qkv Linear (models/submodule_other.py:808-813), so a pad
+ * token's q / k / v are that Linear's bias `bqkv` [3C] (the qkv tensor holds real positions only), its output is cropped, and a logit
+ * between a pad and a real token carries -1000 when BOTH H and W were padded (:822-829).  grad_bias [3C] (zeroed by the call) receives
+ * what reaches the pad tokens' q / k / v: the extra term of the Linear's bias gradient. */
+int ss_window_attention_core_pad_bwd(const float* qkv, const float* bqkv, const float* grad_y, float* grad_qkv, float* grad_bias, int B,
+                                     int C, int D, int H, int W, int heads, int bd, int bh, int bw, ss_stream_t stream);
+/* Backward of the three fused attention-tail launches (training; models/SemStereo.py:279-310 under autograd; r04).  Each recomputes
+ * its forward quantities from the saved inputs.  Gradient outputs that are scattered into neighbouring pixels (fp32 atomics) are
+ * zeroed by the call; any gradient input / output pointer may be NULL unless said otherwise.
+ *   ss_upsample_softmax_regression_bwd  :279-285  up [B,1,D,H,W] (the forward's output), grad_up / grad_disp [B,H,W] / grad_var [B,1,H,W]
+ *                                                 -> grad_coarse [B,1,D/2,H/2,W/2] (required); work: B*D*H*W floats of scratch
+ *   ss_sample_strength_bwd              :286-293  grad_strength [B,5,H,W] (required) -> grad_left / grad_right [B,C,H,W], grad_pred0 [B,H,W],
+ *                                                 grad_var [B,1,H,W], grad_gamma_beta [2]
+ *   ss_topk_candidates_bwd              :295-310  samples [B,K,H,W] = the forward's selection; grad_att_topk [B,1,K,H,W], grad_pred_att [B,H,W]
+ *                                                 -> grad_logits [B,1,D,H,W], grad_strength [B,5,H,W] */
+int ss_upsample_softmax_regression_bwd(const float* up, const float* grad_up, const float* grad_disp, const float* grad_var,
+                                       float* grad_coarse, float* work, int B, int dmin, int ndisp, int H, int W, ss_stream_t stream);
+int ss_sample_strength_bwd(const float* left, const float* right, const float* pred0, const float* var, const float* gamma,
+                           const float* beta, const float* grad_strength, float* grad_left, float* grad_right, float* grad_pred0,
+                           float* grad_var, float* grad_gamma_beta, int B, int C, int H, int W, ss_stream_t stream);
+int ss_topk_candidates_bwd(const float* logits, const float* strength, const float* samples, const float* grad_att_topk,
+                           const float* grad_pred_att, float* grad_logits, float* grad_strength, int B, int dmin, int ndisp, int H, int W,
+                           int k, ss_stream_t stream);
 /* Measurement aid (bench.py): a plain device copy, 16 bytes per lane, nontemporal -- the HBM rate a streaming kernel can
  * reach on this box, which SURVEY.md section 8(d) asks the bandwidth fractions to be read against.  bytes % 16 == 0. */
 int ss_tool_copy_fwd(const void* src, void* dst, long long bytes, ss_stream_t stream);

@@ -18,7 +18,7 @@ TOPK = 24  # models/SemStereo.py:301
 GWC_CLOSED_FORM = False      # True: ops.build_gwc_volume_norm_closed_form (bit-identical, 200x faster on the CPU) at :273
 
 
-def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None, unsigned=False):
+def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None, unsigned=False, force_samples=None):
     """models/SemStereo.py:273-310.  Returns (att_topk [B,1,k,H4,W4],
     disparity_sample_topk [B,k,H4,W4], pred_att [B,H4,W4]).
     unsigned: models/SemStereo_WHU.py's two differing lines (:279 maxdisp//4 planes, :305 no offset) on the unsigned op
@@ -37,7 +37,7 @@ def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None, unsigned=False):
         prob0 = F.softmax(att_weights.squeeze(1), dim=1)
         pred0 = uops.disparity_regression(prob0, m4)
         var = uops.disparity_variance(prob0, m4, pred0.unsqueeze(1))
-        return _attention_tail(P, fl4, fr4, att_weights, pred0, var, 0, out, corr, cost_att)
+        return _attention_tail(P, fl4, fr4, att_weights, pred0, var, 0, out, corr, cost_att, force_samples)
     gwc = ops.build_gwc_volume_norm_closed_form if GWC_CLOSED_FORM else ops.build_gwc_volume_norm
     corr = gwc(fl8, fr8, maxdisp // 8, C8 // 8)                                        # :273
     corr = stack.patch_conv(P, corr)                                                   # :274
@@ -48,11 +48,13 @@ def attention_branch(P, fl8, fr8, fl4, fr4, maxdisp, out=None, unsigned=False):
     prob0 = F.softmax(att_weights.squeeze(1), dim=1)                                   # :281-282
     pred0 = ops.disparity_regression(prob0, m4)                                        # :283
     var = ops.disparity_variance(prob0, m4, pred0.unsqueeze(1))                        # :285
-    return _attention_tail(P, fl4, fr4, att_weights, pred0, var, -m4, out, corr, cost_att)
+    return _attention_tail(P, fl4, fr4, att_weights, pred0, var, -m4, out, corr, cost_att, force_samples)
 
 
-def _attention_tail(P, fl4, fr4, att_weights, pred0, var, dmin, out, corr, cost_att):
-    """models/SemStereo.py:286-310; `dmin`: the disparity of plane 0 (-maxdisp//4, or 0 in SemStereo_WHU.py:305)."""
+def _attention_tail(P, fl4, fr4, att_weights, pred0, var, dmin, out, corr, cost_att, force_samples=None):
+    """models/SemStereo.py:286-310; `dmin`: the disparity of plane 0 (-maxdisp//4, or 0 in SemStereo_WHU.py:305).
+    force_samples [B,k,H4,W4]: take THESE candidates instead of the graph's own top-24 (gradient checks of another
+    evaluation whose picks differ at near-ties: everything downstream of the pick is then compared like for like)."""
     var = torch.sigmoid(P["beta"] + P["gamma"] * var)                                  # :286-287
     var_samples = ops.propagation(var)                                                 # :288
     disp_samples = ops.propagation(pred0.unsqueeze(1))                                 # :289
@@ -64,6 +66,11 @@ def _attention_tail(P, fl4, fr4, att_weights, pred0, var, dmin, out, corr, cost_
     aw_prob = F.softmax(aw, dim=2)                                                     # :298
     _, ind = aw_prob.sort(2, True)                                                     # :299
     ind_k = ind[:, :, :TOPK].sort(2, False)[0]                                         # :302-303
+    if out is not None:
+        srt = aw_prob.sort(2, True)[0]
+        out.update(gap24_rel=((srt[:, :, TOPK - 1] - srt[:, :, TOPK]) / srt[:, :, TOPK - 1]).squeeze(1))
+    if force_samples is not None:
+        ind_k = (force_samples - dmin).round().long().unsqueeze(1)
     att_topk = torch.gather(aw_prob, 2, ind_k)                                         # :304
     samples = ind_k.squeeze(1).float() + dmin                                          # :305
     att_prob = F.softmax(torch.gather(aw, 2, ind_k).squeeze(1), dim=1)                 # :307-308

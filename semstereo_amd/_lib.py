@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -69,13 +69,19 @@ _SIGNATURES = {
     "ss_window_attention_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_tool_copy_fwd": [_P, _P, ctypes.c_longlong, _P],
+    "ss_upsample_softmax_regression_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_sample_strength_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ss_topk_candidates_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ss_batchnorm_train_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, ctypes.c_float, _I, _P],
     "ss_batchnorm_train_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],
+    "ss_batchnorm_train_res_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, ctypes.c_float, _I, _P],
+    "ss_batchnorm_train_res_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],
     "ss_channel_sum_fwd": [_P, _P, _I, _I, ctypes.c_longlong, _P],
     "ss_conv_k1_wgrad_fwd": [_P, _P, _P, _I, _I, _I, ctypes.c_longlong, _P],
     "ss_depthwise_patch_wgrad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_channel_gate_bwd_logits": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_core_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_window_attention_core_pad_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 EXPORTS = sorted(list(_SIGNATURES) + ["ss_abi_version", "ss_status_string", "ss_last_hip_error", "ss_ssr_param_count", "ss_reload_tuning"])
 

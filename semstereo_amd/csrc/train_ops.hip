@@ -64,8 +64,9 @@ __global__ void bn_finish_stats_kernel(const double* __restrict__ sums, float* _
     var_unbiased[c] = (float)(count > 1.0 ? v * count / (count - 1.0) : v);
 }
 
-// y = (x - mean) * invstd * w + b  [ReLU]
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+// y = (x - mean) * invstd * w + b  [+ res]  [ReLU]      (res: the skip branch of the hourglass, models/SemStereo.py:141-142)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int C, long long N,
                                                         long long total, int relu) {
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int c = (int)((i / N) % C);
     const float sc = invstd[c] * (w ? w[c] : 1.f), sh = (bias ? bias[c] : 0.f) - mean[c] * sc;
     float v = x[i] * sc + sh;
+    if (res) v += res[i];
     if (relu) v = fmaxf(v, 0.f);
     y[i] = v;
 }
@@ -82,13 +84,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ w,
-                                                            const double* __restrict__ sums, float* __restrict__ dx, int C,
+                                                            const double* __restrict__ sums, float* __restrict__ dx,
+                                                            float* __restrict__ dres, int C,
                                                             long long N, long long total, double count, int relu) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c = (int)((i / N) % C);
     float gv = g[i];
     if (relu && !(y[i] > 0.f)) gv = 0.f;
+    if (dres) dres[i] = gv;                   // the residual's gradient: the incoming one behind the ReLU mask
     const float xh = (x[i] - mean[c]) * invstd[c];
     const float mg = (float)(sums[2 * c] / count), mgx = (float)(sums[2 * c + 1] / count);
     dx[i] = (w ? w[c] : 1.f) * invstd[c] * (gv - mg - xh * mgx);
@@ -147,13 +151,19 @@ __global__ __launch_bounds__(256) void gate_bwd_logits_kernel(const float* __res
 }
 
 // ---- windowed attention core, backward (models/submodule_other.py:805-834) ------------------------------------------------------
-// qkv [B,3C,D,H,W] (C = heads * 8), gy [B,C,D,H,W] = gradient of y = softmax(q k^T * scale) v per (window, head), un-partitioned.
-// -> gqkv [B,3C,D,H,W].  One workgroup per (window, head): q, k, v, gy tiles [T][8] and the probabilities [T][T] in LDS.
-// Unpadded volumes only (H % bh == 0, W % bw == 0: no pad tokens, no mask).
+// qkv [B,3C,D,H,W] (C = heads * 8), gy [B,C,D,H,W] = gradient of y = softmax(q k^T * scale [+ pad mask]) v per (window, head),
+// un-partitioned.  -> gqkv [B,3C,D,H,W].  One workgroup per (window, head): q, k, v, gy tiles [T][8] and the probabilities
+// [T][T] in LDS.
+// Volumes whose H, W are not window multiples (r04): the reference zero-pads the volume BEFORE the qkv Linear
+// (models/submodule_other.py:808-813), so a pad token's q / k / v are the Linear's bias -- `bqkv` [3C] here, the qkv tensor
+// holds real positions only -- its output is cropped (gradient 0), and a logit between a pad and a real token gets -1000 when
+// BOTH H and W were padded (`mask_on`; the reference's `-0:` slices mark every token when only one was, :822-823: no mask).
+// What reaches a pad token's q / k / v is the bias's gradient: accumulated into gbias [3C] (fp32 atomics).
 template <int T>
-__global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ gy,
-                                                                         float* __restrict__ gqkv, int C, int D, int H, int W,
-                                                                         int heads, int bd, int bh, int bw, float scale) {
+__global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bqkv,
+                                                                         const float* __restrict__ gy, float* __restrict__ gqkv,
+                                                                         float* __restrict__ gbias, int C, int D, int H, int W,
+                                                                         int heads, int bd, int bh, int bw, float scale, int mask_on) {
     constexpr int HD = 8;
     extern __shared__ __attribute__((aligned(16))) float sm_att[];          // 4 x [T][9] + 2 x [T][T + 1] floats (88 KB at T = 96)
     float (*q)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(sm_att);
@@ -162,35 +172,40 @@ __global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const fl
     float (*go)[HD + 1] = v + T;
     float (*P)[T + 1] = reinterpret_cast<float (*)[T + 1]>(sm_att + 4 * T * (HD + 1));
     float (*dS)[T + 1] = P + T;
+    __shared__ unsigned char is_pad[T];
     const int head = blockIdx.y, b = blockIdx.z;
-    const int nw = W / bw, nh = H / bh;
+    const int nw = (W + bw - 1) / bw, nh = (H + bh - 1) / bh;
     int win = blockIdx.x;
     const int ww = win % nw; win /= nw;
     const int wh = win % nh; win /= nh;
     const int wd = win;
     const long long plane = (long long)H * W, vol = (long long)D * plane;
-    auto pos = [&](int t) {                       // token t of the window -> flat spatial offset (d, h, w order as the partition)
+    auto pos = [&](int t, bool& inside) {         // token t of the window -> flat spatial offset (d, h, w order as the partition)
         const int tw = t % bw, th = (t / bw) % bh, td = t / (bw * bh);
-        return (long long)(wd * bd + td) * plane + (long long)(wh * bh + th) * W + (ww * bw + tw);
+        const int gh = wh * bh + th, gw = ww * bw + tw;
+        inside = gh < H && gw < W;
+        return (long long)(wd * bd + td) * plane + (long long)gh * W + gw;
     };
     const float* qb = qkv + (long long)b * 3 * C * vol;
     for (int e = threadIdx.x; e < T * HD; e += 256) {
         const int t = e / HD, j = e % HD;
-        const long long p = pos(t);
+        bool in;
+        const long long p = pos(t, in);
         const int ch = head * HD + j;
-        q[t][j] = qb[(long long)ch * vol + p];
-        k[t][j] = qb[(long long)(C + ch) * vol + p];
-        v[t][j] = qb[(long long)(2 * C + ch) * vol + p];
-        go[t][j] = gy[((long long)b * C + ch) * vol + p];
+        q[t][j] = in ? qb[(long long)ch * vol + p] : bqkv[ch];
+        k[t][j] = in ? qb[(long long)(C + ch) * vol + p] : bqkv[C + ch];
+        v[t][j] = in ? qb[(long long)(2 * C + ch) * vol + p] : bqkv[2 * C + ch];
+        go[t][j] = in ? gy[((long long)b * C + ch) * vol + p] : 0.f;
+        if (j == 0) is_pad[t] = in ? 0 : 1;
     }
     __syncthreads();
-    // P = softmax(q k^T * scale) row-wise; dP = go v^T
+    // P = softmax(q k^T * scale + mask) row-wise; dP = go v^T
     for (int e = threadIdx.x; e < T * T; e += 256) {
         const int i = e / T, j = e % T;
         float s = 0.f, dp = 0.f;
 #pragma unroll
         for (int c = 0; c < HD; ++c) { s += q[i][c] * k[j][c]; dp += go[i][c] * v[j][c]; }
-        P[i][j] = s * scale;
+        P[i][j] = s * scale + ((mask_on && is_pad[i] != is_pad[j]) ? -1000.0f : 0.f);
         dS[i][j] = dp;
     }
     __syncthreads();
@@ -213,11 +228,18 @@ __global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const fl
             dk += dS[j][t] * q[j][c];
             dv += P[j][t] * go[j][c];
         }
-        const long long p = pos(t);
+        bool in;
+        const long long p = pos(t, in);
         const int ch = head * HD + c;
-        gb[(long long)ch * vol + p] = dq;
-        gb[(long long)(C + ch) * vol + p] = dk;
-        gb[(long long)(2 * C + ch) * vol + p] = dv;
+        if (in) {
+            gb[(long long)ch * vol + p] = dq;
+            gb[(long long)(C + ch) * vol + p] = dk;
+            gb[(long long)(2 * C + ch) * vol + p] = dv;
+        } else if (gbias != nullptr) {
+            unsafeAtomicAdd(&gbias[ch], dq);
+            unsafeAtomicAdd(&gbias[C + ch], dk);
+            unsafeAtomicAdd(&gbias[2 * C + ch], dv);
+        }
     }
 }
 
@@ -233,9 +255,9 @@ int reduce_grid(long long N, long long& per_block) {
 // BatchNorm with batch statistics (training, models/submodule_other.py:845-848 / models/submodule.py:89-116) + optional ReLU.
 // x [B,C,N] (N = D*H*W or H*W), weight / bias [C] (may be NULL) -> y, and mean / invstd / var_unbiased [C] for the backward and
 // the running statistics; work: 2*C doubles of scratch.
-extern "C" int ss_batchnorm_train_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean, float* invstd,
-                                      float* var_unbiased, double* work, int B, int C, long long N, float eps, int relu,
-                                      ss_stream_t stream) {
+static int batchnorm_train_fwd_impl(const float* x, const float* residual, const float* weight, const float* bias, float* y, float* mean,
+                                    float* invstd, float* var_unbiased, double* work, int B, int C, long long N, float eps, int relu,
+                                    ss_stream_t stream) {
     SS_REQUIRE(x && y && mean && invstd && var_unbiased && work && B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535);
     hipStream_t st = ss::as_stream(stream);
     if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
@@ -247,15 +269,30 @@ extern "C" int ss_batchnorm_train_fwd(const float* x, const float* weight, const
     const long long total = (long long)B * C * N;
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, mean, invstd, weight, bias, y, C, N, total, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, residual, mean, invstd, weight, bias, y, C, N, total, relu);
     return ss::check_launch();
+}
+
+extern "C" int ss_batchnorm_train_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean, float* invstd,
+                                      float* var_unbiased, double* work, int B, int C, long long N, float eps, int relu,
+                                      ss_stream_t stream) {
+    return batchnorm_train_fwd_impl(x, nullptr, weight, bias, y, mean, invstd, var_unbiased, work, B, C, N, eps, relu, stream);
+}
+
+// ... with a residual joining BEHIND the normalisation and before the ReLU: y = relu(bn(x) + residual) in the same pass
+// (hourglass.forward, models/SemStereo.py:141-142: F.relu(self.conv5(conv4) + self.redir2(conv2)) in train())
+extern "C" int ss_batchnorm_train_res_fwd(const float* x, const float* residual, const float* weight, const float* bias, float* y,
+                                          float* mean, float* invstd, float* var_unbiased, double* work, int B, int C, long long N,
+                                          float eps, int relu, ss_stream_t stream) {
+    SS_REQUIRE(residual != nullptr);
+    return batchnorm_train_fwd_impl(x, residual, weight, bias, y, mean, invstd, var_unbiased, work, B, C, N, eps, relu, stream);
 }
 
 // Its backward: grad_y, x, y (needed only with relu), mean, invstd, weight -> grad_x [B,C,N], grad_weight / grad_bias [C] as
 // doubles in work[2c + 1] / work[2c] (sum g' * xhat, sum g').
-extern "C" int ss_batchnorm_train_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
-                                      const float* weight, float* grad_x, double* work, int B, int C, long long N, int relu,
-                                      ss_stream_t stream) {
+static int batchnorm_train_bwd_impl(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                                    const float* weight, float* grad_x, float* grad_res, double* work, int B, int C, long long N, int relu,
+                                    ss_stream_t stream) {
     SS_REQUIRE(grad_y && x && mean && invstd && grad_x && work && B > 0 && C > 0 && N > 0 && (y || !relu) && C <= 65535 && B <= 65535);
     hipStream_t st = ss::as_stream(stream);
     if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
@@ -265,9 +302,23 @@ extern "C" int ss_batchnorm_train_bwd(const float* grad_y, const float* x, const
     const long long total = (long long)B * C * N;
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x, C,
-                       N, total, (double)B * (double)N, relu);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x,
+                       grad_res, C, N, total, (double)B * (double)N, relu);
     return ss::check_launch();
+}
+
+extern "C" int ss_batchnorm_train_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                                      const float* weight, float* grad_x, double* work, int B, int C, long long N, int relu,
+                                      ss_stream_t stream) {
+    return batchnorm_train_bwd_impl(grad_y, x, y, mean, invstd, weight, grad_x, nullptr, work, B, C, N, relu, stream);
+}
+
+// ... of the residual form: also grad_residual [B,C,N] = grad_y behind the ReLU mask
+extern "C" int ss_batchnorm_train_res_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                                          const float* weight, float* grad_x, float* grad_residual, double* work, int B, int C,
+                                          long long N, int relu, ss_stream_t stream) {
+    SS_REQUIRE(grad_residual != nullptr);
+    return batchnorm_train_bwd_impl(grad_y, x, y, mean, invstd, weight, grad_x, grad_residual, work, B, C, N, relu, stream);
 }
 
 // sums[c] (double) = sum over batch and positions of a[b, c, :]  (bias gradients of the 1x1x1 projections)
@@ -305,29 +356,46 @@ extern "C" int ss_channel_gate_bwd_logits(const float* grad_out, const float* cv
     return ss::check_launch();
 }
 
-// Backward of ss_window_attention_core_fwd for volumes whose H, W are multiples of the window (no pad tokens):
-// qkv [B,3C,D,H,W], grad_y [B,C,D,H,W] -> grad_qkv [B,3C,D,H,W].  Windows of 64 or 96 tokens, 8 channels per head.
-extern "C" int ss_window_attention_core_bwd(const float* qkv, const float* grad_y, float* grad_qkv, int B, int C, int D, int H, int W,
-                                            int heads, int bd, int bh, int bw, ss_stream_t stream) {
+// Backward of ss_window_attention_core_fwd: qkv [B,3C,D,H,W], grad_y [B,C,D,H,W] -> grad_qkv [B,3C,D,H,W].  Windows of 64 or 96
+// tokens, 8 channels per head.  H, W not multiples of the window: `bqkv` [3C] (the qkv Linear's bias = the pad tokens' q / k / v)
+// and `grad_bias` [3C] (zeroed here; what reaches the pad tokens) are required.
+static int window_attention_core_bwd_impl(const float* qkv, const float* bqkv, const float* grad_y, float* grad_qkv, float* grad_bias, int B,
+                                          int C, int D, int H, int W, int heads, int bd, int bh, int bw, ss_stream_t stream) {
     SS_REQUIRE(qkv && grad_y && grad_qkv && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && heads > 0 && bd > 0 && bh > 0 && bw > 0);
-    if (C != heads * 8 || D % bd || H % bh || W % bw || B > 65535 || heads > 65535) return SS_ERR_UNSUPPORTED;
+    const bool padded = (H % bh) != 0 || (W % bw) != 0;
+    SS_REQUIRE(!padded || (bqkv != nullptr && grad_bias != nullptr));
+    if (C != heads * 8 || D % bd || B > 65535 || heads > 65535) return SS_ERR_UNSUPPORTED;
     const int T = bd * bh * bw;
-    const long long windows = (long long)(D / bd) * (H / bh) * (W / bw);
+    const long long windows = (long long)(D / bd) * ss::ceil_div(H, bh) * ss::ceil_div(W, bw);
     if (windows > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     const float scale = 1.0f / sqrtf(8.0f);
     hipStream_t st = ss::as_stream(stream);
+    if (grad_bias != nullptr && hipMemsetAsync(grad_bias, 0, (size_t)3 * C * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    const int mask_on = ((H % bh) != 0 && (W % bw) != 0) ? 1 : 0;       // the reference masks only when BOTH were padded (see the kernel)
     const dim3 grid((unsigned)windows, heads, B);
     const size_t lds = (size_t)(4 * T * 9 + 2 * T * (T + 1)) * sizeof(float);
     if (T == 64) {
         auto kern = window_attention_core_bwd_kernel<64>;
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, qkv, grad_y, grad_qkv, C, D, H, W, heads, bd, bh, bw, scale);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, qkv, bqkv, grad_y, grad_qkv, grad_bias, C, D, H, W, heads, bd, bh, bw, scale, mask_on);
     } else if (T == 96) {
         auto kern = window_attention_core_bwd_kernel<96>;
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, qkv, grad_y, grad_qkv, C, D, H, W, heads, bd, bh, bw, scale);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, qkv, bqkv, grad_y, grad_qkv, grad_bias, C, D, H, W, heads, bd, bh, bw, scale, mask_on);
     } else {
         return SS_ERR_UNSUPPORTED;
     }
     return ss::check_launch();
+}
+
+extern "C" int ss_window_attention_core_bwd(const float* qkv, const float* grad_y, float* grad_qkv, int B, int C, int D, int H, int W,
+                                            int heads, int bd, int bh, int bw, ss_stream_t stream) {
+    if (H > 0 && W > 0 && bh > 0 && bw > 0 && (H % bh || W % bw)) return SS_ERR_UNSUPPORTED;      // pad tokens: the _pad form
+    return window_attention_core_bwd_impl(qkv, nullptr, grad_y, grad_qkv, nullptr, B, C, D, H, W, heads, bd, bh, bw, stream);
+}
+
+extern "C" int ss_window_attention_core_pad_bwd(const float* qkv, const float* bqkv, const float* grad_y, float* grad_qkv, float* grad_bias,
+                                                int B, int C, int D, int H, int W, int heads, int bd, int bh, int bw, ss_stream_t stream) {
+    SS_REQUIRE(bqkv && grad_bias);
+    return window_attention_core_bwd_impl(qkv, bqkv, grad_y, grad_qkv, grad_bias, B, C, D, H, W, heads, bd, bh, bw, stream);
 }

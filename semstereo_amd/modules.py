@@ -342,8 +342,14 @@ class hourglass(nn.Module):
             conv2 = cbr(self.conv2, conv1)
             conv3 = cbr(self.conv3, conv2)
             conv4 = self.attention_block(cbr(self.conv4, conv3))
-            conv5 = F.relu(T.batchnorm_train(self.conv5[1], deconv3d_train(self.conv5[0], conv4)) + self.redir2(conv2))
-            return F.relu(T.batchnorm_train(self.conv6[1], deconv3d_train(self.conv6[0], conv5)) + self.redir1(x))
+            # F.relu(self.conv5(conv4) + self.redir2(conv2)), models/SemStereo.py:141-142: the add and the ReLU inside the
+            # BatchNorm apply of the transposed conv (forward and backward), not two PyTorch element-wise kernels
+            def up(seq, t, skip):
+                if seq[1].training:
+                    return T.batchnorm_train(seq[1], deconv3d_train(seq[0], t), relu=True, residual=skip)
+                return F.relu(seq[1](deconv3d_train(seq[0], t)) + skip)
+            conv5 = up(self.conv5, conv4, self.redir2(conv2))
+            return up(self.conv6, conv5, self.redir1(x))
         PATH_COUNTS["hip"] += 1
         c1 = run_convbn(self, "c1", self.conv1[0][0], self.conv1[0][1], x, relu=True)
         c2 = run_convbn(self, "c2", self.conv2[0][0], self.conv2[0][1], c1, relu=True)

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from . import deferred as dfr
 from . import modules as M
 from . import ops, ops_unsigned
+from . import train as T
 
 TOPK = 24                                   # models/SemStereo.py:301
 
@@ -114,6 +115,10 @@ class HotSegment(nn.Module):
             corr = lib.build_gwc_volume_norm(fl8, fr8, m8, groups)                             # :273
             cost_att = self.corr_feature_att_8(self.patch(corr), fl8)
         cost_att = self.classif_att_(self.hourglass_att(cost_att))                             # :277-278
+        if (not fast and not M._inference(self, fl4, fr4, fl8, fr8) and isinstance(cost_att, torch.Tensor)
+                and T.attention_tail_applies(cost_att, r4, H4, W4)):
+            # training / autograd (main_us3d.py:186-222): :279-310 as the three fused launches with their backward kernels (train.py)
+            return T.attention_tail(cost_att, fl4, fr4, self.gamma, self.beta, r4, H4, W4, TOPK)
         if fast and ops.upsample_softmax_regression_applies(cost_att, m4, H4, W4, r4):
             att_weights, pred0, var = ops.upsample_softmax_regression(cost_att, m4, H4, W4, _range=r4)    # :279-285 fused
         elif fast:

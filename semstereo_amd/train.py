@@ -42,8 +42,12 @@ def _count(kind):
 # ---- BatchNorm with batch statistics (+ ReLU) ---------------------------------------------------------------------------------
 
 class _BatchNormTrain(torch.autograd.Function):
+    """y = bn(x) [+ residual] [-> ReLU] with batch statistics; `residual` (same shape as x, or None) joins behind the
+    normalisation and before the ReLU (hourglass.forward's `F.relu(self.conv5(conv4) + self.redir2(conv2))`,
+    models/SemStereo.py:141-142) in the same pass."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu):
+    def forward(ctx, x, weight, bias, eps, relu, residual):
         x = _c(x)
         B, C = x.shape[0], x.shape[1]
         N = x[0, 0].numel()
@@ -52,10 +56,16 @@ class _BatchNormTrain(torch.autograd.Function):
         invstd, var_u = torch.empty_like(mean), torch.empty_like(mean)
         work = torch.empty(2 * C, dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
-            call("ss_batchnorm_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd), ptr(var_u), ptr(work),
-                 B, C, N, float(eps), int(relu))
+            if residual is None:
+                call("ss_batchnorm_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd), ptr(var_u), ptr(work),
+                     B, C, N, float(eps), int(relu))
+            else:
+                residual = _c(residual)
+                assert residual.shape == x.shape
+                call("ss_batchnorm_train_res_fwd", ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd), ptr(var_u),
+                     ptr(work), B, C, N, float(eps), int(relu))
         ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
-        ctx.relu, ctx.has_bias = bool(relu), bias is not None
+        ctx.relu, ctx.has_bias, ctx.has_res = bool(relu), bias is not None, residual is not None
         ctx.mark_non_differentiable(mean, var_u)
         return y, mean, var_u
 
@@ -66,24 +76,32 @@ class _BatchNormTrain(torch.autograd.Function):
         B, C = x.shape[0], x.shape[1]
         N = x[0, 0].numel()
         gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if ctx.has_res else None
         work = torch.empty(2 * C, dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
-            call("ss_batchnorm_train_bwd", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(work), B, C, N,
-                 int(ctx.relu))
+            if gres is None:
+                call("ss_batchnorm_train_bwd", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(work), B, C, N,
+                     int(ctx.relu))
+            else:
+                call("ss_batchnorm_train_res_bwd", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(gres), ptr(work),
+                     B, C, N, int(ctx.relu))
         sums = work.reshape(C, 2)
         gw = sums[:, 1].float() if weight is not None else None
         gb = sums[:, 0].float() if ctx.has_bias else None
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, gres
 
 
-def batchnorm_train(bn, x, relu=False):
-    """bn(x) [-> ReLU] for a BatchNorm2d / 3d in train(): batch statistics, running statistics updated as F.batch_norm does."""
+def batchnorm_train(bn, x, relu=False, residual=None):
+    """bn(x) [+ residual] [-> ReLU] for a BatchNorm2d / 3d in train(): batch statistics, running statistics updated as
+    F.batch_norm does."""
     if not (_on(x) and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training and x.shape[1] <= 65535):
         _count("torch")
         y = bn(x)
+        if residual is not None:
+            y = y + residual
         return F.relu(y) if relu else y
     _count("hip_train")
-    y, mean, var_u = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu)
+    y, mean, var_u = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, residual)
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             if bn.num_batches_tracked is not None:
@@ -270,40 +288,146 @@ def channel_gate(att_logits, cv):
 # ---- windowed attention core --------------------------------------------------------------------------------------------------
 
 class _WindowAttentionCore(torch.autograd.Function):
+    """y = softmax(q k^T / sqrt(8) [+ pad mask]) v per (window, head).  `bqkv`: the qkv Linear's bias = the q / k / v of the pad
+    tokens of volumes whose H, W are not window multiples (the reference pads the volume before the Linear); its gradient output
+    is what reaches those tokens."""
+
     @staticmethod
     def forward(ctx, qkv, bqkv, heads, block):
         qkv = _c(qkv)
         B, C3, D, H, W = qkv.shape
         C = C3 // 3
         y = torch.empty((B, C, D, H, W), dtype=qkv.dtype, device=qkv.device)
+        bq = _c(bqkv.detach().float())
         with torch.cuda.device(qkv.device):
-            call("ss_window_attention_core_fwd", ptr(qkv), ptr(_c(bqkv.detach().float())), ptr(y), B, C, D, H, W, heads, block[0], block[1], block[2])
-        ctx.save_for_backward(qkv)
+            call("ss_window_attention_core_fwd", ptr(qkv), ptr(bq), ptr(y), B, C, D, H, W, heads, block[0], block[1], block[2])
+        ctx.save_for_backward(qkv, bq)
         ctx.cfg = (heads, tuple(block))
         return y
 
     @staticmethod
     def backward(ctx, g):
-        (qkv,) = ctx.saved_tensors
+        qkv, bq = ctx.saved_tensors
         heads, block = ctx.cfg
         g = _c(g)
         B, C3, D, H, W = qkv.shape
         gq = torch.empty_like(qkv)
+        gbias = torch.empty(C3, dtype=torch.float32, device=qkv.device)
         with torch.cuda.device(qkv.device):
-            call("ss_window_attention_core_bwd", ptr(qkv), ptr(g), ptr(gq), B, C3 // 3, D, H, W, heads, block[0], block[1], block[2])
-        return gq, None, None, None
+            call("ss_window_attention_core_pad_bwd", ptr(qkv), ptr(bq), ptr(g), ptr(gq), ptr(gbias), B, C3 // 3, D, H, W, heads,
+                 block[0], block[1], block[2])
+        return gq, (gbias if ctx.needs_input_grad[1] else None), None, None
 
 
 def window_attention_applies(x, heads, block):
     B, C, D, H, W = x.shape
-    return (_on(x) and C == heads * 8 and D % block[0] == 0 and H % block[1] == 0 and W % block[2] == 0
-            and block[0] * block[1] * block[2] in (64, 96))
+    return _on(x) and C == heads * 8 and D % block[0] == 0 and block[0] * block[1] * block[2] in (64, 96)
 
 
 def window_attention(x, qkv_linear, final_conv, heads, block):
-    """attention_block.forward (models/submodule_other.py:790-837) for volumes whose H, W are multiples of the window: the
-    qkv projection and final1x1 as 1x1x1 convolutions with bias, the attention core per (window, head)."""
+    """attention_block.forward (models/submodule_other.py:790-837): the qkv projection and final1x1 as 1x1x1 convolutions with bias
+    over the REAL positions, the attention core per (window, head) -- pad tokens of volumes whose H, W are not window multiples
+    carry the Linear's bias as their q / k / v (r04: forward and backward)."""
     _count("hip_train")
     qkv = conv_k1(x, qkv_linear.weight, qkv_linear.bias)
     y = _WindowAttentionCore.apply(qkv, qkv_linear.bias, heads, tuple(block))
     return conv_k1(y, final_conv.weight, final_conv.bias)
+
+
+# ---- the attention tail (models/SemStereo.py:279-310) under autograd: the fused forward kernels + their backward kernels --------------
+
+class _UpsampleSoftmaxRegression(torch.autograd.Function):
+    """:279-285: trilinear 2x up-sampling of the classifier's output -> softmax over D -> expectation and variance."""
+
+    @staticmethod
+    def forward(ctx, coarse, H, W, rng):
+        from . import ops
+        up, disp, var = ops.upsample_softmax_regression(coarse, rng[1] // 2 if rng[0] else rng[1], H, W, _range=rng)
+        ctx.save_for_backward(up)
+        ctx.rng = rng
+        return up, disp, var
+
+    @staticmethod
+    def backward(ctx, g_up, g_disp, g_var):
+        (up,) = ctx.saved_tensors
+        B, _, D, H, W = up.shape
+        g_up = None if g_up is None else _c(g_up)
+        g_disp = None if g_disp is None else _c(g_disp)
+        g_var = None if g_var is None else _c(g_var)
+        gc = torch.empty((B, 1, D // 2, H // 2, W // 2), dtype=up.dtype, device=up.device)
+        work = torch.empty_like(up)
+        with torch.cuda.device(up.device):
+            call("ss_upsample_softmax_regression_bwd", ptr(up), ptr(g_up), ptr(g_disp), ptr(g_var), ptr(gc), ptr(work), B, ctx.rng[0], D, H, W)
+        return gc, None, None, None
+
+
+class _SampleStrength(torch.autograd.Function):
+    """:286-293: the 5-candidate matching-strength probe."""
+
+    @staticmethod
+    def forward(ctx, left, right, pred0, var, gamma, beta):
+        from . import ops
+        left, right, pred0, var = _c(left), _c(right), _c(pred0), _c(var)
+        ctx.save_for_backward(left, right, pred0, var, gamma, beta)
+        return ops.sample_strength(left, right, pred0, var, gamma, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        left, right, pred0, var, gamma, beta = ctx.saved_tensors
+        g = _c(g)
+        B, C, H, W = left.shape
+        need = ctx.needs_input_grad
+        gl = torch.empty_like(left) if need[0] else None
+        gr = torch.empty_like(right) if need[1] else None
+        gp = torch.empty_like(pred0) if need[2] else None
+        gv = torch.empty_like(var) if need[3] else None
+        ggb = torch.empty(2, dtype=torch.float32, device=left.device) if (need[4] or need[5]) else None
+        gm, bt = _c(gamma.detach().reshape(1)), _c(beta.detach().reshape(1))
+        with torch.cuda.device(left.device):
+            call("ss_sample_strength_bwd", ptr(left), ptr(right), ptr(pred0), ptr(var), ptr(gm), ptr(bt), ptr(g), ptr(gl), ptr(gr), ptr(gp), ptr(gv),
+                 ptr(ggb), B, C, H, W)
+        return (gl, gr, gp, gv, ggb[0:1].reshape(gamma.shape) if need[4] else None, ggb[1:2].reshape(beta.shape) if need[5] else None)
+
+
+class _TopkCandidates(torch.autograd.Function):
+    """:295-310: strength-weighted propagation of the logits, softmax, the 24 most probable disparities, soft-argmax over them."""
+
+    @staticmethod
+    def forward(ctx, logits, strength, k, rng):
+        from . import ops
+        logits, strength = _c(logits), _c(strength)
+        att_topk, samples, pred_att = ops.topk_candidates(logits, strength, rng[1] // 2 if rng[0] else rng[1], k, _range=rng)
+        ctx.save_for_backward(logits, strength, samples)
+        ctx.cfg = (k, rng)
+        ctx.mark_non_differentiable(samples)
+        return att_topk, samples, pred_att
+
+    @staticmethod
+    def backward(ctx, g_att, _g_samples, g_pred):
+        logits, strength, samples = ctx.saved_tensors
+        k, rng = ctx.cfg
+        B, _, D, H, W = logits.shape
+        g_att = None if g_att is None else _c(g_att)
+        g_pred = None if g_pred is None else _c(g_pred)
+        gl = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(strength) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(logits.device):
+            call("ss_topk_candidates_bwd", ptr(logits), ptr(strength), ptr(samples), ptr(g_att), ptr(g_pred), ptr(gl), ptr(gs), B, rng[0], D, H, W, k)
+        return gl, gs, None, None
+
+
+def attention_tail_applies(cost_att, rng, H, W):
+    """The fused tail under autograd: same shape conditions as the inference kernels (exact 2x up-sampling, D <= 128)."""
+    from . import ops
+    return (_on(cost_att) and ops.upsample_softmax_regression_applies(cost_att, rng[1] // 2 if rng[0] else rng[1], H, W, _range=rng)
+            and rng[1] <= ops.TOPK_CANDIDATES_MAX_D)
+
+
+def attention_tail(cost_att, left, right, gamma, beta, rng, H, W, k):
+    """models/SemStereo.py:279-310 with autograd on: three HIP forward launches, three HIP backward launches.
+    -> (att_topk [B,1,k,H,W], samples [B,k,H,W], pred_att [B,H,W], pred0 [B,H,W])."""
+    _count("hip_train")
+    att_weights, pred0, var = _UpsampleSoftmaxRegression.apply(cost_att, H, W, tuple(rng))
+    strength = _SampleStrength.apply(left, right, pred0, var, gamma, beta)
+    att_topk, samples, pred_att = _TopkCandidates.apply(att_weights, strength, k, tuple(rng))
+    return att_topk, samples, pred_att, pred0

@@ -18,7 +18,12 @@ import semstereo_amd as sa
 from golden import cases
 from oracle import hot_segment as oseg, stack as ostack
 import test_parity_gpu as T
-name = "s128"
+name = sys.argv[1] if len(sys.argv) > 1 else "s128"          # [fixture] [notail] [nopadatt]: switch the r04 training kernels off one by one
+if "notail" in sys.argv:
+    sa.train.attention_tail_applies = lambda *a, **k: False
+if "nopadatt" in sys.argv:
+    _strict = sa.train.window_attention_applies
+    sa.train.window_attention_applies = lambda x, heads, block: _strict(x, heads, block) and x.shape[3] % block[1] == 0 and x.shape[4] % block[2] == 0
 fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
 seg, P = T._segment(sa, maxdisp)
 seg.train()
@@ -28,11 +33,13 @@ r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
 grads = {k: v.grad.detach().cpu() for k, v in seg.named_parameters() if v.grad is not None}
 P64 = {k: v.double().clone().requires_grad_(v.is_floating_point() and not k.endswith(("running_mean", "running_var"))) for k, v in P.items()}
 with ostack.training_mode():
-    att, smp, pred_att = oseg.attention_branch(P64, fl8.double(), fr8.double(), fl4.double(), fr4.double(), maxdisp)
+    att, smp, pred_att = oseg.attention_branch(P64, fl8.double(), fr8.double(), fl4.double(), fr4.double(), maxdisp,
+                                               force_samples=r["samples"].detach().cpu().double())      # like for like: the HIP pass's picks
     pred = oseg.matching_branch(P64, fl4.double(), fr4.double(), att, smp)
 (pred.mean() + pred_att.mean()).backward()
 print("engine", sa.modules.CONV_ENGINE, "pred diff max", float((r["pred"].detach().cpu().double() - pred.detach()).abs().max()), "pred_att diff", float((r["pred_att"].detach().cpu().double() - pred_att.detach()).abs().max()))
 errs = {k: float((g.double() - P64[k].grad).abs().max()) / (float(P64[k].grad.abs().max()) + 1e-12) for k, g in grads.items() if k not in ("gamma", "beta")}
+print("median", sorted(errs.values())[len(errs) // 2])
 for k in sorted(errs, key=errs.get, reverse=True)[:14]: print("%-44s %.2e" % (k, errs[k]))
 print("...")
 for k in sorted(errs, key=errs.get)[:6]: print("%-44s %.2e" % (k, errs[k]))
