@@ -352,11 +352,21 @@ class hourglass(nn.Module):
             return up(self.conv6, conv5, self.redir1(x))
         PATH_COUNTS["hip"] += 1
         c1 = run_convbn(self, "c1", self.conv1[0][0], self.conv1[0][1], x, relu=True)
+        hook = self.__dict__.get("_mid_hook")            # (segment.run_segment: where the second stream's work is released)
+
+        def at(point):
+            if hook is not None and hook[0] == point:
+                hook[1]()
         c2 = run_convbn(self, "c2", self.conv2[0][0], self.conv2[0][1], c1, relu=True)
+        at("c2")
         c3 = run_convbn(self, "c3", self.conv3[0][0], self.conv3[0][1], c2, relu=True)
+        at("c3")
         c4 = run_convbn(self, "c4", self.conv4[0][0], self.conv4[0][1], c3, relu=True)
+        at("c4")
         c4 = self.attention_block(c4)
+        at("att")
         c5 = self._up("u5", self.conv5, self.redir2, c4, c2)
+        at("u5")
         return self._up("u6", self.conv6, self.redir1, c5, x)
 
 

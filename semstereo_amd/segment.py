@@ -50,6 +50,12 @@ class HotSegment(nn.Module):
     FUSED = os.environ.get("SS_FUSED", "1") != "0"
     STEM_BY_HALVES = os.environ.get("SS_STEM_HALVES", "1") != "0"      # concat_stem's broadcast half by linearity
     GWC_PATCH_FUSED = os.environ.get("SS_GWC_PATCH_FUSED", "1") != "0"  # gwc volume -> patch -> gate in one kernel
+    #: where the second stream's work (the matching branch's 2-D convolutions and gate) is released: "start" = with the attention
+    #: branch (r01-r03), or after a layer of hourglass_att ("c2", "c3", "c4", "att", "u5").  r04: released at the start it ran beside
+    #: the volume kernel and the first two convs -- kernels that fill the chip by themselves (the volume kernel took 98 us beside it,
+    #: 36 alone); released after conv4 it runs beside the coarsest layers (128-256 workgroups each).  Interleaved A/B, three rounds
+    #: (tools/ab_env.sh SS_PRELUDE_AT): start 474.1, c3 480.8, c4 482.0, att 481.0, u5 480.5 pairs/s.
+    PRELUDE_AT = os.environ.get("SS_PRELUDE_AT", "c4")
 
     def __init__(self, maxdisp, c8=256, c4=128, unsigned=False):
         """unsigned=False: models/SemStereo.py (disparities [-maxdisp, maxdisp), op set models/submodule.py);
@@ -228,10 +234,24 @@ def run_segment(owner, fl4, fr4, fl8, fr8, matching=True):
         # 256 CUs.  The matching branch's 2-D convolutions are independent of it, so they run on a
         # second HIP stream underneath and join before the sparse concat volume is built.
         cur, side = torch.cuda.current_stream(fl4.device), _side_stream(fl4.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            prelude = HotSegment.matching_prelude(owner, fl4, fr4)
+        box = []
+
+        def launch_prelude():
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                box.append(HotSegment.matching_prelude(owner, fl4, fr4))
+        where = getattr(owner, "PRELUDE_AT", HotSegment.PRELUDE_AT)
+        hg = owner.hourglass_att
+        if where in ("c2", "c3", "c4", "att", "u5") and isinstance(hg, M.hourglass):
+            hg.__dict__["_mid_hook"] = (where, launch_prelude)
+        else:
+            launch_prelude()
     att_topk, samples, pred_att, pred0 = HotSegment.attention_branch(owner, fl4, fr4, fl8, fr8)
+    if matching and fused and overlap and fl4.is_cuda and M._inference(owner, fl4, fr4, fl8, fr8):
+        owner.hourglass_att.__dict__.pop("_mid_hook", None)
+        if not box:
+            launch_prelude()
+        prelude = box[0]
     if prelude is not None:
         cur.wait_stream(side)
         for t in prelude:

@@ -797,6 +797,8 @@ _NON_DEFAULT = {
     "SS_OVERLAP=0": ("segment.HotSegment", "OVERLAP", False),
     "SS_OVERLAP=1": ("segment.HotSegment", "OVERLAP", True),
     "SS_FUSED=0": ("segment.HotSegment", "FUSED", False),
+    "SS_PRELUDE_AT=start": ("segment.HotSegment", "PRELUDE_AT", "start"),
+    "SS_PRELUDE_AT=u5": ("segment.HotSegment", "PRELUDE_AT", "u5"),
     "SS_GWC_PATCH_FUSED=0": ("segment.HotSegment", "GWC_PATCH_FUSED", False),
     "SS_STEM_HALVES=0": ("segment.HotSegment", "STEM_BY_HALVES", False),
     "SS_STEM_LEFT_FUSED=0": ("engine", "STEM_LEFT_FUSED", False),
