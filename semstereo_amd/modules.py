@@ -355,8 +355,8 @@ class hourglass(nn.Module):
         hook = self.__dict__.get("_mid_hook")            # (segment.run_segment: where the second stream's work is released)
 
         def at(point):
-            if hook is not None and hook[0] == point:
-                hook[1]()
+            if hook is not None:
+                hook[1](point)
         c2 = run_convbn(self, "c2", self.conv2[0][0], self.conv2[0][1], c1, relu=True)
         at("c2")
         c3 = run_convbn(self, "c3", self.conv3[0][0], self.conv3[0][1], c2, relu=True)

@@ -39,6 +39,24 @@ def _side_stream(device):
 propagation, propagation_prob = M.propagation, M.propagation_prob
 
 
+class _Pending:
+    """A tensor produced on the second stream: `value()` makes the consuming stream wait for the producing launch (once)."""
+
+    def __init__(self, tensor, event, consumer):
+        self.tensor, self.event, self.consumer, self.joined = tensor, event, consumer, False
+
+    def value(self):
+        if not self.joined:
+            self.consumer.wait_event(self.event)
+            self.tensor.record_stream(self.consumer)
+            self.joined = True
+        return self.tensor
+
+
+def _ready(x):
+    return x.value() if isinstance(x, _Pending) else x
+
+
 class HotSegment(nn.Module):
     #: two-stream overlap of the branches (inference): "auto" = at batch <= 2 only.  Measured (profiles/r03_a_bench_b*_ov*.json):
     #: batch 1: 466.6 vs 462.4 pairs/s with / without; batch 4: 529.3 vs 531.1; batch 8: 538.7 vs 538.5 -- from batch 4 on the
@@ -120,7 +138,10 @@ class HotSegment(nn.Module):
         else:
             corr = lib.build_gwc_volume_norm(fl8, fr8, m8, groups)                             # :273
             cost_att = self.corr_feature_att_8(self.patch(corr), fl8)
+        rel = self.__dict__.get("_release") if fast else None
         cost_att = self.classif_att_(self.hourglass_att(cost_att))                             # :277-278
+        if rel is not None:
+            rel("cls")
         if (not fast and not M._inference(self, fl4, fr4, fl8, fr8) and isinstance(cost_att, torch.Tensor)
                 and T.attention_tail_applies(cost_att, r4, H4, W4)):
             # training / autograd (main_us3d.py:186-222): :279-310 as the three fused launches with their backward kernels (train.py)
@@ -136,7 +157,11 @@ class HotSegment(nn.Module):
             pred0 = lib.disparity_regression(prob0, m4)
             var = lib.disparity_variance(prob0, m4, pred0.unsqueeze(1))
         if fast and r4[1] <= ops.TOPK_CANDIDATES_MAX_D:         # beyond (maxdisp >= 320): the line-by-line form below
+            if rel is not None:
+                rel("up")
             strength = ops.sample_strength(fl4, fr4, pred0, var, self.gamma, self.beta)        # :286-293 fused
+            if rel is not None:
+                rel("st")
             att_topk, samples, pred_att = ops.topk_candidates(att_weights, strength, m4, TOPK, _range=r4)  # :295-310 fused
             return att_topk, samples, pred_att, pred0
         var = self.beta + self.gamma * var                                                     # :286
@@ -161,9 +186,10 @@ class HotSegment(nn.Module):
         return att_topk, samples, pred_att, pred0
 
     # ---- models/SemStereo.py:314-323 ---------------------------------------------------
-    def matching_prelude(self, fl4, fr4):
-        """:314-315 and the image half of :320 -- the 2-D convolutions that do not depend on the attention
-        branch (fast path only): concat features of both views and the concat_feature_att_4 gate (sigmoid applied)."""
+    def prelude_jobs(self, fl4, fr4):
+        """:314-315 and the image half of :320 -- the 2-D convolutions that do not depend on the attention branch (fast path only)
+        as three independent jobs: concat features of the left view, of the right view, and the concat_feature_att_4 gate
+        (sigmoid applied).  -> dict name -> callable."""
         cf = self.concat_feature
 
         def one_view(x):
@@ -177,7 +203,13 @@ class HotSegment(nn.Module):
                     return z if z is not None else cf[1](y)
             return cf(x)
         # one pair of launches per view: batching the two views needed a 34 MB torch.cat in front (28 us of ATen copy)
-        return one_view(fl4), one_view(fr4), self.concat_feature_att_4.logits(fl4, sigmoid=True)
+        return {"cl": lambda: one_view(fl4), "cr": lambda: one_view(fr4),
+                "gate": lambda: self.concat_feature_att_4.logits(fl4, sigmoid=True)}
+
+    def matching_prelude(self, fl4, fr4):
+        """The three jobs of prelude_jobs, in order, on the current stream -> (cl, cr, gate4)."""
+        jobs = HotSegment.prelude_jobs(self, fl4, fr4)
+        return jobs["cl"](), jobs["cr"](), jobs["gate"]()
 
     def matching_branch(self, fl4, fr4, att_topk, samples, prelude=None):
         fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, dfr.real(att_topk))
@@ -189,19 +221,20 @@ class HotSegment(nn.Module):
     def _matching_branch(self, fl4, fr4, att_topk, samples, prelude, fast):
         if fast:
             cl, cr, gate4 = prelude if prelude is not None else HotSegment.matching_prelude(self, fl4, fr4)
+            cl, cr = _ready(cl), _ready(cr)              # (gate4: joined only where the stem conv needs it)
             if M.CONV_ENGINE != "f32" and samples.shape[1] in (6, 24, 32) and HotSegment.STEM_BY_HALVES:
                 # the left half of the volume is the 2-D map `cl` broadcast over the candidates: neither built
                 # nor convolved (modules.stem_of_broadcast_and_volume); only the warped right half is a volume
                 partial = M.stem_broadcast_half(self.concat_stem, cl, att_topk)                # :319, broadcast half
                 if M.stem_presplit_applies(self.concat_stem, cr):
                     xs, xexp = ops.concat_volume_sampled_presplit(cr, samples, att_topk)       # :316 + :318, warped half, pre-split
-                    volume = M.stem_volume_half_presplit(self.concat_stem, xs, xexp, partial, gate4)   # :319 + :320
+                    volume = M.stem_volume_half_presplit(self.concat_stem, xs, xexp, partial, _ready(gate4))   # :319 + :320
                 else:
                     right = ops.concat_volume_sampled(None, cr, samples, att_topk)             # :316 + :318, warped half
-                    volume = M.stem_volume_half(self.concat_stem, right, partial, gate4)       # :319 + :320 (gate4: sigmoid done)
+                    volume = M.stem_volume_half(self.concat_stem, right, partial, _ready(gate4))       # :319 + :320 (gate4: sigmoid done)
             else:
                 volume = ops.concat_volume_sampled(cl, cr, samples, att_topk)                  # :316 + :318 fused
-                volume = self.concat_stem(volume, gate=gate4)                                  # :319 + :320 fused
+                volume = self.concat_stem(volume, gate=_ready(gate4))                          # :319 + :320 fused
         else:
             cl = self.concat_feature(fl4)                                                      # :314
             cr = self.concat_feature(fr4)                                                      # :315
@@ -229,33 +262,41 @@ def run_segment(owner, fl4, fr4, fl8, fr8, matching=True):
     if overlap == "auto":
         overlap = fl4.shape[0] <= 2
     prelude = None
+    released = {}
     if matching and fused and overlap and fl4.is_cuda and M._inference(owner, fl4, fr4, fl8, fr8):
         # The attention branch works at 1/8 scale: at small batch most of its kernels cannot fill
         # 256 CUs.  The matching branch's 2-D convolutions are independent of it, so they run on a
-        # second HIP stream underneath and join before the sparse concat volume is built.
+        # second HIP stream underneath; each result is joined where the matching branch first needs it.
         cur, side = torch.cuda.current_stream(fl4.device), _side_stream(fl4.device)
-        box = []
+        jobs = HotSegment.prelude_jobs(owner, fl4, fr4)
+        where = str(getattr(owner, "PRELUDE_AT", HotSegment.PRELUDE_AT)).split(",")
+        where = dict(zip(("cl", "cr", "gate"), where + [where[-1]] * (3 - len(where))))
 
-        def launch_prelude():
+        def release(point):
+            """Start, on the second stream, the jobs released at `point` (behind everything the main stream has issued so far)."""
+            todo = [k for k in ("cl", "cr", "gate") if k not in released and (point is None or where[k] == point)]
+            if not todo:
+                return
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                box.append(HotSegment.matching_prelude(owner, fl4, fr4))
-        where = getattr(owner, "PRELUDE_AT", HotSegment.PRELUDE_AT)
-        hg = owner.hourglass_att
-        if where in ("c2", "c3", "c4", "att", "u5") and isinstance(hg, M.hourglass):
-            hg.__dict__["_mid_hook"] = (where, launch_prelude)
-        else:
-            launch_prelude()
-    att_topk, samples, pred_att, pred0 = HotSegment.attention_branch(owner, fl4, fr4, fl8, fr8)
-    if matching and fused and overlap and fl4.is_cuda and M._inference(owner, fl4, fr4, fl8, fr8):
-        owner.hourglass_att.__dict__.pop("_mid_hook", None)
-        if not box:
-            launch_prelude()
-        prelude = box[0]
-    if prelude is not None:
-        cur.wait_stream(side)
-        for t in prelude:
-            t.record_stream(cur)
+                for k in todo:
+                    t = jobs[k]()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    released[k] = _Pending(t, ev, cur)
+        owner.__dict__["_release"] = release
+        if isinstance(owner.hourglass_att, M.hourglass):
+            owner.hourglass_att.__dict__["_mid_hook"] = ("*", release)
+        release("start")
+    try:
+        att_topk, samples, pred_att, pred0 = HotSegment.attention_branch(owner, fl4, fr4, fl8, fr8)
+    finally:
+        if "_release" in owner.__dict__:
+            owner.__dict__.pop("_release", None)
+            owner.hourglass_att.__dict__.pop("_mid_hook", None)
+    if released or (matching and fused and overlap and fl4.is_cuda and M._inference(owner, fl4, fr4, fl8, fr8)):
+        release(None)                                  # whatever has not been released yet (unknown point names included)
+        prelude = (released["cl"], released["cr"], released["gate"])
     pred = HotSegment.matching_branch(owner, fl4, fr4, att_topk, samples, prelude) if matching else None
     return dfr.real(dict(pred=pred, pred_att=pred_att, samples=samples, att_topk=att_topk, pred_att0=pred0))
 
