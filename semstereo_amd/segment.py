@@ -72,7 +72,10 @@ class HotSegment(nn.Module):
     #: branch (r01-r03), or after a layer of hourglass_att ("c2", "c3", "c4", "att", "u5").  r04: released at the start it ran beside
     #: the volume kernel and the first two convs -- kernels that fill the chip by themselves (the volume kernel took 98 us beside it,
     #: 36 alone); released after conv4 it runs beside the coarsest layers (128-256 workgroups each).  Interleaved A/B, three rounds
-    #: (tools/ab_env.sh SS_PRELUDE_AT): start 474.1, c3 480.8, c4 482.0, att 481.0, u5 480.5 pairs/s.
+    #: (tools/ab_env.sh SS_PRELUDE_AT): start 474.1, c3 480.8, c4 482.0, att 481.0, u5 480.5 pairs/s.  "a,b,c" gives the left-view
+    #: convs, the right-view convs and the gate their own points (also "cls" / "up" / "st": after classif_att_, the soft-argmax,
+    #: the probe); each result is joined where the matching branch first needs it.  Releasing the later two later did not pay
+    #: (another box): c4 464.8, "c4,c4,st" 464.8, "c4,cls,st" 461.7, "c4,cls,cls" 462.1, "c4,up,st" 449.5, "att,st,st" 448.3.
     PRELUDE_AT = os.environ.get("SS_PRELUDE_AT", "c4")
 
     def __init__(self, maxdisp, c8=256, c4=128, unsigned=False):
