@@ -173,3 +173,44 @@ def test_two_term_fp16_block_floating_scheme_in_numpy():
         kept = h64 * wh64 + h64 * wl64 + l64 * wh64
         exact = (h64 + l64) * (wh64 + wl64)
         assert (np.abs(exact - kept) <= np.abs(h64 * wh64) * 2.0 ** -21 + 2.0 ** -46).all()
+
+
+def test_unfused_helpers_stay_unfused_in_the_isa(tmp_path):
+    """Round 4's root cause, pinned without a GPU: hipcc's __fmul_rn / __fadd_rn are plain operators and HIP compiles with
+    -ffp-contract=fast, so a product written through them was still fused into the subtraction that consumed it (warp kernels:
+    `ix - floor(ix)` on the UNROUNDED product).  ss::mul_rn / add_rn / sub_rn (csrc/common.h) carry `#pragma clang fp contract(off)`:
+    cross-compile a probe for gfx950 and read the instructions -- the round trip must be v_mul, v_floor, v_sub (no fma on the
+    product), while the same expression written with plain operators IS contracted (the compiler's default has not changed under us
+    unnoticed: if this half ever fails the pragma may no longer be needed, not the other way round)."""
+    import os
+    import shutil
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "probe.hip"
+    src.write_text('''
+#include "%s/semstereo_amd/csrc/common.h"
+extern "C" __global__ void probe_rn(const float* t, float half_w, float* out) {
+    const float ix = ss::mul_rn(t[threadIdx.x] + 1.0f, half_w);
+    out[threadIdx.x] = ss::sub_rn(ix, floorf(ix));
+}
+extern "C" __global__ void probe_plain(const float* t, float half_w, float* out) {
+    const float ix = (t[threadIdx.x] + 1.0f) * half_w;
+    out[threadIdx.x] = ix - floorf(ix);
+}
+''' % ROOT)
+    asm = tmp_path / "probe.s"
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", str(src), "-o", str(asm)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = asm.read_text()
+
+    def body(name):
+        a = text.index(name + ":")
+        return text[a:text.index("s_endpgm", a)]
+    rn, plain = body("probe_rn"), body("probe_plain")
+    assert "v_mul_f32" in rn and "v_floor_f32" in rn and "v_sub_f32" in rn, rn
+    assert "v_fma_f32" not in rn and "v_fmac_f32" not in rn, rn
+    assert "v_fma_f32" in plain or "v_fmac_f32" in plain, plain
