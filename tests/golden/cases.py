@@ -44,6 +44,10 @@ WARP = {
     "int24":   (1, 4, 6, 16, 8, "int"),      # sorted distinct integers (the :316 call)
     "prop5":   (1, 8, 4, 12, 5, "frac"),     # 5 samples (the :291 call)
     "h1":      (1, 2, 1, 7, 3, "frac"),      # H == 1 (degenerate row normalisation)
+    # (r04; names that sort behind the others keep their seeds) the quarter-resolution widths of the bench shapes: the coordinate
+    # round trip leaves ix = integer + delta with |delta| ~ W * 1e-7 -- the REFERENCE's own warp at the widths where that matters
+    "w256_int":  (1, 4, 3, 256, 24, "int"),
+    "w512_frac": (1, 2, 2, 512, 5, "frac"),
 }
 # name -> (B, nd, H, W, k)
 TOPK = {
