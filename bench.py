@@ -173,9 +173,8 @@ def pmc_traffic(key):
     if not rec:
         return None, "no PMC record for this kernel in profiles/pmc_traffic.json", None
     mult = rec.get("fetch_size_multiplier")
-    return rec["total_bytes"], (f"transcribed from profiles/{rec['source']} (separate FETCH_SIZE / WRITE_SIZE passes, not measured in this run): "
-                                f"{rec['read_bytes'] / 1e6:.1f} MB read (FETCH_SIZE x {mult}: x2 for 16-byte-per-lane loads as the guide prescribes, "
-                                f"x1 for this repo's 4/8-byte-per-lane kernels, DESIGN.md section 5) + {rec['written_bytes'] / 1e6:.1f} MB written"), mult
+    return rec["total_bytes"], (f"transcribed from profiles/{rec['source']} (separate --pmc passes, not measured in this run): "
+                                f"{rec['read_bytes'] / 1e6:.0f} MB read (FETCH_SIZE x {mult}) + {rec['written_bytes'] / 1e6:.0f} MB written"), mult
 
 
 def launch_ranks(n, argv):
@@ -494,8 +493,9 @@ LINE_BUDGET = 4000          # characters of the JSON line (the driver keeps a 2 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a 0.4 s window at batch 1; r03's 20 steps were 41 ms, "
+                    "inside which boxes of the pool differ by more than most changes)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=1024)
@@ -503,6 +503,8 @@ def main():
     ap.add_argument("--engine", default=None, help="conv engine of the timed run: f32 | bf16x6 | bf16x3 | f16x3 "
                                                    "(default: semstereo_amd.modules.CONV_ENGINE)")
     ap.add_argument("--input-sets", type=int, default=3, help="distinct synthetic input sets rotated through the timed loop")
+    ap.add_argument("--streams", type=int, default=4, help="consecutive steps are issued round-robin on this many HIP streams "
+                    "(semstereo_amd.PairPipeline; 1: every step on the calling stream, which is ALSO timed and reported as single_stream)")
     ap.add_argument("--steady-seconds", type=float, default=1.0, help="length of the steady-state leg after the K timed steps (0: skip)")
     ap.add_argument("--parity-pairs", type=int, default=8, help="seeded pairs per conv engine in the parity leg (N = 1 only)")
     ap.add_argument("--no-other-engines", action="store_true", help="skip the extra timings / parity runs of the other engines")
@@ -588,11 +590,16 @@ def main():
         semstereo_amd.segment.ops.gwc_patch_gate = timer.wrap("gwc_fused", semstereo_amd.ops.gwc_patch_gate)
 
     counter = [0]
+    pipe = semstereo_amd.PairPipeline(seg, args.streams) if (args.streams > 1 and not dry) else None
+    use_pipe = [False]
 
     def step():
+        counter[0] += 1
+        fs = feat_sets[counter[0] % len(feat_sets)]
+        if use_pipe[0]:      # consecutive pairs round-robin on --streams HIP streams (semstereo_amd.PairPipeline); joined by the synchronize
+            return pipe(*fs)
         with torch.no_grad():
-            counter[0] += 1
-            return seg(*feat_sets[counter[0] % len(feat_sets)])
+            return seg(*fs)
     if dry:
         step = dry_step_factory(device)
     graphed = False
@@ -632,8 +639,16 @@ def main():
         pairs, _, _, tmax = sdist.reduce_metrics(B * nsteps, 0.0, 0, dt, device)
         return o, pairs, tmax, dt_own
 
+    # leg 1: every step on the calling stream (W + K steps), with the per-kernel HIP-event timers -> `single_stream`, `roofline`
     out, pairs, tmax, dt_own = timed_run(args.steps, args.warmup, kernel_timers=True)
     assert M.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside the timed region"
+    single = {"pairs_per_s": pairs / tmax, "ms_per_step": 1e3 * tmax / args.steps}
+    if pipe is not None and not graphed:
+        # leg 2, the headline: the same W + K steps issued round-robin on --streams streams (no per-kernel events: they would
+        # serialise the lanes)
+        use_pipe[0] = True
+        out, pairs, tmax, dt_own = timed_run(args.steps, args.warmup)
+        assert M.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside the timed region"
 
     # VERDICT r3 #5d: beside the driver's K steps (41 ms at K = 20), a >= 1 s steady-state rate of the same step
     steady = None
@@ -657,8 +672,10 @@ def main():
         dist_rec["per_rank_pairs_per_s"] = [float(own.item())]
         dist_rec["all_gather_payload_bytes"] = 0
 
-    by_engine, outs = {engine: pairs / tmax}, {engine: out}
+    by_engine, outs = {engine: single["pairs_per_s"]}, {engine: out}
     opbyop_rate, fired, unfused_rate = None, None, None
+    pipelined = use_pipe[0]
+    use_pipe[0] = False                 # the comparison legs below: every step on the calling stream, like `single_stream`
     if not dry and not args.no_other_engines:
         for e in ("f32", "bf16x6", "bf16x3", "f16x3"):
             if e != engine:
@@ -705,8 +722,7 @@ def main():
         "f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for every 3-D layer",
         "bf16x6": "fp32 operands as 3 bf16 terms, 6 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate",
         "bf16x3": "as bf16x6 with 3 cross products (reduced precision, opt-in)",
-        "f16x3": "fp32 operands as 2 block-floating fp16 terms, 3 cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate "
-                 "(error vs float64 at or below the exact-fp32 MFMA's); heads / 1x1x1 projections: 3 bf16 terms x 6",
+        "f16x3": "fp32 operands as 2 block-floating fp16 terms, 3 products on v_mfma_f32_32x32x16_f16, fp32 accumulate (fp32-accurate)",
     }[engine]
     # ---- the line: headline keys first, everything the judge reads inside LINE_BUDGET characters; forensics -> detail ----
     line = {
@@ -717,7 +733,11 @@ def main():
         "config": {"workload": f"BASELINE.json {cfg_name}: {H}x{W} tile, maxdisp={maxdisp}, batch={B} per GPU x {world} GPU(s), features "
                                "[B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity [B,1,H/4,W/4]",
                    "pairs_per_gpu_per_step": B, "input_sets_rotated": len(feat_sets) if not graphed else 1,
+                   "execution": (f"consecutive steps (batch {B} each) round-robin on {args.streams} HIP streams (semstereo_amd.PairPipeline); "
+                                 "results bit-identical to single_stream") if pipelined
+                                else "every step on one HIP stream",
                    "conv_engine": engine, "conv_engine_note": engine_note, "hip_graph": graphed},
+        "single_stream": single,
     }
     detail = {"argv": sys.argv[1:], "weights": "random init at unit gain (init_unit_gain), BatchNorm eval",
               "pairs_per_s_by_conv_engine": by_engine, "pairs_per_s_reference_forward_untouched": unfused_rate,
@@ -747,8 +767,7 @@ def main():
                                 "frac": ex / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
                                 "algorithmic_flop_per_launch": nterms * flops, "fp32_equivalent_tflops": eq,
                                 "frac_of_best_gemm_on_random_data": ex / 1247.0,
-                                "note": f"{nterms} {typ} products per fp32 product; peak = nominal dense 16-bit MFMA (MI355X_MICROARCH.md); "
-                                        "1247 TFLOP/s = its best measured bf16 GEMM on random data"}
+                                "note": f"{nterms} {typ} products per fp32 product; peak: nominal dense 16-bit MFMA; best GEMM measured there: 1247"}
             if (H, W, maxdisp, engine) == (1024, 1024, 128, "f16x3") and halves and not presplit:
                 tb, tnote, mult = pmc_traffic("stem_b1")
                 line["roofline"].update({"traffic": None if tb is None else tb * B, "fetch_size_multiplier": mult, "traffic_note": tnote})
@@ -810,8 +829,8 @@ def main():
         if args.parity_pairs > 0:
             engines = [engine] + ([e for e in ("f32", "bf16x6") if e != engine] if not args.no_other_engines else [])
             stats, rows, secs = seeded_pairs_parity(seg, M, engines, args.parity_pairs, H, W, maxdisp, device, nthreads)
-            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] over the pairs; HIP vs the fp32 CPU oracle of the same pair, picks "
-                                                                      "also vs its float64 attention branch", "by_conv_engine": stats}
+            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] over pairs; vs the fp32 CPU oracle, picks also vs float64",
+                                      "by_conv_engine": stats}
             detail["seeded_pairs_rows"] = rows
             detail["seeded_pairs_oracle_seconds"] = secs
         line["parity"] = parity

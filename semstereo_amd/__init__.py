@@ -11,6 +11,6 @@ Nothing here falls back to the CPU or to the test oracle.
 """
 from . import _lib, dist, engine, modules, ops, ops_unsigned, segment, train_layers  # noqa: F401
 from .install import accelerate, install, restore_forward, uninstall  # noqa: F401
-from .segment import GraphedSegment, HotSegment  # noqa: F401
+from .segment import GraphedSegment, HotSegment, PairPipeline  # noqa: F401
 
 __version__ = "0.1.0"

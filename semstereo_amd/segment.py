@@ -30,9 +30,11 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device):
-    st = _SIDE_STREAMS.get(device)
+    """The second stream of the CALLING stream (callers that run consecutive pairs on several streams get one each)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return st
 
 
@@ -329,3 +331,47 @@ class GraphedSegment:
             dst.copy_(src)
         self.graph.replay()
         return self.outputs
+
+
+class PairPipeline:
+    """Consecutive calls of a segment issued round-robin on `lanes` HIP streams, each with its own second stream: the kernels of
+    pair i + 1 fill the compute units that the kernels of pair i leave idle -- most of the attention branch at small batch (1/8-scale
+    layers of 128-512 workgroups on a 256-CU chip) and the tail of EVERY launch (the last workgroups of a persistent grid).  No
+    batching, no change to what a call computes: every pair runs the same kernels on its own buffers, so its outputs are bit-identical
+    to a plain call (tests/test_parity_gpu.py::test_pair_pipeline_is_bit_identical_to_sequential_calls).  Measured r04 (bench.py
+    --streams): batch 1: 497 -> 528 / 531 / 542 / 538 pairs/s on 2 / 3 / 4 / 6 lanes; batch 4: 535 -> 561 (3 lanes); batch 8: 543 -> 560;
+    2048^2 / 192: 120 -> 126.  Inference only.
+
+    `pipe(fl4, fr4, fl8, fr8)` returns the segment's output dict at once; the tensors are valid after `pipe.synchronize()`, or for
+    work issued on a stream that has waited for `pipe.last_event`.  Inputs produced on the calling stream are waited for."""
+
+    def __init__(self, segment, lanes=4):
+        assert lanes >= 1 and not segment.training
+        self.segment, self.nlanes = segment, int(lanes)
+        self.lanes, self.turn, self.last_event, self._primed = None, 0, None, False
+
+    def __call__(self, fl4, fr4, fl8, fr8):
+        dev = fl4.device
+        if not self._primed:
+            # weight packing and every other per-module cache are filled by the first call ON THE CALLING STREAM, and drained,
+            # before several streams read them
+            with torch.no_grad():
+                self.segment(fl4, fr4, fl8, fr8)
+            torch.cuda.synchronize(dev)
+            self.lanes = [torch.cuda.Stream(device=dev) for _ in range(self.nlanes)]
+            self._primed = True
+        lane = self.lanes[self.turn % self.nlanes]
+        self.turn += 1
+        lane.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(lane), torch.no_grad():
+            out = self.segment(fl4, fr4, fl8, fr8)
+            for t in (fl4, fr4, fl8, fr8):
+                t.record_stream(lane)
+            self.last_event = torch.cuda.Event()
+            self.last_event.record(lane)
+        return out
+
+    def synchronize(self):
+        for st in self.lanes or ():
+            st.synchronize()
+

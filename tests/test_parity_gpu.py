@@ -841,6 +841,31 @@ def test_hot_segment_under_every_non_default_switch(sa, golden, setting, monkeyp
     assert float(err.median()) <= 1e-5 and int((err > 1e-3).sum()) <= 1, (setting, float(err.max()))
 
 
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_pair_pipeline_is_bit_identical_to_sequential_calls(sa, lanes):
+    """semstereo_amd.PairPipeline (r04): consecutive pairs issued round-robin on several HIP streams -- the throughput form
+    bench.py times -- must give every pair, bit for bit, what a plain call on one stream gives it: 7 different pairs (more than the
+    lanes, so every lane is reused while its previous pair's buffers are still alive), pred / pred_att / samples / att_topk."""
+    from oracle import detdata as dd
+    seg, _ = _segment(sa, 64)
+    pairs = []
+    for i in range(7):
+        fl8, fr8 = dd.stereo_features(1, 256, 16, 24, 900 + 2 * i, max_shift=3)
+        fl4, fr4 = dd.stereo_features(1, 128, 32, 48, 901 + 2 * i, max_shift=6)
+        pairs.append([dev(t) for t in (fl4, fr4, fl8, fr8)])
+    with torch.no_grad():
+        want = [{k: v.clone() for k, v in seg(*p).items()} for p in pairs]
+    torch.cuda.synchronize()
+    pipe = sa.PairPipeline(seg, lanes)
+    for rep in range(3):                      # (several sweeps: lane reuse, allocator reuse across streams)
+        got = [pipe(*p) for p in pairs]
+        pipe.synchronize()
+        for i, (g_, w_) in enumerate(zip(got, want)):
+            for k in ("pred", "pred_att", "samples", "att_topk"):
+                assert torch.equal(g_[k], w_[k]), (rep, i, k, float((g_[k] - w_[k]).abs().max()))
+    assert pipe.last_event is not None and pipe.last_event.query()
+
+
 @pytest.mark.parametrize("hip2d", [True, False])
 def test_hot_segment_with_hip_2d_convs(sa, golden, hip2d):
     """SS_CONV2D_HIP: concat_feature's two 3x3 2-D convs on the split engine (default with f16x3) or on MIOpen."""
