@@ -363,8 +363,20 @@ class PairPipeline:
         lane = self.lanes[self.turn % self.nlanes]
         self.turn += 1
         lane.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(lane), torch.no_grad():
-            out = self.segment(fl4, fr4, fl8, fr8)
+        # the lanes ARE the concurrency: the within-pair second stream on top of them costs 0.8 % (4 lanes: 525.7 vs 521.4 pairs/s)
+        had, prev = "OVERLAP" in self.segment.__dict__, self.segment.__dict__.get("OVERLAP")
+        if self.nlanes > 1:
+            self.segment.OVERLAP = False
+        try:
+            with torch.cuda.stream(lane), torch.no_grad():
+                out = self.segment(fl4, fr4, fl8, fr8)
+        finally:
+            if self.nlanes > 1:
+                if had:
+                    self.segment.OVERLAP = prev
+                else:
+                    self.segment.__dict__.pop("OVERLAP", None)
+        with torch.cuda.stream(lane):
             for t in (fl4, fr4, fl8, fr8):
                 t.record_stream(lane)
             self.last_event = torch.cuda.Event()
