@@ -342,21 +342,23 @@ class PairPipeline:
     --streams): batch 1: 497 -> 528 / 531 / 542 / 538 pairs/s on 2 / 3 / 4 / 6 lanes; batch 4: 535 -> 561 (3 lanes); batch 8: 543 -> 560;
     2048^2 / 192: 120 -> 126.  Inference only.
 
-    `pipe(fl4, fr4, fl8, fr8)` returns the segment's output dict at once; the tensors are valid after `pipe.synchronize()`, or for
-    work issued on a stream that has waited for `pipe.last_event`.  Inputs produced on the calling stream are waited for."""
+    `pipe(*inputs)` returns the module's output at once; the tensors are valid after `pipe.synchronize()`, or for work issued on a
+    stream that has waited for `pipe.last_event`.  Inputs produced on the calling stream are waited for.  `segment` is any inference
+    module -- a HotSegment (`pipe(fl4, fr4, fl8, fr8)`) or a whole reference model after `install` + `accelerate`
+    (`pipe(imgL, imgR)`: its backbone's kernels ride the lanes too)."""
 
     def __init__(self, segment, lanes=4):
         assert lanes >= 1 and not segment.training
         self.segment, self.nlanes = segment, int(lanes)
         self.lanes, self.turn, self.last_event, self._primed = None, 0, None, False
 
-    def __call__(self, fl4, fr4, fl8, fr8):
-        dev = fl4.device
+    def __call__(self, *inputs):
+        dev = inputs[0].device
         if not self._primed:
             # weight packing and every other per-module cache are filled by the first call ON THE CALLING STREAM, and drained,
             # before several streams read them
             with torch.no_grad():
-                self.segment(fl4, fr4, fl8, fr8)
+                self.segment(*inputs)
             torch.cuda.synchronize(dev)
             self.lanes = [torch.cuda.Stream(device=dev) for _ in range(self.nlanes)]
             self._primed = True
@@ -369,7 +371,7 @@ class PairPipeline:
             self.segment.OVERLAP = False
         try:
             with torch.cuda.stream(lane), torch.no_grad():
-                out = self.segment(fl4, fr4, fl8, fr8)
+                out = self.segment(*inputs)
         finally:
             if self.nlanes > 1:
                 if had:
@@ -377,8 +379,9 @@ class PairPipeline:
                 else:
                     self.segment.__dict__.pop("OVERLAP", None)
         with torch.cuda.stream(lane):
-            for t in (fl4, fr4, fl8, fr8):
-                t.record_stream(lane)
+            for t in inputs:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(lane)
             self.last_event = torch.cuda.Event()
             self.last_event.record(lane)
         return out

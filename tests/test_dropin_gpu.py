@@ -189,3 +189,26 @@ def test_graphed_segment_replays_the_eager_result(sa):
     got2 = g(*ins2)
     for k in ("pred", "pred_att", "samples"):
         assert torch.equal(got2[k], want2[k]), k
+
+
+def test_pair_pipeline_around_a_whole_model_with_the_untouched_forward(sa, deferral_on):
+    """semstereo_amd.PairPipeline around a model shaped like the reference (backbone + hot segment + SSR head, forward() untouched,
+    install() + accelerate() only): consecutive image pairs on three HIP streams give, bit for bit, what plain calls give."""
+    net, module = _build(sa)
+    previous = sa.install(module)
+    try:
+        sa.accelerate(net)
+        pairs = []
+        for i in range(5):
+            left, right = _images()
+            pairs.append((left + 0.01 * i, torch.roll(right, shifts=i, dims=2)))
+        with torch.no_grad():
+            want = [net(l, r)[0][0].clone() for l, r in pairs]
+        torch.cuda.synchronize()
+        pipe = sa.PairPipeline(net, lanes=3)
+        got = [pipe(l, r) for l, r in pairs]
+        pipe.synchronize()
+        for (g,), w in zip([o[0] for o in got], want):
+            assert torch.equal(g, w), float((g - w).abs().max())
+    finally:
+        sa.uninstall(module, previous)
