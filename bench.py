@@ -505,6 +505,7 @@ def main():
     ap.add_argument("--input-sets", type=int, default=3, help="distinct synthetic input sets rotated through the timed loop")
     ap.add_argument("--streams", type=int, default=4, help="consecutive steps are issued round-robin on this many HIP streams "
                     "(semstereo_amd.PairPipeline; 1: every step on the calling stream, which is ALSO timed and reported as single_stream)")
+    ap.add_argument("--pipelined-only", action="store_true", help="profiling aid: skip the single-stream leg (no per-kernel timers, no roofline)")
     ap.add_argument("--steady-seconds", type=float, default=1.0, help="length of the steady-state leg after the K timed steps (0: skip)")
     ap.add_argument("--parity-pairs", type=int, default=8, help="seeded pairs per conv engine in the parity leg (N = 1 only)")
     ap.add_argument("--no-other-engines", action="store_true", help="skip the extra timings / parity runs of the other engines")
@@ -640,9 +641,12 @@ def main():
         return o, pairs, tmax, dt_own
 
     # leg 1: every step on the calling stream (W + K steps), with the per-kernel HIP-event timers -> `single_stream`, `roofline`
-    out, pairs, tmax, dt_own = timed_run(args.steps, args.warmup, kernel_timers=True)
+    if args.pipelined_only and pipe is not None:
+        out, pairs, tmax, dt_own = timed_run(1, 1)
+    else:
+        out, pairs, tmax, dt_own = timed_run(args.steps, args.warmup, kernel_timers=True)
     assert M.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside the timed region"
-    single = {"pairs_per_s": pairs / tmax, "ms_per_step": 1e3 * tmax / args.steps}
+    single = {"pairs_per_s": pairs / tmax, "ms_per_step": 1e3 * tmax / args.steps} if not args.pipelined_only else None
     if pipe is not None and not graphed:
         # leg 2, the headline: the same W + K steps issued round-robin on --streams streams (no per-kernel events: they would
         # serialise the lanes)
@@ -672,7 +676,7 @@ def main():
         dist_rec["per_rank_pairs_per_s"] = [float(own.item())]
         dist_rec["all_gather_payload_bytes"] = 0
 
-    by_engine, outs = {engine: single["pairs_per_s"]}, {engine: out}
+    by_engine, outs = {engine: single["pairs_per_s"] if single else pairs / tmax}, {engine: out}
     opbyop_rate, fired, unfused_rate = None, None, None
     pipelined = use_pipe[0]
     use_pipe[0] = False                 # the comparison legs below: every step on the calling stream, like `single_stream`
