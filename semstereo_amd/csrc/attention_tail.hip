@@ -92,11 +92,29 @@ __global__ __launch_bounds__(256) void sample_strength_kernel(const float* __res
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     const long long pix = (long long)y * W + x;
     const int cq = (C + 3) / 4, c0 = q * cq, c1 = min(C, c0 + cq);
-    for (int c = c0; c < c1; ++c) {
-        const float l = left[(b * C + c) * plane + pix];
-        const float* rp = right + (b * C + c) * plane;
+    // The row coordinate of all five candidates is the pixel's own row through the fp32 round trip: on 3 rows in 4 it lands exactly
+    // on the integer and both south weights are 0.  When that holds for every lane of the wave (a wave is 64 consecutive pixels:
+    // one row whenever W % 64 == 0) the south taps are not fetched: half of the kernel's gathers (same value for finite features).
+    bool south_live = false;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) acc[t] = ss::add_rn(acc[t], ss::mul_rn(l, bilinear(rp, tp[t])));
+    for (int t = 0; t < 5; ++t) south_live |= (tp[t].w_sw != 0.f) || (tp[t].w_se != 0.f);
+    if (__builtin_amdgcn_ballot_w64(active && south_live) == 0) {
+        for (int c = c0; c < c1; ++c) {
+            const float l = left[(b * C + c) * plane + pix];
+            const float* rp = right + (b * C + c) * plane;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const float a = (tp[t].o_nw >= 0) ? rp[tp[t].o_nw] : 0.f, b2 = (tp[t].o_ne >= 0) ? rp[tp[t].o_ne] : 0.f;
+                acc[t] = ss::add_rn(acc[t], ss::mul_rn(l, ss::add_rn(ss::mul_rn(a, tp[t].w_nw), ss::mul_rn(b2, tp[t].w_ne))));
+            }
+        }
+    } else {
+        for (int c = c0; c < c1; ++c) {
+            const float l = left[(b * C + c) * plane + pix];
+            const float* rp = right + (b * C + c) * plane;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc[t] = ss::add_rn(acc[t], ss::mul_rn(l, bilinear(rp, tp[t])));
+        }
     }
 #pragma unroll
     for (int t = 0; t < 5; ++t) part[q][t][lane] = acc[t];

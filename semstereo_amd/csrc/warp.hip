@@ -223,6 +223,21 @@ __global__ __launch_bounds__(256) void warp_right_gated(const float* __restrict_
     const unsigned off_o = inside ? (unsigned)(((long long)j * plane + pix) * 4) : 0x80000000u;
     const int ystep = (int)(plane * 4), ostep = (int)((long long)nd * plane * 4);
     typedef float f2 __attribute__((ext_vector_type(2)));
+    // The row coordinate depends on h alone, and h is wave-uniform here (one row per wave): on the 3 rows in 4 whose round trip
+    // lands exactly on the integer (fn == 0: both south weights are 0) the south pair is not fetched at all -- half of the kernel's
+    // loads.  Same value for finite features (x + 0 * s == x); a NaN / inf in the skipped row no longer reaches the output
+    // through 0 * inf, which is the one documented difference from F.grid_sample.
+    if (__builtin_amdgcn_readfirstlane(__float_as_int(fn)) == 0) {
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const f2 pn = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(yres, (int)off_n, c * ystep, 0));
+            const float a = west_ok ? (west_is_y ? pn.y : pn.x) : 0.f, bq = east_ok ? (east_is_x ? pn.x : pn.y) : 0.f;
+            float r = ss::add_rn(ss::mul_rn(a, w_nw), ss::mul_rn(bq, w_ne));
+            if (gate) r = ss::mul_rn(g, r);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), ores, (int)off_o, c * ostep, NT ? 2 : 0);
+        }
+        return;
+    }
 #pragma unroll 8
     for (int c = 0; c < C; ++c) {
         const f2 pn = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(yres, (int)off_n, c * ystep, 0));
