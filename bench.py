@@ -173,8 +173,8 @@ def pmc_traffic(key):
     if not rec:
         return None, "no PMC record for this kernel in profiles/pmc_traffic.json", None
     mult = rec.get("fetch_size_multiplier")
-    return rec["total_bytes"], (f"transcribed from profiles/{rec['source']} (separate --pmc passes, not measured in this run): "
-                                f"{rec['read_bytes'] / 1e6:.0f} MB read (FETCH_SIZE x {mult}) + {rec['written_bytes'] / 1e6:.0f} MB written"), mult
+    return rec["total_bytes"], (f"transcribed from profiles/{rec['source']} (--pmc passes, not this run): "
+                                f"{rec['read_bytes'] / 1e6:.0f} MB read (FETCH_SIZE x{mult}) + {rec['written_bytes'] / 1e6:.0f} MB written"), mult
 
 
 def launch_ranks(n, argv):
@@ -355,7 +355,7 @@ def side_rooflines(res, seg, M, timer, H, W, maxdisp, B, device):
     nb8 = 8 * nbytes / B
     tb, tnote, mult = pmc_traffic("gwc_b8")
     res["roofline_cost_volume_b8"] = {
-        "kernel": "gwc_volume_v4<8,true,stream>, batch 8 (BASELINE.json configs[2])", "bound": "hbm",
+        "kernel": "gwc_volume_v4<8,true,stream>, batch 8 (configs[2])", "bound": "hbm",
         "achieved": nb8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "launch_ms": ms8, "frac_cold": nb8 / (ms8_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms_cold": ms8_cold,
         "cold_note": f"frac: one 268 MB input set replayed (reads partly served by the 256 MiB Infinity Cache); frac_cold: {NSETS} input / output "
@@ -738,10 +738,13 @@ def main():
                                "[B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity [B,1,H/4,W/4]",
                    "pairs_per_gpu_per_step": B, "input_sets_rotated": len(feat_sets) if not graphed else 1,
                    "execution": (f"consecutive steps (batch {B} each) round-robin on {args.streams} HIP streams (semstereo_amd.PairPipeline); "
-                                 "results bit-identical to single_stream") if pipelined
+                                 "results bit-identical to one stream") if pipelined
                                 else "every step on one HIP stream",
                    "conv_engine": engine, "conv_engine_note": engine_note, "hip_graph": graphed},
-        "single_stream": single,
+        # (filled below, kept in the line's tail) the headline again beside the one-stream rate of the same K steps
+        "rates": {"pipelined_pairs_per_s": (pairs / tmax) if pipelined else None,
+                  "single_stream_pairs_per_s": single["pairs_per_s"] if single else None,
+                  "single_stream_ms_per_step": single["ms_per_step"] if single else None},
     }
     detail = {"argv": sys.argv[1:], "weights": "random init at unit gain (init_unit_gain), BatchNorm eval",
               "pairs_per_s_by_conv_engine": by_engine, "pairs_per_s_reference_forward_untouched": unfused_rate,
@@ -765,13 +768,13 @@ def main():
             ex = nterms * eq                                   # 16-bit MFMA flops actually issued per second
             sym = ("conv3d_pre<true>" if presplit else
                    f"conv3d_bf16s<1,4,4,4,{code},true,1,3>" if k % 4 == 0 else f"conv3d_bf16s<1,4,2,8,{code},true,1,3>")
-            line["roofline"] = {"kernel": f"{sym} (concat_stem {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]"
-                                          + (", warped half; broadcast half joins as a partial sum" if halves else "") + "; + BN + ReLU + gate)",
+            line["roofline"] = {"kernel": f"{sym}: concat_stem {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]" + (" (warped half) + partial sum" if halves else "")
+                                          + " + BN + ReLU + gate",
                                 "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ex / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
                                 "algorithmic_flop_per_launch": nterms * flops, "fp32_equivalent_tflops": eq,
                                 "frac_of_best_gemm_on_random_data": ex / 1247.0,
-                                "note": f"{nterms} {typ} products per fp32 product; peak: nominal dense 16-bit MFMA; best GEMM measured there: 1247"}
+                                "note": f"{nterms} {typ} products per fp32 product; timed on one stream (single_stream leg)"}
             if (H, W, maxdisp, engine) == (1024, 1024, 128, "f16x3") and halves and not presplit:
                 tb, tnote, mult = pmc_traffic("stem_b1")
                 line["roofline"].update({"traffic": None if tb is None else tb * B, "fetch_size_multiplier": mult, "traffic_note": tnote})
@@ -788,6 +791,7 @@ def main():
             if fcv and "frac" in fcv:
                 line["roofline"]["cost_volume"]["fused_with_patch_and_gate_frac"] = fcv["frac"]
     line["steady_state"] = steady
+    line["rates"]["steady_state_pairs_per_s"] = steady["pairs_per_s"] if steady else None
     line["dist"] = dist_rec
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and parity: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the same workload: about 10 s of CPU
@@ -802,8 +806,8 @@ def main():
         ref = oseg.hot_segment(P, cpu_in[0], cpu_in[1], cpu_in[2], cpu_in[3], maxdisp)
         cdt = time.perf_counter() - c0
         line["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "pairs/s", "cores": nthreads, "kind": "port",
-                                "sample": f"1 pair {H}x{W} maxdisp={maxdisp} through oracle.hot_segment (PyTorch CPU fp32 restatement "
-                                          f"of the reference), {cdt:.1f} s, {nthreads} of {os.cpu_count()} host threads"}
+                                "sample": f"1 pair {H}x{W} md={maxdisp}, oracle.hot_segment (PyTorch CPU fp32 restatement of the reference), "
+                                          f"{cdt:.1f} s, {nthreads} of {os.cpu_count()} host threads"}
         detail["cpu_per_op"] = cpu_per_op_rows(oops, cpu_in, ref, maxdisp, H4, W4, nthreads)
         parity = {}
         with torch.no_grad():
@@ -846,13 +850,34 @@ def main():
             json.dump(detail, f, indent=1)
     except OSError as e:
         line["detail"] = f"not written: {e!r}"
-    text = json.dumps(line)
+
+    def compact(x):
+        """6 significant digits for every float of the line (the detail file keeps them all)."""
+        if isinstance(x, float):
+            return float(f"{x:.6g}")
+        if isinstance(x, dict):
+            return {k_: compact(v) for k_, v in x.items()}
+        if isinstance(x, list):
+            return [compact(v) for v in x]
+        return x
+    # Order (VERDICT r3 #5): the contract's keys first; then the bulk; and LAST -- inside the 2 000-character tail the driver keeps --
+    # the numbers a review needs: rates (pipelined / single stream / steady state), roofline (dominant kernel + the batch-8 cost-volume kernel), cpu_baseline, parity
+    seeded = (line.get("parity") or {}).pop("seeded_pairs", None)
+    tail_keys = ("rates", "roofline", "cpu_baseline", "parity")
+    ordered = {k_: v for k_, v in line.items() if k_ not in tail_keys}
+    if seeded is not None:
+        ordered["parity_seeded_pairs"] = seeded
+    for k_ in tail_keys:
+        if k_ in line:
+            ordered[k_] = line[k_]
+    line = compact(ordered)
+    text = json.dumps(line, separators=(",", ":"))
     if len(text) > LINE_BUDGET:            # never let a note push a headline number out of the driver's record: drop notes first
         for path in (("roofline", "traffic_note"), ("roofline", "note"), ("config", "conv_engine_note"), ("cpu_baseline", "sample")):
             node = line.get(path[0])
             if isinstance(node, dict) and path[1] in node and len(text) > LINE_BUDGET:
                 node[path[1]] = str(node[path[1]])[:60] + "..."
-                text = json.dumps(line)
+                text = json.dumps(line, separators=(",", ":"))
     print(text, flush=True)
     if grouped:
         dist.barrier()

@@ -100,5 +100,5 @@ def test_two_ranks_on_one_gpu_through_the_real_step():
     assert len(lines) == 1, r.stdout
     res = lines[0]
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
-    assert abs(res["value"] * res["ms_per_step"] * 1e-3 - 2.0) < 1e-6          # pairs/s x s/step = 2 pairs per step over both ranks
+    assert abs(res["value"] * res["ms_per_step"] * 1e-3 - 2.0) < 1e-4          # pairs/s x s/step = 2 pairs per step over both ranks (the line carries 6 significant digits)
     assert "roofline" in res
