@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
-usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low attn attn_att warp ssr ssr2048 strength topk
+usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low conv_mid_att conv_low_att attn attn_att warp ssr ssr2048 strength topk
                                                                catt8 catt4 upsoft stem_left stem conv_s1 conv_s2 conv_s2_att deconv"""
 import os
 import sys
@@ -85,8 +85,8 @@ elif name in ("attn", "attn_att"):       # attention_block of hourglass2 ([128,6
     x = R(B, 128, d, hw, hw)
     fn = lambda: ab(x)                                                         # noqa: E731
     nbytes = 4.0 * B * 2 * 128 * d * hw * hw
-elif name in ("conv_mid", "conv_low"):   # hourglass2.conv2: 64 -> 64 at [12,128,128]; conv4: 128 -> 128 at [6,64,64]
-    c, d, hw = (64, 12, 128) if name == "conv_mid" else (128, 6, 64)
+elif name in ("conv_mid", "conv_low", "conv_mid_att", "conv_low_att"):   # hourglass2.conv2: 64 -> 64 at [12,128,128]; conv4: 128 -> 128 at [6,64,64]; hourglass_att's: [16,64,64], [8,32,32]
+    c, d, hw = {"conv_mid": (64, 12, 128), "conv_low": (128, 6, 64), "conv_mid_att": (64, 16, 64), "conv_low_att": (128, 8, 32)}[name]
     x = torch.relu(R(B, c, d, hw, hw))
     ws = M.pack_conv_weight_bf16s(R(c, c, 3, 3, 3) * 0.03, 19)
     sc, sh = torch.rand(c, device=dev) + 0.5, R(c) * 0.1
