@@ -64,11 +64,36 @@ __device__ __forceinline__ float bilinear(const float* __restrict__ plane, const
     return r;
 }
 
+// The west / east taps of a row are neighbours in memory: ONE 8-byte load (4-byte aligned; gfx950 takes it) instead of two
+// 4-byte gathers -- the probe below is bound by its gather instructions (21 -> 11 per channel and pixel; 70 MB algorithmic at
+// 1.1 TB/s).  `off` is where the pair is fetched, `mode` which of its halves are the taps: bit 0 / 1 = west / east tap valid,
+// bit 2 = the west tap is the pair's SECOND element (east neighbour outside the image: the pair is fetched one column to the
+// left so that it stays inside the plane), bit 3 = the east tap is the pair's FIRST element (west neighbour outside).
+typedef float f32x2_u __attribute__((ext_vector_type(2)));
+typedef f32x2_u f32x2_a4 __attribute__((aligned(4)));
+struct PairTap {
+    int off, mode;
+};
+__device__ __forceinline__ PairTap pair_tap(int o_w, int o_e) {
+    PairTap p;
+    if (o_w >= 0 && o_e >= 0) { p.off = o_w; p.mode = 3; }
+    else if (o_w >= 0) { p.off = o_w - 1; p.mode = 1 | 4; }
+    else if (o_e >= 0) { p.off = o_e; p.mode = 2 | 8; }
+    else { p.off = 0; p.mode = 0; }
+    return p;
+}
+__device__ __forceinline__ void pair_fetch(const float* __restrict__ plane, const PairTap& p, float& west, float& east) {
+    const f32x2_u v = *reinterpret_cast<const f32x2_a4*>(plane + p.off);
+    west = (p.mode & 1) ? ((p.mode & 4) ? v.y : v.x) : 0.f;
+    east = (p.mode & 2) ? ((p.mode & 8) ? v.x : v.y) : 0.f;
+}
+
 // strength[b,t,y,x] = softmax_t( mean_c left[c] * warp(right, pred0[nb_t])[c]  *  sigmoid(beta + gamma * var[nb_t]) )
 // 64 pixels x 4 waves: wave q owns channels [q*C/4, (q+1)*C/4) of the same 64 pixels (a pixel per thread
 // would leave a 1024x1024 pair with one wave per SIMD and 1408 dependent L2 reads each); the four partial
 // correlations meet in LDS and wave 0 finishes the softmax.
-__global__ __launch_bounds__(256) void sample_strength_kernel(const float* __restrict__ left, const float* __restrict__ right,
+template <bool PAIRS>      // PAIRS: west / east taps fetched as one 8-byte pair (W >= 2)
+__global__ __launch_bounds__(256, 3) void sample_strength_kernel(const float* __restrict__ left, const float* __restrict__ right,
                                                                const float* __restrict__ pred0, const float* __restrict__ var,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* __restrict__ strength, int C, int H, int W,
@@ -98,7 +123,43 @@ __global__ __launch_bounds__(256) void sample_strength_kernel(const float* __res
     bool south_live = false;
 #pragma unroll
     for (int t = 0; t < 5; ++t) south_live |= (tp[t].w_sw != 0.f) || (tp[t].w_se != 0.f);
-    if (__builtin_amdgcn_ballot_w64(active && south_live) == 0) {
+    const bool north_only = __builtin_amdgcn_ballot_w64(active && south_live) == 0;
+    if constexpr (PAIRS) {     // (a 1-column image has no pair to fetch: the scalar taps below)
+        PairTap pn[5], ps[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            pn[t] = pair_tap(tp[t].o_nw, tp[t].o_ne);
+            ps[t] = pair_tap(tp[t].o_sw, tp[t].o_se);
+        }
+        if (north_only) {
+            for (int c = c0; c < c1; ++c) {
+                const float l = left[(b * C + c) * plane + pix];
+                const float* rp = right + (b * C + c) * plane;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    float a, b2;
+                    pair_fetch(rp, pn[t], a, b2);
+                    acc[t] = ss::add_rn(acc[t], ss::mul_rn(l, ss::add_rn(ss::mul_rn(a, tp[t].w_nw), ss::mul_rn(b2, tp[t].w_ne))));
+                }
+            }
+        } else {
+            for (int c = c0; c < c1; ++c) {
+                const float l = left[(b * C + c) * plane + pix];
+                const float* rp = right + (b * C + c) * plane;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    float a, b2, c2, d2;
+                    pair_fetch(rp, pn[t], a, b2);
+                    pair_fetch(rp, ps[t], c2, d2);
+                    float r = ss::mul_rn(a, tp[t].w_nw);                 // the order of bilinear()
+                    r = ss::add_rn(r, ss::mul_rn(b2, tp[t].w_ne));
+                    r = ss::add_rn(r, ss::mul_rn(c2, tp[t].w_sw));
+                    r = ss::add_rn(r, ss::mul_rn(d2, tp[t].w_se));
+                    acc[t] = ss::add_rn(acc[t], ss::mul_rn(l, r));
+                }
+            }
+        }
+    } else if (north_only) {
         for (int c = c0; c < c1; ++c) {
             const float l = left[(b * C + c) * plane + pix];
             const float* rp = right + (b * C + c) * plane;
@@ -483,8 +544,13 @@ extern "C" int ss_sample_strength_fwd(const float* left, const float* right, con
     SS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0);
     const long long total = (long long)B * H * W;
     const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
-    hipLaunchKernelGGL(sample_strength_kernel, dim3((unsigned)ss::ceil_div_ll(total, 64)), dim3(256), 0,
-                       ss::as_stream(stream), left, right, pred0, var, gamma, beta, strength, C, H, W, half_w, half_h, total);
+    const dim3 grid((unsigned)ss::ceil_div_ll(total, 64));
+    if (W >= 2)
+        hipLaunchKernelGGL(sample_strength_kernel<true>, grid, dim3(256), 0, ss::as_stream(stream), left, right, pred0, var,
+                           gamma, beta, strength, C, H, W, half_w, half_h, total);
+    else
+        hipLaunchKernelGGL(sample_strength_kernel<false>, grid, dim3(256), 0, ss::as_stream(stream), left, right, pred0, var,
+                           gamma, beta, strength, C, H, W, half_w, half_h, total);
     return ss::check_launch();
 }
 
