@@ -321,6 +321,53 @@ def seeded_pairs_parity(seg, M, engines, n_pairs, H, W, maxdisp, device, threads
     return stats, rows, secs
 
 
+def power_under_load(run_steps):
+    """Socket power and shader clock (rocm-smi, ~3 samples a second from a side thread) while `run_steps()` keeps the step loop
+    busy.  The step sits at the package power cap with the shader clock throttled (profiles/r04_w_power_trace.txt: 1335 W of
+    1400, 2.0 of 2.4 GHz): what `roofline.frac` of a NOMINAL-clock peak can reach is bounded by that, and a kernel made faster
+    without spending less energy moves the whole step less than its own time.  None when rocm-smi is not there."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    samples, stop = [], threading.Event()
+
+    def ask(*flags):
+        return subprocess.run([smi, *flags], capture_output=True, text=True, timeout=10).stdout
+
+    def sample():
+        while not stop.is_set():
+            try:
+                o = ask("--showpower", "--showclocks")
+                pw, ck = re.search(r"Power \(W\): ([0-9.]+)", o), re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", o)
+                if pw and ck:
+                    samples.append((float(pw.group(1)), int(ck.group(1))))
+            except Exception:
+                pass
+            stop.wait(0.05)
+    th = threading.Thread(target=sample, daemon=True)
+    th.start()
+    try:
+        run_steps()
+    finally:
+        stop.set()
+        th.join(timeout=15)
+    try:
+        cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", ask("--showmaxpower"))
+        cap = float(cap.group(1)) if cap else None
+    except Exception:
+        cap = None
+    if not samples:
+        return None
+    top = max(w for w, _ in samples)
+    busy = [(w, c) for w, c in samples if w >= 0.85 * top]          # drops the ramp at both ends
+    return {"socket_w": sum(w for w, _ in busy) / len(busy), "cap_w": cap, "sclk_mhz": sum(c for _, c in busy) / len(busy),
+            "samples": len(busy)}
+
+
 def side_rooflines(res, seg, M, timer, H, W, maxdisp, B, device):
     """The bandwidth kernels measured beside the step (forensics: gpurun_out/bench_detail.json; the batch-8 cost-volume kernel --
     the north star's >= 50 % of HBM deliverable -- is also copied into the line's `roofline.cost_volume`)."""
@@ -515,6 +562,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the oracle run")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-side-rooflines", action="store_true", help="skip the bandwidth kernels measured beside the step")
+    ap.add_argument("--power-seconds", type=float, default=2.5, help="seconds of the step loop sampled with rocm-smi (socket power, shader clock; N = 1 only; 0: skip)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), help="where the forensics go")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (one launch per step instead "
                     "of ~45 from Python); the per-kernel HIP-event timers are off in this mode")
@@ -660,6 +708,10 @@ def main():
         n_steady = max(args.steps, int(args.steady_seconds / max(tmax / args.steps, 1e-6)) + 1)
         _, p_s, t_s, _ = timed_run(n_steady, 0)
         steady = {"pairs_per_s": p_s / t_s, "steps": n_steady, "seconds": t_s}
+    power = None
+    if args.power_seconds > 0 and world == 1 and not dry:
+        n_power = int(args.power_seconds / max(tmax / args.steps, 1e-6)) + 1
+        power = power_under_load(lambda: timed_run(n_power, 0))
 
     # what a SCALE run must show to be self-verifying -- the group's size as torch.distributed sees it, every rank's
     # own rate, and the bytes of the one collective that follows the forward (the padded all_gather of the [b,1,H/4,W/4] disparities)
@@ -792,6 +844,7 @@ def main():
                 line["roofline"]["cost_volume"]["fused_with_patch_and_gate_frac"] = fcv["frac"]
     line["steady_state"] = steady
     line["rates"]["steady_state_pairs_per_s"] = steady["pairs_per_s"] if steady else None
+    line["rates"]["power_under_load"] = power
     line["dist"] = dist_rec
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and parity: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the same workload: about 10 s of CPU
