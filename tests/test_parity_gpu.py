@@ -261,6 +261,22 @@ def test_topk_generic_k_and_ties(sa):
     check("topk/ties", sa.ops.regression_topk(dev(c), dev(s), 2), oops.regression_topk(c, s, 2), 1e-5)
 
 
+@pytest.mark.parametrize("H,W", [(2, 2), (3, 2), (2, 3), (5, 3), (4, 65)])      # (H or W = 1: the reference itself divides by W - 1 = 0)
+def test_sample_strength_on_narrow_maps(sa, H, W):
+    """The probe fetches the west / east taps of a row as one 8-byte pair: pairs at the first and last element of a plane, both
+    taps / one tap / no tap inside, a wave that spans several rows (W = 65)."""
+    from oracle import detdata as dd
+    B, C = 2, 8
+    left, right = dd.stereo_features(B, C, H, W, 5, max_shift=1)
+    pred0 = dd.t_uniform((B, H, W), 311, -2.5, 2.5)
+    var = dd.t_uniform((B, 1, H, W), 312, 0.0, 30.0)
+    gamma, beta = torch.tensor([0.25]), torch.tensor([2.0])
+    rw, lb = oops.SpatialTransformer_grid(left, right, oops.propagation(pred0.unsqueeze(1)))
+    strength = torch.softmax((lb * rw).mean(dim=1) * oops.propagation(torch.sigmoid(beta + gamma * var)), dim=1)
+    got = sa.ops.sample_strength(dev(left), dev(right), dev(pred0), dev(var), dev(gamma), dev(beta))
+    check(f"sample_strength_narrow/{H}x{W}", got, strength, 1e-6, 1e-6)
+
+
 @pytest.mark.parametrize("m", [16, 20, 32])      # D = 32, 64: register kernel; D = 40: generic LDS kernel
 def test_attention_tail_fused_kernels(sa, m):
     """ss_sample_strength_fwd (:286-293) and ss_topk_candidates_fwd (:295-310) against the oracle's
