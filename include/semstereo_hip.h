@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (11 since round 4; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -240,6 +240,22 @@ int ss_conv3d_bf16s_partial_fwd(const float* in, const void* wsplit, const float
                                 const float* shift, const float* gate, float* out,
                                 int B, int Cin, int D, int H, int W, int Cout, int relu, int nterms,
                                 ss_stream_t stream);
+/* concat_stem with the warped half of the sparse concat volume formed INSIDE the convolution's staging (round 5; SURVEY.md
+ * section 8 f1, second half).  Replaces, in one launch and without a [B,Cin,nd,H,W] volume,
+ *   models/SemStereo.py:241-244 (concat_volume_generator: SpatialTransformer_grid, models/submodule.py:265-288),
+ *   :318 (att_topk * volume) on the warped half, :319 (concat_stem: Conv3d k3 s1 p1 + BatchNorm + ReLU over THESE Cin channels,
+ *   continuing `partial`) and :320 (the channelAtt gate):
+ *   out[b,co,j,h,w] = gate[b,co,h,w] * relu?(scale[co] * (partial[b,co,j,h,w] + sum_{ci,taps} w * x[b,ci,j',h',w']) + shift[co]),
+ *   x[b,ci,j,h,w] = att[b,j,h,w] * right[b,ci,h,w - cand[b,j,h,w]]  (0 where that column lies outside [0,W)).
+ * right [B,Cin,H,W]; cand, att [B,nd,H,W]; partial [B,Cout,nd,H,W] / scale / shift [Cout] / gate [B,Cout,H,W] may be NULL.
+ * CONTRACT: the candidates are INTEGER-valued floats -- what models/SemStereo.py:299-305 produces (indices - maxdisp/4) --
+ * for which the reference's bilinear F.grid_sample is a gather up to its own coordinate rounding (<= 1e-5 relative on the
+ * columns / rows whose normalise -> unnormalise round trip is inexact; the gather is the float64-exact value).  Fractional
+ * candidates are truncated toward zero: use ss_concat_sampled_fwd + ss_conv3d_bf16s_partial_fwd for those.
+ * Cin % 8 == 0, Cin >= 16; nterms = 19 only (wsplit from ss_pack_conv3d_weights_f16s); SS_ERR_UNSUPPORTED otherwise. */
+int ss_conv3d_gather_fwd(const float* right, const float* cand, const float* att, const void* wsplit, const float* partial,
+                         const float* scale, const float* shift, const float* gate, float* out,
+                         int B, int Cin, int nd, int H, int W, int Cout, int relu, int nterms, ss_stream_t stream);
 /* concat_stem on the pre-split warped half (models/SemStereo.py:319-320): Conv3d(k3, s1, p1, bias=False) over
  * xs / xexp of ss_concat_sampled_presplit_fwd (Cin % 8 == 0), out = gate * relu?(scale * (partial + conv) + shift);
  * wsplit from ss_pack_conv3d_weights_f16s; partial [B,Cout,D,H,W], scale / shift [Cout], gate [B,Cout,H,W] may be NULL.

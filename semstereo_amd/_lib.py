@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "ss_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_bf16s_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_bf16s_partial_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_conv3d_gather_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_weights_bf16s": [_P, _P, _I, _I, _P],
     "ss_pack_conv3d_weights_f16s": [_P, _P, _I, _I, _P],
     "ss_conv2d_bf16s_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

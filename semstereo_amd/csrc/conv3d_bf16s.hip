@@ -97,7 +97,8 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsig
 // KD: kernel depth, 3 (3x3x3) or 1 (3x3 over [B,C,H,W] maps seen as depth-1 volumes: 9 taps, 5 K-steps)
 // WSL: 16-byte LDS slots of a chunk's weight fragments (0: every wave fetches its own)
 // MS: waves that share a row group and split the workgroup's output channels (1: every wave owns NT rows of all of them)
-template <int S, int NT, int TD, int TH, int KD = 3, int LT = 3, int WSL = 0, int MS = 1>      // LT: operand terms kept in LDS
+// XSL: further 16-byte slots behind everything else (the gather form's candidate / weight words)
+template <int S, int NT, int TD, int TH, int KD = 3, int LT = 3, int WSL = 0, int MS = 1, int XSL = 0>      // LT: operand terms kept in LDS
 struct BCfg {
     static constexpr int KT = KD * 9, KSTEPS = (KT + 1) / 2;
     static constexpr int ID = (TD - 1) * S + KD, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
@@ -105,13 +106,19 @@ struct BCfg {
     static constexpr int CS = ID * IH * IW;                    // positions in the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
     // + one all-zero slot (the 28th half-step) + the waves' maxima (f16 form) + the affine of the workgroup's (<= 64) channels
-    static constexpr int SLOTS = LT * CS + 2 + 48 + WSL;
+    static constexpr int SLOTS = LT * CS + 2 + 48 + WSL + XSL;
+    static constexpr int XS0 = LT * CS + 2 + 48 + WSL;         // first extra slot
     static constexpr size_t LDS_BYTES = (size_t)SLOTS * 16;
     static_assert(TD * TH * MS == 4 * NT && TH % NT == 0 && (MS == 1 || MS == 2), "4 / MS wave groups x NT rows tile TD x TH");
 };
 
 constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
     return NTERMS == 19 && S == 1 && NT == 1 && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
+}
+// gather form: per halo position one candidate word and two attention words (this tile's, the next tile's), each thread's
+// own positions p = tid + 256 i -> 3 x NPOS x 256 floats
+constexpr int gather_slots(bool gather, int S, int TD, int TH, int KD) {
+    return gather ? 3 * ((((TD - 1) * S + KD) * ((TH - 1) * S + 3) * (31 * S + 3) + 255) / 256) * 64 : 0;
 }
 
 // Chunk-blocked accumulation (ACCB of the kernel) is a property of the LAYER, never of the tile a launch happens to get: the
@@ -135,13 +142,24 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // fetches the weight fragments of ITS channels only (the vector L1 carried every fragment four times per workgroup: 32 KB
 // per K-step and CU beside 8 KB of activations, 640 clocks at its 64 B/clk for 384 clocks of MFMA issue -- tools/wg_phases_s2.py)
 // and reads the activation fragments of two rows from LDS instead of one.
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false>
+//
+// GATHER (r05; SURVEY.md section 8 f1, second half: sparse concat -> x att -> concat_stem in ONE launch): `in` is the 2-D right
+// feature map [B,Cin,H,W]; the operand of the convolution, x[c, j, h, w] = att[j,h,w] * in[c, h, w - cand[j,h,w]] (zero where
+// the column leaves the image) -- the warped half of the reference's sparse concat volume times the attention weights
+// (models/SemStereo.py:241-244, 316-318; models/submodule.py:265-288 for INTEGER candidates, which is what :299-305 produce) --
+// is formed while the halo tile is staged: no [B,Cin,nd,H,W] volume exists.  Per halo position the candidate and the weight
+// are fetched once per TILE by LDS-DMA (no registers: each thread's own positions, parked in LDS) a chunk ahead of their
+// first use; the gathered loads take the place of the volume loads one for one (same prefetch registers, same slices).
+// D = the number of candidates.  Cin % 8 == 0 and Cin >= 16 (the look-ahead needs two chunks per tile).
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false, bool GATHER = false>
 __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
                                                         float* __restrict__ out,
                                                         int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
-                                                        int tiles_w, int tiles_h, int ntiles, int relu) {
+                                                        int tiles_w, int tiles_h, int ntiles, int relu,
+                                                        const float* __restrict__ cand, const float* __restrict__ catt) {
+    static_assert(!GATHER || (S == 1 && MT == 1 && KD == 3 && MS == 1), "gather form: plain stride-1 3-D tiles");
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
     constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed weights
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     constexpr bool WLDS = wlds_form(S, NT, NTERMS, MT, KD);
     static_assert(!ACCB || NTERMS == F16X3, "chunk-blocked accumulation: fp16 form only");
     static_assert(!WLDS || MS == 1, "the LDS copy of the weights is one channel tile's");
-    using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS>;
+    using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS, gather_slots(GATHER, S, TD, TH, KD)>;
     constexpr int WL = NC * C::CS + 2 + 48;                    // first slot of the weight fragments
     constexpr int KSTEPS = C::KSTEPS;                          // shadows the 3-D constant
     constexpr int ZSLOT = NC * C::CS;                          // the all-zero slot; ZSLOT + 1: the four waves' maxima
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     auto cbase = [&](int mt, int r) { return cow + mt * 32 + (r & 3) + 8 * (r >> 2); };
     f32x16 acc[MT * NT];                  // index mt * NT + row
 
-    const size_t in_plane = (size_t)H * W, chan = (size_t)D * in_plane;
+    const size_t in_plane = (size_t)H * W, chan = GATHER ? in_plane : (size_t)D * in_plane;     // (gather: channels of a 2-D map)
     const float* inb = in + (size_t)b * Cin * chan;
 
     // staging plan of a tile: this thread owns positions p = tid + 256*i of the halo tile, all 8 channels
@@ -241,7 +259,51 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         }
     };
     unsigned poff[C::NPOS];
-    make_poff(blockIdx.x, poff);
+    if constexpr (!GATHER) make_poff(blockIdx.x, poff);
+    // ---- gather form: candidates and attention weights of a tile's halo positions, parked in LDS ----
+    float* gcand = reinterpret_cast<float*>(&lds[C::XS0]);                       // [NPOS * 256]: candidates of the tile set up next
+    float* gatt = gcand + C::NPOS * 256;                                        // [2][NPOS * 256]: weights of this tile / the next
+    const __amdgpu_buffer_rsrc_t cres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(GATHER ? cand + (size_t)b * D * in_plane : in), 0, GATHER ? (int)min((long long)D * (long long)in_plane * 4, 0x7fffffffLL) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(GATHER ? catt + (size_t)b * D * in_plane : in), 0, GATHER ? (int)min((long long)D * (long long)in_plane * 4, 0x7fffffffLL) : 0, 0x00020000);
+    // request (LDS-DMA, 4 bytes per lane, no registers) the candidate and weight words of `tile`'s halo positions; positions
+    // outside the volume -- and every position of a tile that does not exist -- read beyond the buffers and get zeros
+    auto gather_request = [&](int tile, int buf) {
+        unsigned po[C::NPOS];
+        make_poff(tile, po);                                   // offsets into [D][H][W]: the candidates' and the weights' own layout
+        const unsigned dead = tile < ntiles ? 0u : 0x80000000u;
+        const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);
+#pragma unroll
+        for (int i = 0; i < C::NPOS; ++i) {
+            lds_dma4(cres, gcand + 256 * i + wbase, (int)(po[i] | dead), 0);
+            lds_dma4(tres, gatt + buf * (C::NPOS * 256) + 256 * i + wbase, (int)(po[i] | dead), 0);
+        }
+    };
+    // offsets of the gathered elements of `tile` (its candidates have landed in gcand): row h, column w - candidate of the 2-D map
+    auto gather_offsets = [&](int tile, unsigned (&po)[C::NPOS]) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the LDS-DMA words have landed
+        int ow0, oh0, od0;
+        tile_origin(tile, ow0, oh0, od0);
+        const int iw0 = ow0 - 1, ih0 = oh0 - 1, id0 = od0 - 1;
+#pragma unroll
+        for (int i = 0; i < C::NPOS; ++i) {
+            const int p = tid + 256 * i;
+            const int wx = p % C::IW;
+            int r = p / C::IW;
+            const int hy = r % C::IH;
+            const int dz = r / C::IH;
+            const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz;
+            const int col = gw - (int)lds_read4(gcand + p);      // integer candidates (the ABI's contract)
+            const bool ok = (p < C::CS) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W &&
+                            (unsigned)col < (unsigned)W && tile < ntiles;
+            po[i] = ok ? (unsigned)(((size_t)gh * W + col) * 4) : 0x80000000u;
+        }
+    };
+    if constexpr (GATHER) {
+        gather_request(blockIdx.x, 0);
+        gather_offsets(blockIdx.x, poff);
+    }
     // input prefetch registers, flattened q = c * NPOS + i, loaded in KSTEPS slices spread over the
     // K-steps of the previous chunk so that a wait for a weight fragment never drains them all
     constexpr int NQ = 8 * C::NPOS;
@@ -302,6 +364,17 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // (scale 2^(E_ONE - e)); e_run = that of the running maximum of the tile (monotone: the accumulators only scale DOWN
     // after the first chunk, so they cannot overflow)
     int e_cur = E_ONE, e_run = E_MIN;
+    // gather form: the prefetched chunk times the attention weights of its positions (models/SemStereo.py:318), rounded to fp32 as
+    // the reference's materialised product is
+    auto apply_att = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < C::NPOS; ++i) {
+            const float a = lds_read4(gatt + buf * (C::NPOS * 256) + tid + 256 * i);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rin[c * C::NPOS + i] = ss::mul_rn(rin[c * C::NPOS + i], a);
+        }
+    };
+    if constexpr (GATHER) apply_att(0);
     auto publish_max = [&](float m) {                                         // this wave's max(m, |rin|) -> LDS
 #pragma unroll
         for (int q = 0; q < NQ; ++q) m = fmaxf(m, fabsf(rin[q]));
@@ -314,7 +387,8 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     }
     SS_STAMP(1);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int gbuf = 0;                                               // gather form: which half of gatt holds this tile's weights
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, gbuf ^= 1) {
     const bool has_next = tile + (int)gridDim.x < ntiles;
 #pragma unroll
     for (int i = 0; i < MT * NT; ++i)
@@ -375,7 +449,12 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         const bool more = ci0 + 8 < Cin;                       // another chunk of THIS tile follows
         // what the K-steps prefetch: the next chunk of this tile, or (last chunk) the first chunk of the workgroup's next tile
         // (this tile's own offsets are not needed past this point: its last chunk is already staged)
-        if (!more) make_poff(tile + (int)gridDim.x, poff);                  // pure index arithmetic under a wave-uniform branch
+        if constexpr (GATHER) {
+            // second-to-last chunk: request the next tile's candidates / weights; last chunk: they have landed (every load of the
+            // chunk in between was issued behind them) -- the prefetch below then gathers the next tile's first chunk
+            if (more && ci0 + 16 >= Cin) gather_request(tile + (int)gridDim.x, gbuf ^ 1);
+            if (!more) gather_offsets(tile + (int)gridDim.x, poff);
+        } else if (!more) make_poff(tile + (int)gridDim.x, poff);          // pure index arithmetic under a wave-uniform branch
         nlive_next = more ? min(8, Cin - ci0 - 8) : min(8, Cin);
         const int ch_next = more ? ci0 + 8 : 0;
         const unsigned nomore = (more || has_next) ? 0u : 0x80000000u;
@@ -501,6 +580,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         }
         nlive = nlive_next;
         SS_STAMP_STEPS_END();
+        if (GATHER && (more || has_next)) apply_att(more ? gbuf : gbuf ^ 1);
         if (F16 && (more || has_next)) publish_max(0.f);       // of the chunk staged next (its loads were issued >= 4 K-steps ago)
         __syncthreads();
     }
@@ -609,6 +689,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     SS_STAMP_FINISH();
 }
 
+#ifndef SS_CONV_GATHER_TU
 // [Cout,Cin,3,3,3] fp32 -> [ceil(Cin/8)][14 steps][3 terms][2 halves][Cout][8] bf16 (zero padded)
 __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit, int Cout,
                                           int Cin, int ktaps, long long total) {
@@ -668,15 +749,19 @@ __global__ void pack_weights_f16s_kernel(const float* __restrict__ w, unsigned s
     wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
 }
 
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false>
+#endif  // !SS_CONV_GATHER_TU
+
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false, bool GATHER = false>
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
-              const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
-    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2, wlds_form(S, NT, NTERMS, MT, KD) ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS>;
+              const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st,
+              const float* cand = nullptr, const float* catt = nullptr) {
+    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2, wlds_form(S, NT, NTERMS, MT, KD) ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS,
+                   gather_slots(GATHER, S, TD, TH, KD)>;
     const int Do = (D + 2 * (KD / 2) - KD) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD, MS, ACCB>;
+    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD, MS, ACCB, GATHER>;
     if (C::LDS_BYTES > 64 * 1024) {
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
@@ -691,10 +776,11 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
     // the same time.  Starting the first round's workgroups spread over 0.5-1.5 estimated lifetimes, in 2-16 groups, was
     // measured: no gain, -0 .. -8 %.)
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
-                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, (int)nt, relu);
+                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, (int)nt, relu, cand, catt);
     return ss::check_launch();
 }
 
+#ifndef SS_CONV_GATHER_TU
 template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, bool ACCB>
 int launch_bg(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st) {
@@ -729,8 +815,11 @@ int launch_b(const float* in, const void* wsplit, const float* scale, const floa
     return launch_bg<S, NT, TD, TH, NTERMS, false, false>(in, wsplit, scale, shift, residual, gate, out, B, Cin, D, H, W, Cout, relu, st);
 }
 
+#endif  // !SS_CONV_GATHER_TU
+
 }  // namespace
 
+#ifndef SS_CONV_GATHER_TU
 static int conv3d_bf16s_impl(const float* in, const void* wsplit, const float* scale, const float* shift,
                              const float* residual, const float* gate, float* out, int B, int Cin, int D, int H,
                              int W, int Cout, int stride, int relu, int nterms, ss_stream_t stream);
@@ -853,3 +942,4 @@ extern "C" int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const fl
     SS_B2(1, 4);
 #undef SS_B2
 }
+#endif  // !SS_CONV_GATHER_TU

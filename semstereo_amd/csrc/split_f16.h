@@ -38,6 +38,14 @@ __device__ __forceinline__ unsigned wave_max_bits(unsigned x) {
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t res, uint4* dst, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(res, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
 }
+// ... and 4 bytes per lane (buffer_load_dword ... lds): 64 lanes -> 256 bytes of LDS at `dst`
+__device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t res, float* dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(res, (__attribute__((address_space(3))) void*)dst, 4, voffset, soffset, 0, 0);
+}
+// a 4-byte LDS read that stays a ds_read_b32 on data the compiler cannot see being written (LDS-DMA); `p` points into LDS
+__device__ __forceinline__ float lds_read4(const float* p) {
+    return *(const volatile float __attribute__((address_space(3)))*)(p);
+}
 constexpr int F16X3 = 19;                                       // the ABI's `nterms` code of this form
 // biased fp32 exponents.  A maximum with exponent e is scaled by 2^(E_ONE - e) into [2^14, 2^15); E_MIN floors e so that
 // every scale and its inverse stay normal fp32 numbers (values below 2^-111 are flushed).  Both operands being normalised,

@@ -532,6 +532,44 @@ def stem_volume_half_presplit(stem, xs, xexp, partial, gate=None):
     return out
 
 
+#: SS_STEM_GATHER (r05): concat_stem's warped half GATHERED inside the conv's staging from the 2-D right
+#: feature map (ss_conv3d_gather_fwd) -- no warp launch, no 201 MB volume.  For INTEGER candidates only (what the reference's
+#: top-24 selection produces, models/SemStereo.py:299-305): callers pass `integer_candidates=True` when they know the provenance.
+STEM_GATHER = os.environ.get("SS_STEM_GATHER", "1") != "0"
+
+
+def stem_gather_applies(stem, right, samples):
+    return (STEM_GATHER and CONV_ENGINE == "f16x3" and right.shape[1] % 8 == 0 and right.shape[1] >= 16
+            and stem.conv.in_channels == 2 * right.shape[1] and _conv_geometry(stem.conv) == (3, 1)
+            and right.dtype == torch.float32 and samples.dtype == torch.float32)
+
+
+def stem_gather_half(stem, right, samples, att, partial, gate=None):
+    """`stem` over its last C input channels when they are att * (the 2-D map `right` [B,C,H,W] warped by the INTEGER candidates
+    `samples` [B,nd,H,W]) -- models/SemStereo.py:241-244, 316-320 -- continuing `partial`, then BatchNorm, ReLU and the gate:
+    one launch, the operand gathered while the conv stages its tiles."""
+    assert stem.is_3d and not stem.deconv and CONV_ENGINE == "f16x3" and _inference(stem, right, partial, gate)
+    right, samples = right.contiguous(), samples.contiguous()
+    att = att.reshape(att.shape[0], att.shape[-3], att.shape[-2], att.shape[-1]).contiguous()
+    B, C, H, W = right.shape
+    nd = samples.shape[1]
+    assert samples.shape == (B, nd, H, W) and att.shape == samples.shape
+    _, _, wr, scale, shift = _stem_halves_params(stem, C)
+    Cout = stem.conv.out_channels
+    g = None if gate is None else gate.contiguous()
+    dev = _lib.require_device(right, samples, att, partial, scale, shift, g)
+    out = torch.empty((B, Cout, nd, H, W), dtype=torch.float32, device=right.device)
+    if partial is not None:
+        assert partial.shape == out.shape and partial.is_contiguous()
+    if g is not None:
+        assert g.shape == (B, Cout, H, W)
+    PATH_COUNTS["hip"] += 1
+    with torch.cuda.device(dev):
+        call("ss_conv3d_gather_fwd", ptr(right), ptr(samples), ptr(att), ptr(wr), ptr(partial), ptr(scale), ptr(shift), ptr(g),
+             ptr(out), B, C, nd, H, W, Cout, int(bool(stem.relu)), _tiled_nterms())
+    return out
+
+
 def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate=None):
     """`stem` (a 3x3x3 stride-1 BasicConv with 2C input channels) applied to cat(att * left broadcast over the
     candidates, right_vol) WITHOUT building the left half of that volume or convolving it: by linearity its
@@ -543,4 +581,4 @@ ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launc
 
 #: the names tests / tools may SET on this module; `modules.X` forwards reads of them here
 SWITCHES = ("CONV_ENGINE", "DECONV_F16", "DECONV_MIN_WORKGROUPS", "DECONV_BF16S", "CLASSIFIER_CL", "TRAIN_HIP", "ATTENTION_FORM",
-            "STEM_LEFT_FUSED", "STEM_PRESPLIT", "HEAD_F16", "CONV2D_HIP")
+            "STEM_LEFT_FUSED", "STEM_PRESPLIT", "STEM_GATHER", "HEAD_F16", "CONV2D_HIP")

@@ -33,7 +33,7 @@ from .engine import (PATH_COUNTS, _cache, _conv_geometry, _inference, _is_plain_
                      conv3d_pointwise_bf16s_hip, deconv3d_bf16s_hip, deconv3d_hip, fold_bn, pack_conv2d_weight_bf16s,
                      pack_conv_weight, pack_conv_weight_bf16s, pack_deconv_weight_bf16s, pack_head_weight_bf16s,
                      pack_pointwise_weight_bf16s, run_conv2d, run_convbn, stem_broadcast_half, stem_of_broadcast_and_volume,
-                     stem_presplit_applies, stem_volume_half, stem_volume_half_presplit, _aux_nterms, _deconv_nterms,
+                     stem_gather_applies, stem_gather_half, stem_presplit_applies, stem_volume_half, stem_volume_half_presplit, _aux_nterms, _deconv_nterms,
                      _head_nterms, _tiled_nterms)
 from .train_layers import (_conv_k3_forward, _deconv_k3_forward, conv3d_train, conv3d_wgrad_hip, deconv3d_train)  # noqa: F401
 

@@ -281,12 +281,16 @@ def test_hot_segment_full_size_vs_reference_checksums(sa, golden, name):
     # within 1e-3 px at BOTH sizes and the mean far inside it.  (Until r04 the bound was 3e-3 at D4 = 96 and the measured worst
     # pixel 1.6e-3: that was the warp kernels' contracted coordinate arithmetic, not the soft-argmax's conditioning -- with it
     # fixed the default engine measures 1.1e-4 / 1.9e-4 at 1024^2 / 2048^2.)
+    # (r05: the gathered stem computes the warped half EXACTLY where the reference's F.grid_sample carries its coordinate rounding,
+    # so the distance to the reference is now the reference's own distance from the exact answer -- 3.3e-4 / 8.0e-4 px on its worst
+    # pixel at the two sizes, tests/golden/make_golden.py -- and the bound against it is the north star's 1e-3.)
     default_engine = sa.modules.CONV_ENGINE == "f16x3"
-    bound = 5e-4 if default_engine else 1e-3
+    gathered = default_engine and sa.engine.STEM_GATHER
+    bound = 1e-3 if (gathered or not default_engine) else 5e-4
     bad = (err > bound) & clean
     assert not bool(bad.any()), (f"pred off by up to {float(err[bad].max()):.2e} px on {int(bad.sum())} pixel(s) with no tie in the "
                                  f"reference's costs and no differing candidate set within {RF_RADIUS} px")
-    assert float(err[clean].mean()) <= (3e-5 if default_engine else 1e-4) and float(err.median()) <= 1e-4
+    assert float(err[clean].mean()) <= ((4e-5 if gathered else 3e-5) if default_engine else 1e-4) and float(err.median()) <= 1e-4
 
 
 @pytest.mark.parametrize("name", sorted(cases.SEGMENT_FULL))
@@ -328,8 +332,16 @@ def test_hot_segment_full_size_strict_on_the_reference_picks(sa, golden, name):
     # pixel; r03: 3x / 1.9x).  Bounds: worst pixel <= 1.25x the reference's, mean <= 1.3x, and against the REFERENCE itself every
     # pixel off its own cost ties within 5e-4 px at both sizes (r03: max(1e-3, 3 r) = 2.4e-3 at 2048^2; measured 7.6e-5 / 1.6e-4).
     # The other engines (single accumulation chains everywhere) keep r03's bounds.
-    bound_truth = 1.25 * ref_self if default_engine else max(1e-3, 2.0 * ref_self)
-    bound = 5e-4 if default_engine else max(1e-3, 3.0 * ref_self)
+    # Round 5: concat_stem gathers the warped half inside its staging (ss_conv3d_gather_fwd) -- for the integer
+    # candidates of the live call that IS the exact value of the bilinear sample, where the reference's F.grid_sample (and r04's
+    # operation-by-operation restatement of it) carries the coordinate round trip's error on a quarter of the columns and rows.
+    # Measured: the HIP path is now 0.42x / 0.29x the reference's own mean distance from the float64 truth at 1024^2 / 2048^2 and
+    # 0.21x / 0.19x on the worst pixel; the distance between the two fp32 evaluations is then the REFERENCE's own error
+    # (3.4e-4 / 8.0e-4 px worst pixel against its 3.3e-4 / 8.0e-4 from the truth).  Bounds with the gathered stem: worst pixel and
+    # mean vs truth <= 0.6x the reference's, every pixel off the reference's cost ties within min(1e-3, 1.25 r) px of it.
+    gathered = default_engine and sa.engine.STEM_GATHER
+    bound_truth = (0.6 if gathered else 1.25) * ref_self if default_engine else max(1e-3, 2.0 * ref_self)
+    bound = (min(1e-3, 1.25 * ref_self) if gathered else 5e-4) if default_engine else max(1e-3, 3.0 * ref_self)
     rep["bound_px"], rep["bound_vs_truth_px"] = bound, bound_truth
     rep["mean_ratio_to_reference"] = rep["hip_vs_truth_epe_off_ties_px"] / ref_mean
     rep["max_ratio_to_reference"] = rep["hip_vs_truth_max_off_ties_px"] / ref_self
@@ -341,7 +353,7 @@ def test_hot_segment_full_size_strict_on_the_reference_picks(sa, golden, name):
     assert bound <= 3e-3, rep
     assert rep["max_err_off_ties_px"] <= bound, rep                         # EVERY pixel away from the reference's own cost ties
     assert rep["hip_vs_truth_max_off_ties_px"] <= bound_truth, rep
-    assert rep["hip_vs_truth_epe_off_ties_px"] <= (1.3 * ref_mean if default_engine else max(1e-4, 4.0 * ref_mean)), rep
+    assert rep["hip_vs_truth_epe_off_ties_px"] <= ((0.6 if gathered else 1.3) * ref_mean if default_engine else max(1e-4, 4.0 * ref_mean)), rep
     assert rep["epe_vs_reference_off_ties_px"] <= (1.5 * ref_mean if default_engine else max(1e-4, 5.0 * ref_mean)) and rep["median_abs_err_px"] <= 1e-4, rep
     if 2 * (maxdisp // 4) <= 64 or default_engine:
         # whole map INCLUDING the reference's own cost ties (where a top-2 flip moves a pixel by whole candidates), full-resolution

@@ -616,6 +616,72 @@ def test_stem_on_the_presplit_warped_half(sa, shape, gated):
     assert e_pre <= max(2.0 * e_f32 + 1e-6, 8e-6), (e_pre, e_f32)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 24, 9, 37), (1, 32, 6, 5, 70), (1, 32, 32, 3, 3), (1, 32, 24, 40, 96), (1, 32, 6, 13, 65),
+                                   (1, 32, 24, 96, 128),      # >= 512 four-row tiles: the 4 x 4 x 4 tile, single chain (the bench's form)
+                                   (2, 32, 24, 64, 96),       # ... the same tile on a layer that is "small" per pair: chunk-blocked
+                                   (1, 16, 6, 160, 160),      # 2 x 8 tile (depth not a multiple of 4), two chunks per tile
+                                   (1, 32, 24, 17, 300)])     # columns pushed far outside the image on both sides
+@pytest.mark.parametrize("gated", [True, False])
+def test_stem_gathers_the_warped_half_in_its_staging(sa, shape, gated):
+    """SURVEY.md section 8 f1, second half (models/SemStereo.py:241-244, 316-320): ss_conv3d_gather_fwd forms
+    att * warp(right, integer candidates) while the conv stages its tiles -- one launch, no volume.  Against (a) the
+    float64 convolution of the EXACT gather (which is what grid_sample computes for integer candidates in exact arithmetic):
+    as close as the three-launch form (warp kernel -> volume -> conv) is to ITS float64 convolution; (b) the three-launch
+    form itself: equal up to the reference's coordinate rounding in the warp (<= 1e-5 relative on a quarter of the columns
+    / rows, see include/semstereo_hip.h) -- bounded here at 2e-4 absolute on O(1) outputs."""
+    if sa.modules.CONV_ENGINE != "f16x3":
+        pytest.skip("the gathered stem exists for the f16x3 engine")
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, C, nd, H, W = shape
+    cl, cr = dd.t_normalish((B, C, H, W), 331), dd.t_normalish((B, C, H, W), 332) * 3.0
+    samples = dd.distinct_sorted_candidates(B, nd, H, W, max(nd, min(W // 2, 48)), 333)
+    assert bool((samples == samples.round()).all())
+    att = dd.t_uniform((B, 1, nd, H, W), 334, 0.0, 0.7)
+    gate = torch.sigmoid(dd.t_normalish((B, C, H, W), 335)) if gated else None
+    stem = sa.modules.BasicConv(2 * C, C, is_3d=True, kernel_size=3, stride=1, padding=1)
+    with torch.no_grad():
+        stem.conv.weight.copy_(dd.t_uniform((C, 2 * C, 3, 3, 3), 336, -1, 1) * (3.0 / (2 * C * 27)) ** 0.5)
+        stem.bn.weight.copy_(dd.t_uniform((C,), 337, 0.6, 1.4)); stem.bn.bias.copy_(dd.t_uniform((C,), 338, -0.1, 0.1))
+        stem.bn.running_mean.copy_(dd.t_uniform((C,), 339, -0.1, 0.1)); stem.bn.running_var.copy_(dd.t_uniform((C,), 340, 0.6, 1.4))
+    stem = stem.cuda().eval()
+    g = None if gate is None else dev(gate)
+    with torch.no_grad():
+        assert sa.modules.stem_gather_applies(stem, dev(cr), dev(samples)) and sa.ops.integer_candidates(dev(samples))
+        # (the broadcast half's projection kernel is written for the model's 32 channels: the 16-channel case continues a stand-in)
+        partial = sa.modules.stem_broadcast_half(stem, dev(cl), dev(att)) if C == 32 else dev(dd.t_normalish((B, C, nd, H, W), 341))
+        y_g = sa.modules.stem_gather_half(stem, dev(cr), dev(samples), dev(att), partial, g)
+        right = sa.ops.concat_volume_sampled(None, dev(cr), dev(samples), dev(att))
+        y_3 = sa.modules.stem_volume_half(stem, right, partial, g)
+        y_g0 = sa.modules.stem_gather_half(stem, dev(cr), dev(samples), dev(att), None, g)      # no partial sum
+        y_30 = sa.modules.conv3d_bf16s_hip(right, sa.engine._stem_halves_params(stem, C)[2], C, *sa.modules.fold_bn(stem.bn), True, 19, None, g)
+    assert y_g.shape == y_3.shape == (B, C, nd, H, W)
+    # exact gather in float64
+    idx = torch.arange(W).reshape(1, 1, 1, W) - samples.long()                               # [B,nd,H,W]
+    ok = (idx >= 0) & (idx < W)
+    gathered = torch.gather(cr.unsqueeze(2).expand(B, C, nd, H, W), 4, idx.clamp(0, W - 1).unsqueeze(1).expand(B, C, nd, H, W))
+    xg = (att * (gathered * ok.unsqueeze(1))).float()                                        # the reference's fp32 product (:318)
+    sc, sh = sa.modules.fold_bn(stem.bn)
+    w64 = stem.conv.weight.detach().cpu().double()
+
+    def finish(acc):
+        r = F.relu(acc * sc.cpu().double().reshape(1, -1, 1, 1, 1) + sh.cpu().double().reshape(1, -1, 1, 1, 1))
+        return r if gate is None else gate.double().unsqueeze(2) * r
+    left64 = F.conv3d((att * cl.unsqueeze(2)).float().double(), w64[:, :C], None, 1, 1) if C == 32 else partial.double().cpu()
+    ref_g = finish(left64 + F.conv3d(xg.double(), w64[:, C:], None, 1, 1))
+    ref_3 = finish(left64 + F.conv3d(right.cpu().double(), w64[:, C:], None, 1, 1))
+    e_g, e_3 = float((y_g.double().cpu() - ref_g).abs().max()), float((y_3.double().cpu() - ref_3).abs().max())
+    REPORT[f"stem_gather/{shape}/{gated}"] = e_g
+    REPORT[f"stem_gather_three_launch/{shape}/{gated}"] = e_3
+    assert e_g <= max(2.0 * e_3 + 1e-6, 8e-6), (e_g, e_3)
+    ref_g0 = finish(F.conv3d(xg.double(), w64[:, C:], None, 1, 1))
+    assert float((y_g0.double().cpu() - ref_g0).abs().max()) <= max(2.0 * e_3 + 1e-6, 8e-6)
+    d = float((y_g - y_3).abs().max())
+    REPORT[f"stem_gather_vs_three_launch/{shape}/{gated}"] = d
+    assert d <= 2e-4, d
+    assert float((y_g0 - y_30).abs().max()) <= 2e-4
+
+
 HEAD_CASES = [
     # (B, Cin, D, H, W, relu): the 32 -> 1 classifier heads; W not a multiple of 30, both tile shapes, tiny volumes
     (2, 32, 5, 9, 37, False),
@@ -819,7 +885,8 @@ _NON_DEFAULT = {
     "SS_GWC_PATCH_FUSED=0": ("segment.HotSegment", "GWC_PATCH_FUSED", False),
     "SS_STEM_HALVES=0": ("segment.HotSegment", "STEM_BY_HALVES", False),
     "SS_STEM_LEFT_FUSED=0": ("engine", "STEM_LEFT_FUSED", False),
-    "SS_STEM_PRESPLIT=1": ("engine", "STEM_PRESPLIT", True),
+    "SS_STEM_PRESPLIT=1": ("engine", "STEM_PRESPLIT", True),      # (with the gathered stem off: it has precedence)
+    "SS_STEM_GATHER=0": ("engine", "STEM_GATHER", False),
     "SS_ATTENTION=fused": ("engine", "ATTENTION_FORM", "fused"),
     "SS_HEAD_F16=1": ("engine", "HEAD_F16", True),
     "SS_DECONV_F16=0": ("engine", "DECONV_F16", False),
@@ -839,6 +906,8 @@ def test_hot_segment_under_every_non_default_switch(sa, golden, setting, monkeyp
     for part in path.split("."):
         obj = getattr(obj, part)
     monkeypatch.setattr(obj, attr, value)
+    if setting == "SS_STEM_PRESPLIT=1":
+        monkeypatch.setattr(sa.engine, "STEM_GATHER", False)
     name = "s128"
     seg, P = _segment(sa, cases.SEGMENT[name][3])
     fl4, fr4, fl8, fr8, maxdisp = cases.segment_inputs(name)
