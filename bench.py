@@ -633,6 +633,8 @@ def main():
             E.conv3d_bf16s_hip = lambda *a, **k: (timed if (k.get("gate") is not None or (len(a) > 8 and a[8] is not None))
                                                   else plain)(*a, **k)
             M.stem_volume_half_presplit = timer.wrap("concat_stem_presplit", M.stem_volume_half_presplit)
+            # r05: the gathered form -- warp + x att + conv + BN + ReLU + gate in ONE launch (ss_conv3d_gather_fwd)
+            M.stem_gather_half = timer.wrap("concat_stem_gather", M.stem_gather_half)
         # the cost-volume kernel of the step: build_gwc_volume_norm fused with `patch` and the channelAtt gate
         # (models/SemStereo.py:273-276, ss_gwc_patch_gate_fwd); the volume kernel alone when that fusion is off
         semstereo_amd.segment.ops.build_gwc_volume_norm = timer.wrap("gwc", semstereo_amd.ops.build_gwc_volume_norm)
@@ -801,7 +803,9 @@ def main():
     detail = {"argv": sys.argv[1:], "weights": "random init at unit gain (init_unit_gain), BatchNorm eval",
               "pairs_per_s_by_conv_engine": by_engine, "pairs_per_s_reference_forward_untouched": unfused_rate,
               "pairs_per_s_reference_forward_untouched_no_deferral": opbyop_rate, "deferred_rules_fired_per_run": fired}
-    ms, presplit = timer.mean_ms("concat_stem"), False
+    ms, presplit, gathered = timer.mean_ms("concat_stem_gather"), False, True
+    if not ms:
+        ms, presplit, gathered = timer.mean_ms("concat_stem"), False, False
     if not ms:
         ms, presplit = timer.mean_ms("concat_stem_presplit"), True
     if ms:
@@ -819,16 +823,19 @@ def main():
             typ = "fp16" if engine == "f16x3" else "bf16"
             ex = nterms * eq                                   # 16-bit MFMA flops actually issued per second
             sym = ("conv3d_pre<true>" if presplit else
-                   f"conv3d_bf16s<1,4,4,4,{code},true,1,3>" if k % 4 == 0 else f"conv3d_bf16s<1,4,2,8,{code},true,1,3>")
-            line["roofline"] = {"kernel": f"{sym}: concat_stem {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]" + (" (warped half) + partial sum" if halves else "")
-                                          + " + BN + ReLU + gate",
+                   f"conv3d_bf16s<1,4,4,4,{code},true,1,3" if k % 4 == 0 else f"conv3d_bf16s<1,4,2,8,{code},true,1,3")
+            if not presplit:
+                sym += ",1,false,true>" if gathered else ">"
+            what = (" (warped half GATHERED from the 2-D right map inside the staging: warp + x att + conv) + partial sum" if gathered
+                    else " (warped half) + partial sum" if halves else "")
+            line["roofline"] = {"kernel": f"{sym}: concat_stem {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]" + what + " + BN + ReLU + gate",
                                 "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ex / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
                                 "algorithmic_flop_per_launch": nterms * flops, "fp32_equivalent_tflops": eq,
                                 "frac_of_best_gemm_on_random_data": ex / 1247.0,
                                 "note": f"{nterms} {typ} products per fp32 product; timed on one stream (single_stream leg)"}
             if (H, W, maxdisp, engine) == (1024, 1024, 128, "f16x3") and halves and not presplit:
-                tb, tnote, mult = pmc_traffic("stem_b1")
+                tb, tnote, mult = pmc_traffic("stem_gather_b1" if gathered else "stem_b1")
                 line["roofline"].update({"traffic": None if tb is None else tb * B, "fetch_size_multiplier": mult, "traffic_note": tnote})
     if not args.no_side_rooflines:
         side = {}

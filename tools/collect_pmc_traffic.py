@@ -12,7 +12,7 @@ import sys
 # for other widths.  Kernels whose loads are 4 or 8 bytes per lane are taken at x1: calibrated on the stem conv, whose x2 figure
 # (847 MB of activation reads) would exceed what its halo geometry can re-read at all (6x6x34 positions per 4x4x32 outputs =
 # 2.39 x 201 MB = 481 MB), while the x1 figure (319 MB = 1.6x) sits inside it.
-NARROW_LOADS = {"stem", "warp", "strength", "stem_left", "conv_s1", "conv_s2", "conv_mid", "conv_low"}
+NARROW_LOADS = {"stem", "stem_gather", "stem_gather_smooth", "warp", "strength", "stem_left", "conv_s1", "conv_s2", "conv_mid", "conv_low"}
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

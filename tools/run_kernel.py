@@ -2,7 +2,7 @@
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
 usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low conv_mid_att conv_low_att attn attn_att warp ssr ssr2048 strength topk
-                                                               catt8 catt4 upsoft stem_left stem conv_s1 conv_s2 conv_s2_att deconv"""
+                                                               catt8 catt4 upsoft stem_left stem stem_gather stem_gather_smooth conv_s1 conv_s2 conv_s2_att deconv"""
 import os
 import sys
 import time
@@ -115,6 +115,19 @@ elif name == "stem":             # the dominant launch: concat_stem on the warpe
     sc, sh = torch.rand(32, device=dev) + 0.5, R(32) * 0.1
     fn = lambda: M.conv3d_bf16s_hip(x, ws, 32, sc, sh, True, 19, None, gate, partial=part)       # noqa: E731
     nbytes = 4.0 * B * (3 * 32 * 24 + 32) * 256 * 256
+elif name in ("stem_gather", "stem_gather_smooth"):     # r05: the same launch with the warped half gathered inside its staging (ss_conv3d_gather_fwd)
+    stem = M.BasicConv(64, 32, is_3d=True, kernel_size=3, stride=1, padding=1).to(dev).eval()
+    cr = R(B, 32, 256, 256)
+    if name == "stem_gather":        # 24 of 64 disparities drawn independently per pixel: the least coherent gather
+        smp = torch.rand(B, 64, 256, 256, device=dev).argsort(dim=1)[:, :24].sort(dim=1).values.float() - 32.0
+    else:                            # a window of 24 around a smooth disparity field: the most coherent one
+        yy, xx = torch.meshgrid(torch.arange(256, device=dev), torch.arange(256, device=dev), indexing="ij")
+        centre = (12.0 * torch.sin(xx / 40.0) * torch.cos(yy / 55.0)).round()
+        smp = (centre.reshape(1, 1, 256, 256) + torch.arange(-12, 12, device=dev).reshape(1, 24, 1, 1)).expand(B, 24, 256, 256).contiguous().float()
+    att = torch.rand(B, 1, 24, 256, 256, device=dev)
+    part, gate = R(B, 32, 24, 256, 256), torch.rand(B, 32, 256, 256, device=dev)
+    fn = lambda: M.stem_gather_half(stem, cr, smp, att, part, gate)           # noqa: E731
+    nbytes = 4.0 * B * (32 + 24 + 24 + 2 * 32 * 24 + 32) * 256 * 256
 elif name == "conv_s2_att":      # hourglass_att.conv3: 64 -> 128 stride 2 on [16,64,64] (256 workgroups: the one-tile-per-wave form)
     x = torch.relu(R(B, 64, 16, 64, 64))
     ws = M.pack_conv_weight_bf16s(R(128, 64, 3, 3, 3) * 0.03, 19)
