@@ -26,6 +26,9 @@ ss::Tuning read_tuning() {
     t.warp_vec4 = env_int("SS_WARP_VEC") == 4 ? 1 : 0;
     t.warp_generic = env_int("SS_WARP_GENERIC");
     t.deconv_split = env_int("SS_DECONV_SPLIT");
+    t.deconv_groups = env_int("SS_DECONV_GROUPS");
+    if (t.deconv_groups > 2) t.deconv_groups = -1;
+    t.deconv_stream = env_int("SS_DECONV_STREAM");
     return t;
 }
 

@@ -34,6 +34,8 @@ struct Tuning {
     int warp_vec4;        // SS_WARP_VEC=4
     int warp_generic;     // SS_WARP_GENERIC set: the generic warp kernel for the live form too
     int deconv_split;     // SS_DECONV_SPLIT 0/1: even/odd-plane split of the exact-fp32 transposed conv
+    int deconv_groups;    // SS_DECONV_GROUPS (fp16 transposed convs): 0 = all 8 parity classes per workgroup, 1 = two class groups, 2 = + chunk-blocked accumulation; unset: by layer size
+    int deconv_stream;    // SS_DECONV_STREAM 0/1: plain / nontemporal stores of the fp16 transposed convs' output; unset: by output size
 };
 const Tuning& tuning();
 

@@ -13,6 +13,7 @@
 // slices over the K-steps.  The skip projection (redir) is two more K-steps per 16 skip channels with the operand
 // read straight from global memory (each lane's 2x2x2 output cube as four float2 per channel) and split in registers.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "split_f16.h"
@@ -52,30 +53,81 @@ __host__ __device__ constexpr int off_of(int s) {
 }
 
 constexpr int KST = 27;           // K-steps per 16-channel chunk
+// STREAM (template argument of the kernel): the output goes out with NONTEMPORAL stores (buffer aux 2).  Measured r05 on
+// hourglass2.conv6 (201 MB written, alone): 128 -> 108 us; sc0 + nt the same; nontemporal loads of the skip tensor 119, both 124
+// (profiles/r05_f_deconv_forms.txt).  The launcher streams outputs of >= 192 MB per launch (the rule of the gwc volume kernel:
+// smaller outputs are handed to the next kernel by the 256 MB Infinity Cache); SS_DECONV_STREAM=0/1 forces it.
+#ifndef SS_DECONV_SKIP_AUX
+#define SS_DECONV_SKIP_AUX 0      // ... of the skip tensor's loads
+#endif
 
-template <int TD, int TH, int LT = 3, bool WLDS = false>      // LT: operand terms kept in LDS; WLDS: + a chunk's weights
+// ---- parity-class groups (r05) ----
+// GRP < 0: a workgroup computes all 8 parity classes of its tile (8 accumulators = 128 registers per wave: two waves per SIMD).
+// GRP = 0 / 1: the classes are split over TWO workgroups per tile -- {0,1,6,7} (15 taps) and {2,3,4,5} (12 taps): each group's
+// output cube I/O is two whole (plane, row) pairs of float2 -- so a wave keeps 4 accumulators, the chunk's weight slab in LDS
+// is the group's taps only (30 / 24 KB instead of 55), and a CU holds three workgroups instead of two; the freed registers
+// also hold the second accumulator set of the chunk-blocked summation (ACCB, see conv3d_bf16s.hip).  Both workgroups stage
+// the same input tile (it is read twice from L2: 50 MB of the layer's 453 MB), everything else is disjoint.
+struct GrpTable { int ns; int step[KST]; int next_off[KST]; };
+constexpr bool grp_has(int grp, int cls) { return grp < 0 || (grp == 0 ? (cls < 2 || cls >= 6) : (cls >= 2 && cls < 6)); }
+constexpr GrpTable make_grp_table(int grp) {
+    GrpTable t{};
+    for (int s = 0; s < KST; ++s)
+        if (grp_has(grp, cls_of(s))) t.step[t.ns++] = s;
+    for (int k = t.ns; k < KST; ++k) t.step[k] = KST - 1;
+    // the input offset of the next RUN of equal offsets after position k of the group's step list (-1: none)
+    for (int k = 0; k < KST; ++k) {
+        t.next_off[k] = -1;
+        for (int j = k + 1; j < t.ns; ++j)
+            if (off_of(t.step[j]) != off_of(t.step[k])) { t.next_off[k] = off_of(t.step[j]); break; }
+    }
+    return t;
+}
+template <int GRP>
+struct Grp {
+    static constexpr int NA = GRP < 0 ? 8 : 4;                  // accumulators per wave
+    static constexpr int NQ2 = GRP < 0 ? 4 : 2;                 // (pd, ph) rows of the output cube
+    static constexpr int idx(int cls) { return GRP < 0 ? cls : (GRP == 0 ? (cls < 2 ? cls : cls - 4) : cls - 2); }
+    static constexpr int q(int j) { return GRP < 0 ? j : (GRP == 0 ? (j == 0 ? 0 : 3) : (j == 0 ? 1 : 2)); }      // pd * 2 + ph of row j
+    static constexpr GrpTable T = make_grp_table(GRP);
+    static constexpr int NS = T.ns;                             // 27 / 15 / 12
+};
+// the groups' K-steps as a run-time table (the LDS-DMA of the weight slab picks its steps by a wave-dependent index)
+struct GroupSteps { int s[2][16]; };
+constexpr GroupSteps make_group_steps() {
+    GroupSteps t{};
+    for (int k = 0; k < 16; ++k) { t.s[0][k] = Grp<0>::T.step[k]; t.s[1][k] = Grp<1>::T.step[k]; }
+    return t;
+}
+__device__ const GroupSteps kGroupSteps = make_group_steps();
+
+template <int TD, int TH, int LT = 3, bool WLDS = false, int WSTEPS = 27>      // LT: operand terms kept in LDS; WLDS: + WSTEPS K-steps of a chunk's weights
 struct DB {
     static constexpr int ID = TD + 1, IH = TH + 1, IW = 33;
     static constexpr int CS = ID * IH * IW;                    // positions of the halo tile
     static constexpr int NPOS = (CS + 255) / 256;              // positions per thread
     // + the four waves' maxima (fp16 form) + the per-channel epilogue constants of the workgroup's 32 channels
-    static constexpr int WSLOTS = WLDS ? 27 * 2 * 64 : 0;      // [27 K-steps][2 terms][2 halves x 32 channels] 16-byte slots
+    static constexpr int WSLOTS = WLDS ? WSTEPS * 2 * 64 : 0;  // [K-steps][2 terms][2 halves x 32 channels] 16-byte slots
     static constexpr size_t LDS_BYTES = (size_t)(LT * 2 * CS + 1 + 16 + WSLOTS) * 16;
     static_assert(TD * TH == 4, "4 waves x one input row each");
 };
 
-template <int TD, int TH, int NTERMS, bool HAS_SKIP>
-__global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
+// SPLIT: two workgroups per tile, one per parity-class group (blockIdx.x = 2 * tile + group; fp16 form only); ACCB: chunk-blocked
+// accumulation (fp16 form, SPLIT only: it lives in the registers the split frees)
+template <int TD, int TH, int NTERMS, bool HAS_SKIP, bool SPLIT = false, bool ACCB = false, bool STREAM = false>
+__global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                           const float* __restrict__ shift, const float* __restrict__ skip,
                                                           const uint4* __restrict__ skip_wsplit, float* __restrict__ out,
                                                           int Cin, int D, int H, int W, int Cout, int Cs, int tiles_w,
-                                                          int tiles_h, int relu) {
+                                                          int tiles_h, int relu, int nunits) {
+    static_assert(!SPLIT || NTERMS == F16X3, "the class-group split exists for the fp16 form (weights through LDS)");
+    static_assert(!ACCB || SPLIT, "chunk-blocked accumulation: in the registers the split frees");
     // NTERMS = 19 (F16X3): the main loop on two fp16 terms with block-floating operands (split_f16.h; the scheme of
     // conv3d_bf16s.hip); the skip projection, whose operand never passes through LDS, stays on three bf16 terms
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;
     constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed main weights
-    using C = DB<TD, TH, NC, F16>;
+    using C = DB<TD, TH, NC, F16, SPLIT ? 15 : 27>;
     constexpr int MSLOT = NC * 2 * C::CS;                      // LDS slot of the waves' maxima
     // fp16 form: the chunk's weight fragments (27 K-steps x 2 terms, 55 KB) are brought into LDS once per workgroup by
     // LDS-DMA loads (buffer_load_dwordx4 ... lds: no registers) instead of being fetched by each of the four waves: a K-step
@@ -85,38 +137,39 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [NC terms][2 channel halves][CS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    int t = blockIdx.x;
-    const int tw = t % tiles_w; t /= tiles_w;
-    const int th = t % tiles_h; t /= tiles_h;
-    const int iw0 = tw * 32, ih0 = th * TH, id0 = t * TD;
+    // a workgroup's unit of work: a tile (SPLIT: a tile and one of its two class groups, unit = 2 * tile + group)
+    int iw0 = 0, ih0 = 0, id0 = 0, grp = -1;                    // origin (and SPLIT: class group, wave-uniform) of the current unit
+    auto unit_origin = [&](int u, int& w0, int& h0, int& d0) {
+        int t = SPLIT ? (u >> 1) : u;
+        const int tw = t % tiles_w; t /= tiles_w;
+        const int th = t % tiles_h; t /= tiles_h;
+        w0 = tw * 32; h0 = th * TH; d0 = t * TD;
+    };
     const int co0 = blockIdx.y * 32;
     const int b = blockIdx.z;
     const int dzw = wave / TH, hyw = wave % TH;
     const int lane_pos = (dzw * C::IH + hyw) * C::IW + l31;        // this lane's position, offset (0,0,0)
-
-    f32x16 acc[8];                        // index pd*4 + ph*2 + pw
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     const size_t in_plane = (size_t)H * W, chan = (size_t)D * in_plane;
     const float* inb = in + (size_t)b * Cin * chan;
 
     // staging plan: this thread owns positions p = tid + 256*i of the halo tile, all 16 channels of the chunk
     unsigned poff[C::NPOS];
+    auto make_poff = [&](int u) {                                  // (a unit that does not exist: every position beyond the buffer)
+        int w0, h0, d0;
+        unit_origin(u, w0, h0, d0);
 #pragma unroll
-    for (int i = 0; i < C::NPOS; ++i) {
-        const int p = tid + 256 * i;
-        const int wx = p % C::IW;
-        int r = p / C::IW;
-        const int hy = r % C::IH, dz = r / C::IH;
-        const int gw = iw0 + wx, gh = ih0 + hy, gd = id0 + dz;
-        const bool ok = (p < C::CS) && gd < D && gh < H && gw < W;
-        poff[i] = ok ? (unsigned)(((size_t)gd * in_plane + (size_t)gh * W + gw) * 4) : 0x80000000u;     // beyond the buffer: reads 0
-    }
+        for (int i = 0; i < C::NPOS; ++i) {
+            const int p = tid + 256 * i;
+            const int wx = p % C::IW;
+            int r = p / C::IW;
+            const int hy = r % C::IH, dz = r / C::IH;
+            const int gw = w0 + wx, gh = h0 + hy, gd = d0 + dz;
+            const bool ok = (p < C::CS) && gd < D && gh < H && gw < W && u < nunits;
+            poff[i] = ok ? (unsigned)(((size_t)gd * in_plane + (size_t)gh * W + gw) * 4) : 0x80000000u;     // beyond the buffer: reads 0
+        }
+    };
     constexpr int NQ = 16 * C::NPOS;
-    constexpr int QS = (NQ + 19) / 20;                         // the next chunk's loads are issued over the first 20 K-steps
     float rin[NQ];
 
     const int nchunks = (Cin + 15) / 16;
@@ -140,15 +193,8 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     auto load_in_masked = [&](int ch, int i, unsigned mask) {          // mask 0x80000000: beyond the buffer, reads 0
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(poff[i] | mask), min(ch, Cin - 1) * chan_b, 0));
     };
-    uint4 aq[3][NC];                      // aq[g % 3]
-    if (!F16) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) aq[k][c] = load_a(min(k, G - 1), c);
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) rin[q] = load_in(q / C::NPOS, q % C::NPOS);
+    constexpr int AQ = F16 ? 2 : 3;       // fragment ring: fp16 form (from LDS) one step ahead, bf16 forms (from L2) two
+    uint4 aq[AQ][NC];                     // aq[step % AQ]
 
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const size_t out_plane = (size_t)Ho * Wo;
@@ -165,7 +211,38 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     // HBM (measured on the last layer of hourglass2: 173 us of main loop + 61 us of skip reads + 29 us of stores = the
     // 263 us of the whole kernel, nothing overlapped).  Same sums, deterministic per workgroup.
     constexpr int SNT = F16 ? 6 : NTERMS, SNC = (SNT == 6) ? 3 : 2;      // cross products / terms of the skip projection
+    // ---- everything from here on is written once for a compile-time class group (Grp<GRP>) and instantiated for the one(s) this
+    // kernel serves; `acc[j * 2 + pw]` holds class Grp::q(j) * 2 + pw ----
+    auto body = [&](auto grp_tag, const int unit) {
+    constexpr int GRP = decltype(grp_tag)::value;
+    using GP = Grp<GRP>;
+    constexpr int NA = GP::NA, NS = GP::NS;
+    // XPF: the next unit's first chunk prefetched under this unit's last chunk (as conv3d_bf16s does).  Off: the prefetched
+    // registers would stay live through the skip projection and the epilogue beside all accumulators (73 spilled registers
+    // measured at the 256 of two workgroups per CU); the next unit's first loads are issued at its top instead, while this
+    // unit's stores drain.
+    constexpr bool XPF = false;
+    const bool has_next = XPF && unit + (int)gridDim.x < nunits;
+    if (!XPF) {
+        make_poff(unit);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rin[q] = load_in(q / C::NPOS, q % C::NPOS);
+    }
+    if (!F16) {                           // bf16 forms: the first two K-steps' weight fragments of this unit
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) aq[k][c] = load_a(min(k, G - 1), c);
+    }
+    f32x16 acc[NA];
+#pragma unroll
+    for (int p = 0; p < NA; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     auto skip_phase = [&]() {
+#ifdef SS_EXP_DECONV_NOSKIP           // (timing experiment, wrong results)
+        return;
+#endif
         // ---- 1x1x1 projection of the skip tensor at the 8 output positions of every lane: per 16 skip channels one K-step
         // per parity class; the operand (8 channels x this lane's 2x2x2 cube) comes straight from global memory ----
         const size_t schan = (size_t)Do * out_plane;
@@ -187,16 +264,16 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             // channels (interleaved by the compiler, each of the four (pd, ph) groups waited for its own 8 loads: four)
             // (r03: in TWO batches of 16 -- all 32 at once left the kernel 2 VGPRs short: 12 bytes of scratch per lane)
 #pragma unroll
-            for (int q0 = 0; q0 < 4; q0 += 2) {
-            float2 v[4][8];
+            for (int q0 = 0; q0 < GP::NQ2; q0 += 2) {
+            float2 v[GP::NQ2][8];
 #pragma unroll
-            for (int q = q0; q < q0 + 2; ++q) {            // (pd, ph); the float2 holds pw = 0, 1
-                const unsigned qo = (unsigned)(((size_t)(q >> 1) * out_plane + (size_t)(q & 1) * Wo) * 4);
+            for (int q = q0; q < q0 + 2; ++q) {            // row q of the group = (pd, ph); the float2 holds pw = 0, 1
+                const unsigned qo = (unsigned)(((size_t)(GP::q(q) >> 1) * out_plane + (size_t)(GP::q(q) & 1) * Wo) * 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int cs = ks * 16 + 8 * half + j;     // channels beyond Cs: a clamped (valid) address, value zeroed
                     v[q][j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
-                                                             sres, (int)(lane_s + qo + (unsigned)min(cs, Cs - 1) * schan_b), 0, 0));
+                                                             sres, (int)(lane_s + qo + (unsigned)min(cs, Cs - 1) * schan_b), 0, SS_DECONV_SKIP_AUX));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +307,10 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     };
 
 
-    const bool skip_first = HAS_SKIP && ((blockIdx.x ^ blockIdx.y) & 1);
+    // (SPLIT: always after the main loop -- before it the prefetched first chunk is live beside the skip operands, 92 spilled
+    // registers at the 168 of three workgroups per CU; the two class groups of a tile and the third workgroup of the CU already
+    // spread the phases)
+    const bool skip_first = !SPLIT && HAS_SKIP && ((unit ^ blockIdx.y) & 1);
     if (HAS_SKIP && skip_first) {
         skip_phase();
         if (F16) {      // the main loop's accumulators carry the channel's weight scale (a power of two: exact)
@@ -239,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
                 // (from global memory: `aff` is not visible before the first barrier)
                 const float ws = __uint_as_float((254u << 23) - __float_as_uint(wunscale[min(co0 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1)]));
 #pragma unroll
-                for (int p = 0; p < 8; ++p) acc[p][r] *= ws;
+                for (int p = 0; p < NA; ++p) acc[p][r] *= ws;
             }
         }
     }
@@ -255,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         float m0 = 0.f;
         if (HAS_SKIP && skip_first) {                          // see E_INIT_SHIFT (split_f16.h)
 #pragma unroll
-            for (int p = 0; p < 8; ++p)
+            for (int p = 0; p < NA; ++p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, fabsf(acc[p][r]));
             m0 *= __uint_as_float((unsigned)(127 - E_INIT_SHIFT) << 23);
@@ -269,10 +349,12 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         // ---- split + transpose: registers -> [term][half][position] ----
         if (F16) {          // this chunk's weights: wave w issues the (K-step, term) pairs i = w, w + 4, ...; lane -> (half, channel)
 #pragma unroll
-            for (int k = 0; k < (KST * 2 + 3) / 4; ++k) {
-                const int i = wave + 4 * k;                    // wave-uniform
-                if (i < KST * 2)
-                    lds_dma16(wres, &lds[WL + i * 64], wlane, (g0 + i / 2) * wstep + (i & 1) * 2 * Cout * 16);
+            for (int k = 0; k < (NS * 2 + 3) / 4; ++k) {
+                const int i = wave + 4 * k;                    // wave-uniform; slab entry i = (the group's step i / 2, term i & 1)
+                if (i < NS * 2) {
+                    const int sg = GRP < 0 ? i / 2 : __builtin_amdgcn_readfirstlane(kGroupSteps.s[GRP < 0 ? 0 : GRP][i / 2]);
+                    lds_dma16(wres, &lds[WL + i * 64], wlane, (g0 + sg) * wstep + (i & 1) * 2 * Cout * 16);
+                }
             }
         }
         float in_scale = 1.f;
@@ -283,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
             if (e_new != e_cur) {                              // wave-uniform; exact power-of-two rescale
                 const float ratio = __uint_as_float((unsigned)max(127 + e_cur - e_new, 0) << 23);
 #pragma unroll
-                for (int p = 0; p < 8; ++p)
+                for (int p = 0; p < NA; ++p)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[p][r] *= ratio;
                 e_cur = e_new;
@@ -310,10 +392,15 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
                 if (NC == 3) lds[(2 * 2 + hf) * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
             }
         }
+#ifndef SS_EXP_DECONV_NOWAIT      // (timing experiment, wrong results: the upper bound of what a look-ahead of the weight DMA can buy)
         if (F16) __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the LDS-DMA weight loads have landed
+#endif
         __syncthreads();
         const bool more = ck + 1 < nchunks;
-        const unsigned nomore = more ? 0u : 0x80000000u;
+        // what the K-steps prefetch: the next chunk of this unit, or (last chunk) the first chunk of the workgroup's next unit
+        if (XPF && !more) make_poff(unit + (int)gridDim.x);     // pure index arithmetic under a wave-uniform branch
+        const unsigned nomore = (more || has_next) ? 0u : 0x80000000u;
+        const int ch_next = more ? ci0 + 16 : 0;
 
         uint4 bcur[NC], bnxt[NC];
         auto read_b = [&](uint4 (&dst)[NC], int o) {
@@ -321,62 +408,80 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
 #pragma unroll
             for (int c = 0; c < NC; ++c) dst[c] = lds[(c * 2 + half) * C::CS + slot];
         };
-        read_b(bcur, 0);
+        read_b(bcur, off_of(GP::T.step[0]));
         if (F16) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) aq[0][c] = lds[WL + c * 64 + lane];
         }
+        // ACCB: the chunk's MFMAs accumulate from ZERO in a second register set that joins `acc` once per chunk (two-level
+        // blocked summation, as the CPU GEMMs the reference runs on: conv3d_bf16s.hip has the measurements)
+        f32x16 tacc[ACCB ? NA : 1];
+        if constexpr (ACCB) {
 #pragma unroll
-        for (int s = 0; s < KST; ++s) {
+            for (int p = 0; p < NA; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tacc[p][r] = 0.f;
+        }
+        constexpr int QSG = (NQ + (NS * 20 / 27) - 1) / (NS * 20 / 27);     // the next chunk's loads: over the first ~3/4 of the steps
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int s = GP::T.step[k];                       // (compile-time after unrolling)
             // no vector-memory instruction under a branch (see conv3d_bf16s.hip: the wait-count pass falls back to vmcnt(0)
             // at control-flow merges): past the end the last fragment is requested again, the input loads go beyond the buffer
             if (!F16) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) aq[(s + 2) % 3][c] = load_a(min(g0 + s + 2, G - 1), c);
-            } else if (s + 1 < KST) {                          // next step's fragments from the LDS copy
+                for (int c = 0; c < NC; ++c) aq[(s + 2) % AQ][c] = load_a(min(g0 + s + 2, G - 1), c);
+            } else if (k + 1 < NS) {                           // next step's fragments from the LDS copy
 #pragma unroll
-                for (int c = 0; c < NC; ++c) aq[(s + 1) % 3][c] = lds[WL + ((s + 1) * 2 + c) * 64 + lane];
+                for (int c = 0; c < NC; ++c) aq[(k + 1) % AQ][c] = lds[WL + ((k + 1) * 2 + c) * 64 + lane];
             }
 #pragma unroll
-            for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q) rin[q] = load_in_masked(ci0 + 16 + q / C::NPOS, q % C::NPOS, nomore);
-            // first tap of an offset group: fetch the next group's activation fragment
-            if ((s == 0 || off_of(s) != off_of(s - 1)) && off_of(s) < 7) read_b(bnxt, off_of(s) + 1);
-            const int cls = cls_of(s);
+            for (int q = k * QSG; q < (k + 1) * QSG && q < NQ; ++q) rin[q] = load_in_masked(ch_next + q / C::NPOS, q % C::NPOS, nomore);
+            // first tap of a run of equal input offsets: fetch the next run's activation fragment
+            if ((k == 0 || off_of(s) != off_of(GP::T.step[k > 0 ? k - 1 : 0])) && GP::T.next_off[k] >= 0) read_b(bnxt, GP::T.next_off[k]);
+            const int ai = GP::idx(cls_of(s));
+            f32x16& dst = ACCB ? tacc[ACCB ? ai : 0] : acc[ai];
             if (F16) {
                 f16x8 a[NC], bq[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    a[c] = __builtin_bit_cast(f16x8, aq[s % 3][c]);
+                    a[c] = __builtin_bit_cast(f16x8, aq[k % AQ][c]);
                     bq[c] = __builtin_bit_cast(f16x8, bcur[c]);
                 }
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[1], acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bq[0], acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[0], acc[cls], 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[1], dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bq[0], dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[0], dst, 0, 0, 0);
             } else {
                 bf16x8 a[NC], bq[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    a[c] = __builtin_bit_cast(bf16x8, aq[s % 3][c]);
+                    a[c] = __builtin_bit_cast(bf16x8, aq[s % AQ][c]);
                     bq[c] = __builtin_bit_cast(bf16x8, bcur[c]);
                 }
                 if (NTERMS == 6) {
-                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], acc[cls], 0, 0, 0);
-                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[NC - 1], acc[cls], 0, 0, 0);
-                    acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NC - 1], bq[0], acc[cls], 0, 0, 0);
+                    dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], dst, 0, 0, 0);
+                    dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[NC - 1], dst, 0, 0, 0);
+                    dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NC - 1], bq[0], dst, 0, 0, 0);
                 }
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[cls], 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], dst, 0, 0, 0);
             }
-            // last tap of an offset group: the prefetched fragment becomes current
-            if (s + 1 < KST && off_of(s + 1) != off_of(s)) {
+            // last tap of a run: the prefetched fragment becomes current
+            if (k + 1 < NS && off_of(GP::T.step[k + 1 < NS ? k + 1 : k]) != off_of(s)) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) bcur[c] = bnxt[c];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (ACCB) {
+#pragma unroll
+            for (int p = 0; p < NA; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][r] += tacc[p][r];
+        }
         // steps 27, 28 of this chunk are steps 0, 1 of the next: re-base the fragment ring (27 % 3 == 0: already in place)
-        if (F16 && more) publish_max(0.f);                        // of the chunk staged next
+        if (F16 && more) publish_max(0.f);                        // of the chunk staged next (a next UNIT's first chunk: at that unit's top)
         __syncthreads();
     }
     if (F16) {          // back to plain values: 2^-(activation scale) x the channel's 2^-(weight scale), exact
@@ -385,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         for (int r = 0; r < 16; ++r) {
             const float un = au * aff[32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) acc[p][r] *= un;
+            for (int p = 0; p < NA; ++p) acc[p][r] *= un;
         }
     }
 
@@ -399,11 +504,11 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
         out + (size_t)b * Cout * Do * out_plane, 0, (int)min((long long)Cout * (long long)ochan_b, 0x7fffffffLL), 0x00020000);
     const bool ok = jw < W && jd < D && jh < H;
-    unsigned vo[4];
+    unsigned vo[GP::NQ2];
 #pragma unroll
-    for (int pdh = 0; pdh < 4; ++pdh)
-        vo[pdh] = ok ? (unsigned)((((size_t)(2 * jd + (pdh >> 1)) * Ho + 2 * jh + (pdh & 1)) * Wo + 2 * jw) * 4) + 4u * half * ochan_b
-                     : 0x80000000u;
+    for (int j = 0; j < GP::NQ2; ++j)
+        vo[j] = ok ? (unsigned)((((size_t)(2 * jd + (GP::q(j) >> 1)) * Ho + 2 * jh + (GP::q(j) & 1)) * Wo + 2 * jw) * 4) + 4u * half * ochan_b
+                   : 0x80000000u;
     const float floor_v = relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -411,12 +516,29 @@ __global__ __launch_bounds__(256, 2) void deconv3d_bf16s(const float* __restrict
         const bool cok = cb + 4 * half < Cout;
         const float sh = aff[(r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-        for (int pdh = 0; pdh < 4; ++pdh) {
-            const float v0 = fmaxf(ss::add_rn(acc[pdh * 2 + 0][r], sh), floor_v);
-            const float v1 = fmaxf(ss::add_rn(acc[pdh * 2 + 1][r], sh), floor_v);
+        for (int j = 0; j < GP::NQ2; ++j) {
+            const float v0 = fmaxf(ss::add_rn(acc[j * 2 + 0][r], sh), floor_v);
+            const float v1 = fmaxf(ss::add_rn(acc[j * 2 + 1][r], sh), floor_v);
+#ifdef SS_EXP_DECONV_NOSTORE          // (timing experiment: one store per lane instead of 64)
+            if (r == 0 && j == 0)
+#endif
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ss_u32x2, make_float2(v0, v1)), ores,
-                                                  (int)(cok ? vo[pdh] : 0x80000000u), cb * (int)ochan_b, 0);
+                                                  (int)(cok ? vo[j] : 0x80000000u), cb * (int)ochan_b, STREAM ? 2 : 0);
         }
+    }
+    };      // body
+    // ONE unit per workgroup.  (The persistent form -- a workgroup walking units blockIdx.x, blockIdx.x + gridDim.x, ... so that a
+    // unit's stores drain under the next one's loads -- was built and measured in r05: the loop costs 65 spilled registers at the
+    // 256 of two workgroups per CU, 129 -> 177 us on hourglass2.conv6, and with the spills equalised persistence itself bought
+    // 4 %: profiles/r05_e_deconv_persist.txt.)
+    const int unit = blockIdx.x;
+    unit_origin(unit, iw0, ih0, id0);
+    if constexpr (!SPLIT) {
+        body(std::integral_constant<int, -1>{}, unit);
+    } else {
+        grp = unit & 1;
+        if (grp == 0) body(std::integral_constant<int, 0>{}, unit);
+        else body(std::integral_constant<int, 1>{}, unit);
     }
 }
 
@@ -474,20 +596,22 @@ __global__ void pack_deconv_weights_f16s_kernel(const float* __restrict__ wpack,
     wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
 }
 
-template <int TD, int TH, int NTERMS, bool HAS_SKIP>
+template <int TD, int TH, int NTERMS, bool HAS_SKIP, bool SPLIT = false, bool ACCB = false, bool STREAM = false>
 int launch_db(const float* in, const void* wsplit, const float* shift, const float* skip, const void* skip_wsplit, float* out,
               int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu, hipStream_t st) {
-    using C = DB<TD, TH, (NTERMS == 6) ? 3 : 2, NTERMS == F16X3>;
+    using C = DB<TD, TH, (NTERMS == 6) ? 3 : 2, NTERMS == F16X3, SPLIT ? 15 : 27>;
     const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, TH), tiles_d = ss::ceil_div(D, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = deconv3d_bf16s<TD, TH, NTERMS, HAS_SKIP>;
+    auto kern = deconv3d_bf16s<TD, TH, NTERMS, HAS_SKIP, SPLIT, ACCB, STREAM>;
     if (C::LDS_BYTES > 64 * 1024) {
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }
-    dim3 grid((unsigned)nt, ss::ceil_div(Cout, 32), B);
+    if (nt > 0x3fffffffLL) return SS_ERR_UNSUPPORTED;
+    const long long nunits = SPLIT ? 2 * nt : nt;
+    dim3 grid((unsigned)nunits, ss::ceil_div(Cout, 32), B);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), shift, skip,
-                       reinterpret_cast<const uint4*>(skip_wsplit), out, Cin, D, H, W, Cout, Cs, tiles_w, tiles_h, relu);
+                       reinterpret_cast<const uint4*>(skip_wsplit), out, Cin, D, H, W, Cout, Cs, tiles_w, tiles_h, relu, (int)nunits);
     return ss::check_launch();
 }
 
@@ -495,8 +619,29 @@ template <int TD, int TH>
 int launch_db_all(const float* in, const void* wsplit, const float* shift, const float* skip, const void* skip_wsplit,
                   float* out, int B, int Cin, int D, int H, int W, int Cout, int Cs, int relu, int nterms, hipStream_t st) {
 #define SS_DB(NTERMS, HAS_SKIP) launch_db<TD, TH, NTERMS, HAS_SKIP>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st)
-    if (skip != nullptr) return nterms == 6 ? SS_DB(6, true) : (nterms == 3 ? SS_DB(3, true) : SS_DB(F16X3, true));
-    return nterms == 6 ? SS_DB(6, false) : (nterms == 3 ? SS_DB(3, false) : SS_DB(F16X3, false));
+#define SS_DF(HAS_SKIP, SPLIT, ACCB, STREAM) \
+    launch_db<TD, TH, F16X3, HAS_SKIP, SPLIT, ACCB, STREAM>(in, wsplit, shift, skip, skip_wsplit, out, B, Cin, D, H, W, Cout, Cs, relu, st)
+    if (nterms == F16X3) {
+        // Parity-class groups (r05, Grp<> above), measured alone on the four transposed convs of the 1024^2 pair (hourglass2.conv6 /
+        // .conv5, hourglass_att.conv6 / .conv5; profiles/r05_f_deconv_forms.txt): all 8 classes per workgroup 128 / 55 / 38 / 39 us;
+        // two class groups at three workgroups per CU 148 / 56 / 55 / 36; two groups + chunk-blocked accumulation 163 / 75 / 55 / 36.
+        // The second staging of the input tile costs more than the third workgroup per CU returns wherever the layer fills the
+        // chip; it pays -- and brings the blocked sum's accuracy -- on a layer whose tiles number fewer than the chip's CUs.
+        // That is a property of the LAYER (tiles x channel tiles of ONE pair), so a pair gets the same bits at every batch size.
+        // SS_DECONV_GROUPS=0 / 1 / 2 forces the form (2 = groups + chunk-blocked accumulation).
+        const long long per_pair = (long long)ss::ceil_div(W, 32) * ss::ceil_div(H, TH) * ss::ceil_div(D, TD) * ss::ceil_div(Cout, 32);
+        int groups = ss::tuning().deconv_groups;
+        if (groups < 0) groups = per_pair < 256 ? 2 : 0;
+        const int stream_env = ss::tuning().deconv_stream;
+        const bool stream = stream_env >= 0 ? stream_env != 0 : (long long)B * Cout * 8 * D * H * W * 4 >= (192LL << 20);
+        if (groups == 2) return skip != nullptr ? SS_DF(true, true, true, false) : SS_DF(false, true, true, false);
+        if (groups == 1) return skip != nullptr ? SS_DF(true, true, false, false) : SS_DF(false, true, false, false);
+        if (stream) return skip != nullptr ? SS_DF(true, false, false, true) : SS_DF(false, false, false, true);
+        return skip != nullptr ? SS_DF(true, false, false, false) : SS_DF(false, false, false, false);
+    }
+    if (skip != nullptr) return nterms == 6 ? SS_DB(6, true) : SS_DB(3, true);
+    return nterms == 6 ? SS_DB(6, false) : SS_DB(3, false);
+#undef SS_DF
 #undef SS_DB
 }
 

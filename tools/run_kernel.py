@@ -2,7 +2,7 @@
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
 usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low conv_mid_att conv_low_att attn attn_att warp ssr ssr2048 strength topk
-                                                               catt8 catt4 upsoft stem_left stem stem_gather stem_gather_smooth conv_s1 conv_s2 conv_s2_att deconv"""
+                                                               catt8 catt4 upsoft stem_left stem stem_gather stem_gather_smooth conv_s1 conv_s2 conv_s2_att deconv deconv5 deconv_att6 deconv_att5"""
 import os
 import sys
 import time
@@ -134,6 +134,16 @@ elif name == "conv_s2_att":      # hourglass_att.conv3: 64 -> 128 stride 2 on [1
     sc, sh = torch.rand(128, device=dev) + 0.5, R(128) * 0.1
     fn = lambda: M.conv3d_bf16s_hip(x, ws, 128, sc, sh, True, 19, stride=2)       # noqa: E731
     nbytes = 4.0 * B * (64 * 16 * 64 * 64 + 128 * 8 * 32 * 32)
+elif name in ("deconv5", "deconv_att6", "deconv_att5"):     # the other three transposed convs of the step
+    hg = (M.hourglass2(32) if name == "deconv5" else M.hourglass(32)).to(dev).eval()
+    if name == "deconv5":        # hourglass2.conv5: 128 -> 64 from [6,64,64] + redir2 of the 64-channel [12,128,128] volume
+        xin, xskip, args = torch.relu(R(B, 128, 6, 64, 64)), torch.relu(R(B, 64, 12, 128, 128)), ("u5", hg.conv5, hg.redir2)
+    elif name == "deconv_att6":  # hourglass_att.conv6: 64 -> 32 from [16,64,64] + redir1 of [32,32,128,128]
+        xin, xskip, args = torch.relu(R(B, 64, 16, 64, 64)), torch.relu(R(B, 32, 32, 128, 128)), ("u6", hg.conv6, hg.redir1)
+    else:                        # hourglass_att.conv5: 128 -> 64 from [8,32,32] + redir2 of [64,16,64,64]
+        xin, xskip, args = torch.relu(R(B, 128, 8, 32, 32)), torch.relu(R(B, 64, 16, 64, 64)), ("u5", hg.conv5, hg.redir2)
+    fn = lambda: hg._up(*args, xin, xskip)                                     # noqa: E731
+    nbytes = 4.0 * B * (xin[0].numel() + 2 * xskip[0].numel())
 elif name in ("conv_s2", "conv_s1", "deconv"):
     if name == "deconv":            # hourglass2.conv6: 64 -> 32 to [24,256,256] with the 1x1x1 skip projection of a 32-channel volume
         hg = M.hourglass2(32).to(dev).eval()
