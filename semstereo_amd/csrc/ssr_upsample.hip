@@ -17,20 +17,21 @@
 namespace {
 
 constexpr int NCLS = 6;
-// offsets into the packed parameter block (floats); BN layers are folded to scale/shift on the host
-constexpr int P_BN0 = 0;                       // scale, shift
-constexpr int P_CW = 2;                        // conv 1->n weights [n][9]
-constexpr int P_CB = P_CW + NCLS * 9;          // conv bias [n]
-constexpr int P_BNA = P_CB + NCLS;             // scale[n], shift[n]
-constexpr int P_W1 = P_BNA + 2 * NCLS;         // conv1 [n][n] (out, in)
-constexpr int P_B1 = P_W1 + NCLS * NCLS;
-constexpr int P_BN1 = P_B1 + NCLS;
-constexpr int P_W2 = P_BN1 + 2 * NCLS;
+// The packed parameter block (floats), built on the host (semstereo_amd/modules.py: SSR_upsample._params) with every eval-mode
+// BatchNorm FOLDED into the convolution it follows, in float64, and the two gate stages pre-multiplied by -log2(e) so that their
+// sigmoid is 1 / (1 + exp2(a)) on the accumulated value (r05: the head was instruction-bound -- 1450 VALU instructions per 4
+// pixels, 124 of them quarter-rate, ~117 us of issue at batch 8 against 67 us of HBM; compensated exponentials, Newton steps and
+// separately rounded BatchNorm affines are not what the 2e-5 px contract of the head needs):
+constexpr int P_BN0 = 0;                       // scale, shift of the BatchNorm on the up-sampled disparity (zero padding follows it)
+constexpr int P_CW = 2;                        // [n][9]  sa[c] * conv(1->n) weights
+constexpr int P_CB = P_CW + NCLS * 9;          // [n]     sa[c] * bias + ta[c]
+constexpr int P_W1 = P_CB + NCLS;              // [n][n]  -log2e * s1[o] * conv1 (out, in)
+constexpr int P_B1 = P_W1 + NCLS * NCLS;       // [n]     -log2e * (s1 * b1 + t1)
+constexpr int P_W2 = P_B1 + NCLS;
 constexpr int P_B2 = P_W2 + NCLS * NCLS;
-constexpr int P_BN2 = P_B2 + NCLS;
-constexpr int P_W3 = P_BN2 + 2 * NCLS;         // conv3 [n]
+constexpr int P_W3 = P_B2 + NCLS;              // conv3 [n]
 constexpr int P_B3 = P_W3 + NCLS;
-constexpr int P_TOTAL = P_B3 + 1;              // 189
+constexpr int P_TOTAL = P_B3 + 1;              // 153
 
 // ATen upsample_bilinear2d, align_corners=False, scale = in/out = 0.25
 __device__ __forceinline__ void src_index(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
@@ -52,14 +53,8 @@ __device__ __forceinline__ float upsampled(const float* __restrict__ low, int h,
     return ss::add_rn(ss::mul_rn(ly0, t0), ss::mul_rn(ly1, t1));
 }
 
-// The head is 18 exponentials and 18 divisions per pixel beside 26 bytes of traffic: libm's expf (~20 instructions) and the
-// IEEE division (~10) made it instruction-bound (0.29 of HBM, r02).  exp: the 6-instruction compensated v_exp_f32 of common.h
-// (1.5 ulp); 1 / d: v_rcp_f32 (1 ulp) + one Newton step (<= 1 ulp of the quotient for the d in [1, 1 + 5e34] that occur).
-__device__ __forceinline__ float recip_nr(float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    return r * (2.0f - d * r);
-}
-__device__ __forceinline__ float sigmoidf(float x) { return recip_nr(1.0f + ss::exp_fast(fminf(-x, 80.0f))); }
+// 1 / (1 + 2^a): v_exp_f32 and v_rcp_f32 are 1 ulp each; a -> +inf gives 0, a -> -inf gives 1, as the sigmoid's limits
+__device__ __forceinline__ float gate2(float a) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
 
 // one pixel: everything after the 3x3 neighbourhood `nb` of BN0(up) and the raw centre value are known
 __device__ __forceinline__ float ssr_pixel(const float (&nb)[9], float centre, const float (&labv)[NCLS], const float (&wt)[NCLS],
@@ -67,45 +62,42 @@ __device__ __forceinline__ float ssr_pixel(const float (&nb)[9], float centre, c
     float depth[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) {
-        float a = 0.f;
+        float a = prm[P_CB + c];
 #pragma unroll
         for (int k = 0; k < 9; ++k) a = fmaf(prm[P_CW + c * 9 + k], nb[k], a);
-        a = ss::add_rn(a, prm[P_CB + c]);
-        depth[c] = ss::add_rn(ss::mul_rn(a, prm[P_BNA + c]), prm[P_BNA + NCLS + c]);
+        depth[c] = a;
     }
-    // class probabilities and the two gated 1x1 stages
-    float lab[NCLS], mx = -INFINITY;
+    // class probabilities (soft-max over the 6 logits) times the guidance weights; the 1 / sum joins the first stage's accumulator
+    float mx = labv[0];
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) mx = fmaxf(mx, labv[c]);
-    float sum = 0.f;
+    for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, labv[c]);
+    float z[NCLS], sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) { lab[c] = ss::exp_fast(fmaxf(labv[c] - mx, -100.0f)); sum = ss::add_rn(sum, lab[c]); }
-    float z[NCLS];
-    const float rsum = recip_nr(sum);                         // sum in [1, 6]
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c) z[c] = ss::mul_rn(ss::mul_rn(lab[c], rsum), wt[c]);
+    for (int c = 0; c < NCLS; ++c) {
+        const float e = __builtin_amdgcn_exp2f((labv[c] - mx) * 1.44269504088896340736f);
+        sum += e;
+        z[c] = e * wt[c];
+    }
+    const float rsum = __builtin_amdgcn_rcpf(sum);             // sum in [1, 6]
     float p1[NCLS];
 #pragma unroll
     for (int o = 0; o < NCLS; ++o) {
         float a = 0.f;
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) a = fmaf(prm[P_W1 + o * NCLS + c], z[c], a);
-        a = ss::add_rn(a, prm[P_B1 + o]);
-        p1[o] = sigmoidf(ss::add_rn(ss::mul_rn(a, prm[P_BN1 + o]), prm[P_BN1 + NCLS + o]));
+        p1[o] = gate2(fmaf(a, rsum, prm[P_B1 + o]));
     }
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) z[c] = ss::mul_rn(p1[c], wt[c]);
-    float res = 0.f;
+    for (int c = 0; c < NCLS; ++c) z[c] = p1[c] * wt[c];
+    float res = prm[P_B3];
 #pragma unroll
     for (int o = 0; o < NCLS; ++o) {
-        float a = 0.f;
+        float a = prm[P_B2 + o];
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) a = fmaf(prm[P_W2 + o * NCLS + c], z[c], a);
-        a = ss::add_rn(a, prm[P_B2 + o]);
-        const float p2 = sigmoidf(ss::add_rn(ss::mul_rn(a, prm[P_BN2 + o]), prm[P_BN2 + NCLS + o]));
-        res = fmaf(prm[P_W3 + o], ss::mul_rn(depth[o], p2), res);
+        res = fmaf(prm[P_W3 + o] * depth[o], gate2(a), res);
     }
-    return ss::add_rn(centre, ss::add_rn(res, prm[P_B3]));
+    return centre + res;
 }
 
 // Any size: one thread per output pixel, the 9 taps of the 3x3 conv re-interpolated from the 1/4-scale map.

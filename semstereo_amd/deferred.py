@@ -24,7 +24,9 @@ import threading
 import torch
 
 ENABLED = os.environ.get("SS_DEFER", "1") != "0"
-STATS = {"fused": {}, "replayed": 0}          # which rules fired (tests and bench.py read this)
+#: which rules fired (tests and bench.py read this); "ssr": SSR_upsample calls that handed out a handle / handles that were ever
+#: computed (the `pred_att_up` of an eval forward, models/SemStereo.py:311 vs :346, is handed out and never computed)
+STATS = {"fused": {}, "replayed": 0, "ssr": {"deferred": 0, "computed": 0}}
 
 
 _TLS = threading.local()
@@ -137,7 +139,10 @@ class Deferred:
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         op = _fname(func)
-        if op is None:                                   # not a recorded function: it gets the values
+        # not a recorded function: it gets the values.  Nor is anything recorded on top of the SSR head's result: that handle exists
+        # so that a result nobody touches is never computed (models/SemStereo.py:311 vs :346); whatever IS done with it -- the
+        # `* 4` of the return statement -- computes, so that forward() returns tensors
+        if op is None or any(_is(a, "ssr") for a in args):
             return func(*real(args), **real(kwargs))
         node = Deferred(op, func, args, kwargs)
         return Deferred.pair(node) if op == "sort" else node
@@ -152,19 +157,25 @@ class Deferred:
 
     def __getattr__(self, name):
         # (only reached for names not defined on the class: tensor methods and attributes)
-        if name in _METHODS:
+        if name in _METHODS and self.op != "ssr":
             return self._method(name)
         if name.startswith("__") and name.endswith("__"):
             raise AttributeError(name)
         return getattr(self.value(), name)               # .shape, .size(), .cpu(), .item(), ...: the real tensor's
 
     def __mul__(self, other):
+        if self.op == "ssr":
+            return torch.mul(*real((self, other)))
         return Deferred("mul", torch.mul, (self, other))
 
     def __rmul__(self, other):
+        if self.op == "ssr":
+            return torch.mul(*real((other, self)))
         return Deferred("mul", torch.mul, (other, self))
 
     def __add__(self, other):
+        if self.op == "ssr":
+            return torch.add(*real((self, other)))
         return Deferred("add", torch.add, (self, other))
 
     def __radd__(self, other):

@@ -86,7 +86,18 @@ def accelerate(model, fuse_forward=False):
         done.append(name)
     if fuse_forward and not getattr(type(target), "_ss_fused_forward", False):
         target.__class__ = _fused_class(type(target))
+    if not target.__dict__.get("_ss_output_hook"):
+        # deferred handles (deferred.py) never leave the model: whatever forward() returns is realised on the way out -- since r05
+        # also the SSR head's result (`pred_up * 4`, models/SemStereo.py:346); a handle that is NOT part of the output, like the
+        # `pred_att_up` of an eval forward (:311), is simply never computed
+        target.register_forward_hook(_realise_outputs)
+        target.__dict__["_ss_output_hook"] = True
     return done
+
+
+def _realise_outputs(module, inputs, output):
+    from . import deferred as dfr
+    return dfr.real(output)
 
 
 _FUSED_CLASSES = {}
@@ -159,4 +170,5 @@ def fused_inference_forward(self, left, right, reference_forward=None):
         disp = self.ssr_upsample(r["pred_att"].unsqueeze(1), spx_pred, pred_label)           # :311
     else:
         disp = self.ssr_upsample(r["pred"], spx_pred, pred_label)                            # :324
-    return ([disp * 4], pred_label) if self.seg_if else [disp * 4]                           # :340-346
+    from . import deferred as dfr
+    return dfr.real(([disp * 4], pred_label) if self.seg_if else [disp * 4])                 # :340-346

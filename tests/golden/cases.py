@@ -161,7 +161,7 @@ SEGMENT_WHU = {
     "whu96x160_md256_b2": (2, 96, 160, 256),     # D8 = 32, D4 = 64
 }
 _SEGMENT_SEED = {"whu128_md128": 828, "whu96x160_md256_b2": 832, "s128": 800, "s96x160_b2": 804, "s256_md128": 808, "s192x256_md192": 812,
-                 "s256_md128_cal": 816, "f1024_md128_cal": 820, "f2048_md192_cal": 824}
+                 "s256_md128_cal": 816, "f1024_md128_cal": 820, "f2048_md192_cal": 824, "f1024_md128_cal_b": 836, "f1024_md128_cal_c": 840}
 
 # "_cal": BatchNorm running statistics CALIBRATED on the fixture's own input (one pass of the reference with batch
 # statistics, momentum 1), as a trained network has them: every layer's activations are normalised, so the costs of a
@@ -177,6 +177,10 @@ SEGMENT_CAL = {
 SEGMENT_FULL = {
     "f1024_md128_cal": (1, 1024, 1024, 128),
     "f2048_md192_cal": (1, 2048, 2048, 192),
+    # r05: two more records at the size the north star's EPE is stated for, other closed-form inputs -- the plain-run
+    # figure of one record is one toss of the near-tied top-24 picks; three records are three
+    "f1024_md128_cal_b": (1, 1024, 1024, 128),
+    "f1024_md128_cal_c": (1, 1024, 1024, 128),
 }
 FULL_SAMPLES = 2048
 # The explained-deviation criterion of the hot-segment tests (tests/test_parity_gpu.py, tests/test_fullsize_gpu.py,
@@ -220,7 +224,7 @@ def segment_params(name, fixture=None):
     statistics of a "_cal" case taken from its fixture file (an np.load mapping)."""
     from oracle import hot_segment as oseg
     P = oseg.deterministic_params()
-    if name.endswith("_cal"):
+    if "_cal" in name:
         pre = name + "/bn/"
         found = [k for k in fixture.files if k.startswith(pre)]
         assert found, f"{name}: the fixture holds no calibrated BatchNorm statistics"

@@ -50,10 +50,17 @@ def test_fused_forward_equals_untouched_forward(sa, att_only, deferral_on):
         assert sa.accelerate(net) == []                       # the stand-in is already built from the twins
         from semstereo_amd import deferred as dfr
         dfr.STATS["fused"].clear()
+        ssr0 = dict(dfr.STATS["ssr"])
         before = dict(sa.modules.PATH_COUNTS)
         with torch.no_grad():
             (d0,), lab0 = net(left, right)                     # forward() untouched: HIP ops + HIP modules; deferred handles fuse
+        assert isinstance(d0, torch.Tensor) and isinstance(lab0, torch.Tensor), "a deferred handle left the model"
         assert sa.modules.PATH_COUNTS["torch"] == before["torch"]
+        if deferral_on:
+            # models/SemStereo.py:311 vs :324 / :346: the head is called twice, an eval forward returns one result -- the other
+            # handle (`pred_att_up` when the matching branch runs) is never computed: one launch, not two
+            calls = 1 if att_only else 2
+            assert dfr.STATS["ssr"]["deferred"] - ssr0["deferred"] == calls and dfr.STATS["ssr"]["computed"] - ssr0["computed"] == 1, dfr.STATS
         want_rules = {"gwc_patch_gate", "upsample_softmax_regression", "sample_strength", "topk_candidates"} | (set() if att_only else {"stem_by_halves"})
         assert set(dfr.STATS["fused"]) == want_rules and all(v == 1 for v in dfr.STATS["fused"].values()), dfr.STATS
         dfr.ENABLED = False

@@ -53,7 +53,8 @@ elif name in ("ssr", "ssr2048"):
     Hf = 1024 if name == "ssr" else 2048
     ssr = M.SSR_upsample(6).to(dev).eval()
     d, w, l = R(B, 1, Hf // 4, Hf // 4), R(B, 6, Hf, Hf), R(B, 6, Hf, Hf)
-    fn = lambda: ssr(d, w, l)                                                  # noqa: E731
+    from semstereo_amd import deferred as dfr              # (in inference the head hands out a deferred handle: ask for its value)
+    fn = lambda: dfr.real(ssr(d, w, l))                                        # noqa: E731
     nbytes = 4.0 * B * (13 + 1.0 / 16) * Hf * Hf
 elif name == "strength":
     fl, fr, p0, var = R(B, 128, 256, 256), R(B, 128, 256, 256), R(B, 256, 256) * 8, torch.rand(B, 1, 256, 256, device=dev)
