@@ -224,6 +224,12 @@ __global__ __launch_bounds__(256) void sample_strength_bwd_kernel(const float* _
     }
 }
 
+// DETERMINISM: the three backward kernels of this file scatter into neighbouring pixels (the 5 replicate-padded taps
+// of Propagation / Propagation_prob, the bilinear taps of the probe) and into per-block partial sums with fp32 hardware atomics
+// (unsafeAtomicAdd), like the backward of SpatialTransformer_grid (warp.hip) and ATen's own grid_sampler / replication_pad
+// backward on GPUs: TRAINING gradients of the attention tail are therefore reproducible to rounding (~1e-7 relative), not bit
+// for bit from run to run -- unlike every forward of this library, which is bit-exact and batch-invariant.  A gather form
+// (each pixel reading its inverse neighbours) would be deterministic at ~5x the loads; not built.
 // ---- :295-310 ---------------------------------------------------------------------------------------------------------------------
 // One thread per pixel; LDS: aw[D][T] (the strength-weighted propagated logits, then their gradient).  `samples` [B,K,H,W] are the
 // forward's selected disparities (ascending), so the selection itself is not repeated.
@@ -260,10 +266,10 @@ __global__ void topk_candidates_bwd_kernel(const float* __restrict__ logits, con
     for (int k = 0; k < D; ++k) sum += expf(aw[k * T + tid] - mx);
     // the selected planes: probabilities, the soft-argmax over them, and the two dot products of the softmax backward
     float mx2 = -INFINITY;
-    for (int j = 0; j < K; ++j) mx2 = fmaxf(mx2, aw[((int)samples[(b * K + j) * plane + pix] - dmin) * T + tid]);
+    for (int j = 0; j < K; ++j) mx2 = fmaxf(mx2, aw[min(max((int)samples[(b * K + j) * plane + pix] - dmin, 0), D - 1) * T + tid]);
     float sum2 = 0.f, e1 = 0.f, dotP = 0.f;
     for (int j = 0; j < K; ++j) {
-        const int k = (int)samples[(b * K + j) * plane + pix] - dmin;
+        const int k = min(max((int)samples[(b * K + j) * plane + pix] - dmin, 0), D - 1);    // (clamped: `samples` is caller data, the index goes into LDS)
         const float e = expf(aw[k * T + tid] - mx2);
         sum2 += e;
         e1 += e * (float)(dmin + k);
@@ -277,7 +283,7 @@ __global__ void topk_candidates_bwd_kernel(const float* __restrict__ logits, con
     }
     // second walk over the selected planes needs their ORIGINAL aw: recompute from the logits (24 x 5 loads)
     for (int j = 0; j < K; ++j) {
-        const int k = (int)samples[(b * K + j) * plane + pix] - dmin;
+        const int k = min(max((int)samples[(b * K + j) * plane + pix] - dmin, 0), D - 1);    // (clamped: `samples` is caller data, the index goes into LDS)
         float a = 0.f;
 #pragma unroll
         for (int t = 0; t < 5; ++t) a += st[t] * lg[k * plane + nb[t]];

@@ -37,6 +37,35 @@ def _inference(module, *tensors):
     return True
 
 
+#: Every build of a cache entry (first use, a weight / BatchNorm update, an engine switch, a new shape's key) bumps this counter,
+#: and -- while a multi-stream caller has asked for it (retain_replaced) -- the entry it REPLACES is parked in `_RETIRED` instead
+#: of being freed: a caller that issues consecutive calls on several HIP streams (segment.PairPipeline) compares the counter
+#: around a call; when it moved, the packing kernels ran on that call's stream only and pairs in flight on the other streams may
+#: still be reading the replaced tensors: the caller drains its streams, then drops the retired entries.
+_CACHE_GENERATION = [0]
+_RETIRED = []
+_RETAIN = [0]
+
+
+def cache_generation():
+    return _CACHE_GENERATION[0]
+
+
+def retain_replaced(on):
+    """Multi-stream callers: keep replaced cache entries alive until drop_retired() (counted: several callers may ask)."""
+    _RETAIN[0] = max(0, _RETAIN[0] + (1 if on else -1))
+
+
+def drop_retired():
+    del _RETIRED[:]
+
+
+def _note_build(old):
+    _CACHE_GENERATION[0] += 1
+    if old is not None and _RETAIN[0]:
+        _RETIRED.append(old)
+
+
 class _ParamCache:
     """Derived device tensors (packed weights, folded affines), rebuilt when a source tensor changes."""
 
@@ -48,6 +77,7 @@ class _ParamCache:
         stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in sources)
         hit = self._store.get(key)
         if hit is None or hit[0] != stamp:
+            _note_build(hit)
             with torch.no_grad():
                 hit = (stamp, build())
             self._store[key] = hit
@@ -70,6 +100,7 @@ class _ReplicaCache:
         k = ("replica", self.device, key)
         hit = self.shared._store.get(k)
         if hit is None or hit[0] != stamp:
+            _note_build(hit)
             with torch.no_grad():
                 hit = (stamp, build())
             self.shared._store[k] = hit

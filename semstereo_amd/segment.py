@@ -9,7 +9,9 @@ section 8(f) asks for (volume+patch+gate, up-sampling+softmax+regression+varianc
 the top-24 selection, warp+concat+gate, stem by halves + gate); with autograd on (training) the same
 graph runs line by line on the reference-named ops (HIP forward / backward) and the module twins.
 """
+import contextlib
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -27,6 +29,20 @@ OWNED_PREFIXES = ("patch", "corr_feature_att_8", "hourglass_att", "classif_att_"
 
 
 _SIDE_STREAMS = {}
+_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def overlap_override(value):
+    """The within-pair second stream forced on / off for the calls of THIS thread inside the block, whatever the module's or the
+    class's OVERLAP says -- callers that bring their own concurrency (PairPipeline) pass their choice down this way instead of
+    writing to the shared module (two pipelines, or a pipeline beside nn.DataParallel's replica threads, raced on that write)."""
+    prev = getattr(_TLS, "overlap", None)
+    _TLS.overlap = value
+    try:
+        yield
+    finally:
+        _TLS.overlap = prev
 
 
 def _side_stream(device):
@@ -147,8 +163,8 @@ class HotSegment(nn.Module):
         cost_att = self.classif_att_(self.hourglass_att(cost_att))                             # :277-278
         if rel is not None:
             rel("cls")
-        if (not fast and not M._inference(self, fl4, fr4, fl8, fr8) and isinstance(cost_att, torch.Tensor)
-                and T.attention_tail_applies(cost_att, r4, H4, W4)):
+        if (not fast and getattr(self, "FUSED", HotSegment.FUSED) and not M._inference(self, fl4, fr4, fl8, fr8)
+                and isinstance(cost_att, torch.Tensor) and T.attention_tail_applies(cost_att, r4, H4, W4, fl4, fr4, TOPK)):
             # training / autograd (main_us3d.py:186-222): :279-310 as the three fused launches with their backward kernels (train.py)
             return T.attention_tail(cost_att, fl4, fr4, self.gamma, self.beta, r4, H4, W4, TOPK)
         if fast and ops.upsample_softmax_regression_applies(cost_att, m4, H4, W4, r4):
@@ -268,6 +284,8 @@ def run_segment(owner, fl4, fr4, fl8, fr8, matching=True):
     `matching=False` stops after the attention branch (the reference's att_weights_only mode)."""
     fused = getattr(owner, "FUSED", HotSegment.FUSED)
     overlap = getattr(owner, "OVERLAP", HotSegment.OVERLAP)
+    if getattr(_TLS, "overlap", None) is not None:       # a caller's overlap_override(...) for this thread
+        overlap = _TLS.overlap
     if overlap == "auto":
         overlap = fl4.shape[0] <= 2
     prelude = None
@@ -346,8 +364,9 @@ class PairPipeline:
     --streams): batch 1: 497 -> 528 / 531 / 542 / 538 pairs/s on 2 / 3 / 4 / 6 lanes; batch 4: 535 -> 561 (3 lanes); batch 8: 543 -> 560;
     2048^2 / 192: 120 -> 126.  Inference only.
 
-    `pipe(*inputs)` returns the module's output at once; the tensors are valid after `pipe.synchronize()`, or for work issued on a
-    stream that has waited for `pipe.last_event`.  Inputs produced on the calling stream are waited for.  `segment` is any inference
+    `pipe(*inputs)` returns the module's output at once; the tensors are valid after `pipe.synchronize()`, or on another stream
+    after `pipe.join(outputs, stream)` (waits for the call's event AND records the consumer stream on the outputs: they live in the
+    lane's allocator pool).  Inputs produced on the calling stream are waited for.  `segment` is any inference
     module -- a HotSegment (`pipe(fl4, fr4, fl8, fr8)`) or a whole reference model after `install` + `accelerate`
     (`pipe(imgL, imgR)`: its backbone's kernels ride the lanes too)."""
 
@@ -355,33 +374,58 @@ class PairPipeline:
         assert lanes >= 1 and not segment.training
         self.segment, self.nlanes = segment, int(lanes)
         self.lanes, self.turn, self.last_event, self._primed = None, 0, None, False
+        self.rebuilds = 0                       # calls during which a per-module cache entry was (re)built (see __call__)
+
+    def _prime(self, inputs, dev):
+        # weight packing and every other per-module cache are filled by a call ON THE CALLING STREAM, and drained, before several
+        # streams read them
+        with torch.no_grad():
+            self.segment(*inputs)
+        torch.cuda.synchronize(dev)
+        if self.lanes is None:
+            self.lanes = [torch.cuda.Stream(device=dev) for _ in range(self.nlanes)]
+            if self.nlanes > 1:
+                M.E.retain_replaced(True)
+        M.E.drop_retired()
+        self._primed = True
+
+    def close(self):
+        """Drain the lanes and stop retaining replaced cache entries (also called when the pipeline is collected)."""
+        if self.lanes is not None:
+            self.synchronize()
+            if self.nlanes > 1:
+                M.E.retain_replaced(False)
+            M.E.drop_retired()
+            self.lanes = None
+            self._primed = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def __call__(self, *inputs):
         dev = inputs[0].device
         if not self._primed:
-            # weight packing and every other per-module cache are filled by the first call ON THE CALLING STREAM, and drained,
-            # before several streams read them
-            with torch.no_grad():
-                self.segment(*inputs)
-            torch.cuda.synchronize(dev)
-            self.lanes = [torch.cuda.Stream(device=dev) for _ in range(self.nlanes)]
-            self._primed = True
+            self._prime(inputs, dev)
         lane = self.lanes[self.turn % self.nlanes]
         self.turn += 1
         lane.wait_stream(torch.cuda.current_stream(dev))
-        # the lanes ARE the concurrency: the within-pair second stream on top of them costs 0.8 % (4 lanes: 525.7 vs 521.4 pairs/s)
-        had, prev = "OVERLAP" in self.segment.__dict__, self.segment.__dict__.get("OVERLAP")
-        if self.nlanes > 1:
-            self.segment.OVERLAP = False
-        try:
-            with torch.cuda.stream(lane), torch.no_grad():
-                out = self.segment(*inputs)
-        finally:
-            if self.nlanes > 1:
-                if had:
-                    self.segment.OVERLAP = prev
-                else:
-                    self.segment.__dict__.pop("OVERLAP", None)
+        gen = M.E.cache_generation()
+        # the lanes ARE the concurrency: the within-pair second stream on top of them costs 0.8 % (4 lanes: 525.7 vs 521.4 pairs/s);
+        # passed down per thread (overlap_override), the shared module is not written to
+        with torch.cuda.stream(lane), torch.no_grad(), overlap_override(False if self.nlanes > 1 else None):
+            out = self.segment(*inputs)
+        if M.E.cache_generation() != gen and self.nlanes > 1:
+            # A cache entry was (re)built during this call -- load_state_dict / an in-place weight update, an engine switch, a shape
+            # whose key had not been built: its packing kernels ran on THIS lane only, and the entries they replace may still be read
+            # by pairs in flight on the other lanes (they are parked, not freed: engine.retain_replaced).  Rare and not worth
+            # anything finer: drain every lane, then let the replaced tensors go.  (ADVICE r4, medium.)
+            self.rebuilds += 1
+            for st in self.lanes:
+                st.synchronize()
+            M.E.drop_retired()
         with torch.cuda.stream(lane):
             for t in inputs:
                 if isinstance(t, torch.Tensor):
@@ -389,6 +433,27 @@ class PairPipeline:
             self.last_event = torch.cuda.Event()
             self.last_event.record(lane)
         return out
+
+    def join(self, outputs=None, stream=None):
+        """Make `stream` (default: the current stream) wait for the last issued call and tell the allocator that `outputs` (a
+        tensor or any nesting of dicts / lists of tensors: what that call returned) are used there -- the outputs live in the
+        lane's allocator pool, and without record_stream the lane could reuse their memory while the consumer still reads it."""
+        stream = stream or torch.cuda.current_stream()
+        if self.last_event is not None:
+            stream.wait_event(self.last_event)
+
+        def mark(x):
+            if isinstance(x, torch.Tensor):
+                if x.is_cuda:
+                    x.record_stream(stream)
+            elif isinstance(x, dict):
+                for v in x.values():
+                    mark(v)
+            elif isinstance(x, (list, tuple)):
+                for v in x:
+                    mark(v)
+        mark(outputs)
+        return outputs
 
     def synchronize(self):
         for st in self.lanes or ():

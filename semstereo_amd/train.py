@@ -416,9 +416,17 @@ class _TopkCandidates(torch.autograd.Function):
         return gl, gs, None, None
 
 
-def attention_tail_applies(cost_att, rng, H, W):
-    """The fused tail under autograd: same shape conditions as the inference kernels (exact 2x up-sampling, D <= 128)."""
+def attention_tail_applies(cost_att, rng, H, W, left=None, right=None, k=None):
+    """The fused tail under autograd: same shape conditions as the inference kernels (exact 2x up-sampling, D <= 128), fp32 HIP
+    feature maps of the output's size, and a candidate count the selection kernel is built for (anything else -- half
+    tensors under autocast, k > D -- takes the PyTorch statements instead of surfacing as a C-ABI error)."""
     from . import ops
+    for t in (left, right):
+        if t is not None and not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4
+                                  and tuple(t.shape[-2:]) == (H, W)):
+            return False
+    if k is not None and not (k in (6, 24, 32) and k <= rng[1]):
+        return False
     return (_on(cost_att) and ops.upsample_softmax_regression_applies(cost_att, rng[1] // 2 if rng[0] else rng[1], H, W, _range=rng)
             and rng[1] <= ops.TOPK_CANDIDATES_MAX_D)
 

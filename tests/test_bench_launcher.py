@@ -41,6 +41,33 @@ def test_self_launch_two_ranks_prints_one_json_line():
     assert res["steady_state"]["steps"] >= 4 and res["steady_state"]["pairs_per_s"] > 0
 
 
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("argv, config, batch", [
+    (["--batch", "4"], "configs[3]", 4),                                                   # 1024^2 / 128, batch 32 over 8 GPUs
+    (["--height", "2048", "--width", "2048", "--maxdisp", "192"], "configs[4]", 1),        # 2048^2 / 192, batch 8 over 8 GPUs
+])
+def test_eight_rank_rehearsal_of_the_sharded_configs(argv, config, batch):
+    """the two 8-GPU configurations of BASELINE.json as `--dry-launch` rehearsals -- eight self-launched ranks, rank
+    r bound to device r, per-rank workload as the config says, the padded all_gather of the whole batch, the reductions --
+    so that the launch line of a SCALE run is known to hold before an 8-GPU node appears (reference: nn.DataParallel over
+    the visible GPUs, test_us3d.py:58).  No scaling curve exists; this asserts control flow only."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-launch", "--steps", "2", "--warmup", "1"] + argv,
+                       env=_env(OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    res = lines[0]
+    assert res["n_gpus"] == 8 and res["pairs_counted"] == 8 * batch * 2
+    d = res["dist"]
+    assert d["world_size"] == 8 and len(d["per_rank_pairs_per_s"]) == 8
+    assert sorted(b["rank"] for b in d["rank_devices"]) == list(range(8))
+    assert all(b["local_rank"] == b["rank"] and b["device"].endswith("cuda:%d)" % b["rank"]) for b in d["rank_devices"])
+    assert d["all_gather_shape"][0] == 8 * batch
+    assert d["workload_per_rank"]["config"] == config and d["workload_per_rank"]["pairs_per_step"] == batch
+
+
 def test_self_launch_fails_when_a_rank_fails():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "0"],
                        env=_env(SS_DRY_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
@@ -68,9 +95,6 @@ def test_parent_makes_no_gpu_call_before_spawning():
     launcher = src[src.index("def launch_ranks"):src.index("def dry_step_factory")]
     launcher = launcher[launcher.index('"""', launcher.index('"""') + 3):]          # code only, not the docstring
     assert "torch.cuda" not in launcher and "os.exec" not in launcher and "execv" not in launcher
-
-
-import pytest  # noqa: E402
 
 
 @pytest.mark.gpu

@@ -951,6 +951,53 @@ def test_pair_pipeline_is_bit_identical_to_sequential_calls(sa, lanes):
     assert pipe.last_event is not None and pipe.last_event.query()
 
 
+def test_pair_pipeline_survives_a_weight_update_and_a_new_shape(sa):
+    """a per-module cache entry rebuilt WHILE the lanes are in use -- an in-place weight update, then a
+    shape whose entries had not been built -- is packed on one lane only.  The pipeline must notice (engine.cache_generation),
+    drain its lanes and keep the replaced tensors alive for the pairs in flight: every pair still gets, bit for bit, what a
+    plain call with the weights of that moment gives.  Also: the module's OVERLAP attribute is never written (the choice is
+    passed down per thread), and join() hands the outputs to another stream."""
+    from oracle import detdata as dd
+    seg, _ = _segment(sa, 64)
+
+    def pair(i, h8=16, w8=24):
+        fl8, fr8 = dd.stereo_features(1, 256, h8, w8, 700 + 2 * i, max_shift=3)
+        fl4, fr4 = dd.stereo_features(1, 128, 2 * h8, 2 * w8, 701 + 2 * i, max_shift=6)
+        return [dev(t) for t in (fl4, fr4, fl8, fr8)]
+    pairs = [pair(i) for i in range(6)]
+    pipe = sa.PairPipeline(seg, 3)
+    first = [pipe(*p) for p in pairs[:3]]
+    assert "OVERLAP" not in seg.__dict__
+    with torch.no_grad():                                       # pairs 0-2 may still be in flight on the lanes
+        seg.classif[0][0].weight.mul_(1.25)
+        seg.hourglass.conv1[0][1].running_var.mul_(0.9)
+    gen = sa.engine.cache_generation()
+    second = [pipe(*p) for p in pairs[3:]]
+    assert sa.engine.cache_generation() > gen and pipe.rebuilds >= 1
+    other = pair(9, 12, 20)                                     # another shape: its entries are built inside a lane, too
+    third = pipe(*other)
+    side = torch.cuda.Stream()
+    pipe.join(third, side)
+    with torch.cuda.stream(side):
+        doubled = third["pred"] * 2.0
+    side.synchronize()
+    pipe.synchronize()
+    with torch.no_grad():
+        want_second = [seg(*p) for p in pairs[3:]]
+        want_third = seg(*other)
+        seg.classif[0][0].weight.div_(1.25)
+        seg.hourglass.conv1[0][1].running_var.div_(0.9)
+        want_first = [seg(*p) for p in pairs[:3]]
+    torch.cuda.synchronize()
+    for got, want in ((first, want_first), (second, want_second), ([third], [want_third])):
+        for g_, w_ in zip(got, want):
+            for k in ("pred", "pred_att", "samples"):
+                assert torch.equal(g_[k], w_[k]), k
+    assert torch.equal(doubled, want_third["pred"] * 2.0)
+    pipe.close()
+    assert not sa.engine._RETIRED
+
+
 @pytest.mark.parametrize("hip2d", [True, False])
 def test_hot_segment_with_hip_2d_convs(sa, golden, hip2d):
     """SS_CONV2D_HIP: concat_feature's two 3x3 2-D convs on the split engine (default with f16x3) or on MIOpen."""
