@@ -969,8 +969,8 @@ def test_pair_pipeline_survives_a_weight_update_and_a_new_shape(sa):
     first = [pipe(*p) for p in pairs[:3]]
     assert "OVERLAP" not in seg.__dict__
     with torch.no_grad():                                       # pairs 0-2 may still be in flight on the lanes
-        seg.classif[0][0].weight.mul_(1.25)
-        seg.hourglass.conv1[0][1].running_var.mul_(0.9)
+        seg.classif[0][0].weight.mul_(2.0)             # (powers of two: undone exactly below)
+        seg.hourglass.conv1[0][1].running_var.mul_(0.5)
     gen = sa.engine.cache_generation()
     second = [pipe(*p) for p in pairs[3:]]
     assert sa.engine.cache_generation() > gen and pipe.rebuilds >= 1
@@ -985,8 +985,8 @@ def test_pair_pipeline_survives_a_weight_update_and_a_new_shape(sa):
     with torch.no_grad():
         want_second = [seg(*p) for p in pairs[3:]]
         want_third = seg(*other)
-        seg.classif[0][0].weight.div_(1.25)
-        seg.hourglass.conv1[0][1].running_var.div_(0.9)
+        seg.classif[0][0].weight.mul_(0.5)
+        seg.hourglass.conv1[0][1].running_var.mul_(2.0)
         want_first = [seg(*p) for p in pairs[:3]]
     torch.cuda.synchronize()
     for got, want in ((first, want_first), (second, want_second), ([third], [want_third])):

@@ -18,7 +18,14 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(root, "profiles", "pmc_traffic.json")
 table = json.load(open(path)) if os.path.exists(path) else {}
-for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_*_b*.json"))):
+files = sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_*_b*.json")))
+# gpurun_out/ accumulates over calls and rounds: only the records of the LATEST measurement run (within two hours of the newest
+# file) are filed under this tag -- an older record keeps the tag it was collected under
+newest = max((os.path.getmtime(f) for f in files), default=0.0)
+for f in files:
+    if os.path.getmtime(f) < newest - 7200:
+        print("skipped (stale):", os.path.basename(f))
+        continue
     rec = json.load(open(f))
     key = f"{rec['run_kernel']}_b{rec['batch']}"
     md = f[:-5] + ".md"
