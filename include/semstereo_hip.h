@@ -187,8 +187,9 @@ int ss_regression_topk_bwd(const float* grad_out, const float* cost, const float
 /* SSR_upsample.forward(depth_low, weights, pred_label)   models/submodule.py:412-431 (calls: SemStereo.py:311, 324)
  * 4x bilinear up-sampling of the 1/4-scale disparity + class-probability-gated residual, one kernel.
  *   depth_low [B,1,h,w]; weights (spx_pred), pred_label [B,n,4h,4w]; out [B,4h,4w]; n = 6.
- *   params: ss_ssr_param_count() floats = the module's parameters with every BatchNorm2d folded to
- *   (scale, shift), packed as laid out at the top of csrc/ssr_upsample.hip (semstereo_amd/modules.py packs it). */
+ *   params: ss_ssr_param_count() floats (153 since ABI 12) = the module's parameters with every eval-mode BatchNorm2d
+ *   FOLDED into the convolution before it and the two gate stages pre-multiplied by -log2(e), packed as laid out at the top of
+ *   csrc/ssr_upsample.hip (semstereo_amd/modules.py: SSR_upsample._params packs it, in float64). */
 int ss_ssr_upsample_fwd(const float* depth_low, const float* weights, const float* pred_label,
                         const float* params, float* out, int B, int h, int w, int num_classes,
                         ss_stream_t stream);
@@ -282,6 +283,11 @@ int ss_pack_conv3d_weights_f16s(const float* w, void* wsplit, int Cout, int Cin,
 int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                         const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int relu,
                         int nterms, ss_stream_t stream);
+/* The same layer on TWO input tensors in one launch: out [2B,Cout,H,W], elements 0..B-1 from in_a, B..2B-1 from in_b (both
+ * [B,Cin,H,W]) -- `concat_feature` applied to the left and to the right view (models/SemStereo.py:314-315) without a torch.cat
+ * in front and with twice the workgroups per launch (round 5).  No residual operand. */
+int ss_conv2d_bf16s_pair_fwd(const float* in_a, const float* in_b, const void* wsplit, const float* scale, const float* shift,
+                             float* out, int B, int Cin, int H, int W, int Cout, int relu, int nterms, ss_stream_t stream);
 int ss_pack_conv2d_weights_bf16s(const float* w, void* wsplit, int Cout, int Cin, ss_stream_t stream);
 /* two-term fp16 form of the 2-D weights (nterms = 19 of ss_conv2d_bf16s_fwd; see ss_pack_conv3d_weights_f16s):
  * ceil(Cin/8)*5*2*2*Cout*16 + 4*Cout bytes. */

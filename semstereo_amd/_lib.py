@@ -51,6 +51,7 @@ _SIGNATURES = {
     "ss_pack_conv3d_weights_bf16s": [_P, _P, _I, _I, _P],
     "ss_pack_conv3d_weights_f16s": [_P, _P, _I, _I, _P],
     "ss_conv2d_bf16s_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_conv2d_bf16s_pair_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv2d_weights_bf16s": [_P, _P, _I, _I, _P],
     "ss_pack_conv2d_weights_f16s": [_P, _P, _I, _I, _P],
     "ss_conv3d_head_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

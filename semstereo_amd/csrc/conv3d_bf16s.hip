@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                                                         float* __restrict__ out,
                                                         int Cin, int D, int H, int W, int Cout, int Do, int Ho, int Wo,
                                                         int tiles_w, int tiles_h, int ntiles, int relu,
-                                                        const float* __restrict__ cand, const float* __restrict__ catt) {
+                                                        const float* __restrict__ cand, const float* __restrict__ catt,
+                                                        const float* __restrict__ in2, int bsplit) {
     static_assert(!GATHER || (S == 1 && MT == 1 && KD == 3 && MS == 1), "gather form: plain stride-1 3-D tiles");
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
@@ -237,7 +238,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     f32x16 acc[MT * NT];                  // index mt * NT + row
 
     const size_t in_plane = (size_t)H * W, chan = GATHER ? in_plane : (size_t)D * in_plane;     // (gather: channels of a 2-D map)
-    const float* inb = in + (size_t)b * Cin * chan;
+    // (in2: batch elements bsplit, bsplit + 1, ... of the launch come from a SECOND input tensor -- the left and right views of
+    // concat_feature in one launch without a torch.cat in front, ss_conv2d_bf16s_pair_fwd)
+    const float* inb = (in2 != nullptr && b >= bsplit) ? in2 + (size_t)(b - bsplit) * Cin * chan : in + (size_t)b * Cin * chan;
 
     // staging plan of a tile: this thread owns positions p = tid + 256*i of the halo tile, all 8 channels
     auto make_poff = [&](int tile, unsigned (&po)[C::NPOS]) {
@@ -754,7 +757,7 @@ __global__ void pack_weights_f16s_kernel(const float* __restrict__ w, unsigned s
 template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false, bool GATHER = false>
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st,
-              const float* cand = nullptr, const float* catt = nullptr) {
+              const float* cand = nullptr, const float* catt = nullptr, const float* in2 = nullptr, int bsplit = 0) {
     using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2, wlds_form(S, NT, NTERMS, MT, KD) ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS,
                    gather_slots(GATHER, S, TD, TH, KD)>;
     const int Do = (D + 2 * (KD / 2) - KD) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
@@ -776,7 +779,7 @@ int launch_bgm(const float* in, const void* wsplit, const float* scale, const fl
     // the same time.  Starting the first round's workgroups spread over 0.5-1.5 estimated lifetimes, in 2-16 groups, was
     // measured: no gain, -0 .. -8 %.)
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, in, reinterpret_cast<const uint4*>(wsplit), scale, shift,
-                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, (int)nt, relu, cand, catt);
+                       residual, gate, out, Cin, D, H, W, Cout, Do, Ho, Wo, tiles_w, tiles_h, (int)nt, relu, cand, catt, in2, bsplit);
     return ss::check_launch();
 }
 
@@ -923,9 +926,26 @@ extern "C" int ss_pack_conv2d_weights_f16s(const float* w, void* wsplit, int Cou
     return ss::check_launch();
 }
 
+static int conv2d_bf16s_impl(const float* in, const float* in2, int bsplit, const void* wsplit, const float* scale, const float* shift,
+                            const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int relu,
+                            int nterms, ss_stream_t stream);
+
 extern "C" int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                                    const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int relu,
                                    int nterms, ss_stream_t stream) {
+    return conv2d_bf16s_impl(in, nullptr, 0, wsplit, scale, shift, residual, out, B, Cin, H, W, Cout, relu, nterms, stream);
+}
+
+extern "C" int ss_conv2d_bf16s_pair_fwd(const float* in_a, const float* in_b, const void* wsplit, const float* scale,
+                                        const float* shift, float* out, int B, int Cin, int H, int W, int Cout, int relu,
+                                        int nterms, ss_stream_t stream) {
+    SS_REQUIRE(in_a && in_b);
+    return conv2d_bf16s_impl(in_a, in_b, B, wsplit, scale, shift, nullptr, out, 2 * B, Cin, H, W, Cout, relu, nterms, stream);
+}
+
+static int conv2d_bf16s_impl(const float* in, const float* in2, int bsplit, const void* wsplit, const float* scale, const float* shift,
+                            const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int relu,
+                            int nterms, ss_stream_t stream) {
     SS_REQUIRE(in && wsplit && out);
     SS_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && (nterms == 3 || nterms == 6 || nterms == F16X3));
     SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0);
@@ -934,9 +954,9 @@ extern "C" int ss_conv2d_bf16s_fwd(const float* in, const void* wsplit, const fl
     auto blocks = [&](int th) { return (long long)ss::ceil_div(W, 32) * ss::ceil_div(H, th) * ss::ceil_div(Cout, 32) * B; };
     const int r = relu ? 1 : 0;
 #define SS_B2(NT, TH)                                                                                                      \
-    return (nterms == 6) ? launch_bgm<1, NT, 1, TH, 6, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st) \
-         : (nterms == 3) ? launch_bgm<1, NT, 1, TH, 3, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st) \
-                         : launch_bgm<1, NT, 1, TH, F16X3, false, 1, 1, 1, SS_ACC_BLOCKED != 0>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st)
+    return (nterms == 6) ? launch_bgm<1, NT, 1, TH, 6, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st, nullptr, nullptr, in2, bsplit) \
+         : (nterms == 3) ? launch_bgm<1, NT, 1, TH, 3, false, 1, 1>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st, nullptr, nullptr, in2, bsplit) \
+                         : launch_bgm<1, NT, 1, TH, F16X3, false, 1, 1, 1, SS_ACC_BLOCKED != 0>(in, wsplit, scale, shift, residual, nullptr, out, B, Cin, 1, H, W, Cout, r, st, nullptr, nullptr, in2, bsplit)
     if (blocks(16) >= 512) { SS_B2(4, 16); }
     if (blocks(8) >= 512) { SS_B2(2, 8); }
     SS_B2(1, 4);

@@ -594,6 +594,41 @@ def _rule_stem(node):
     return True
 
 
+# ---- rule: concat_feature(left view), concat_feature(right view), :314-315 -> one pair of launches ---------------------------------
+
+def _rule_cfeat(node):
+    """The value of one view's concat features is asked for while the other view's handle of the SAME module is still pending:
+    both through ss_conv2d_bf16s_pair_fwd + one batch-2B launch of the second layer.  Anything else: the recorded call."""
+    from . import modules as M
+    from .segment import HotSegment
+    mod = node.info.get("module")
+    if mod is None or not HotSegment.PAIR_VIEWS or len(mod) != 2:
+        return False
+    x = real(node.args[0])
+    for ref in mod.__dict__.get("_ss_pending_cf", []):
+        other = ref()
+        if other is None or other is node or other.done or other.info.get("module") is not mod:
+            continue
+        y = real(other.args[0])
+        if not (isinstance(y, torch.Tensor) and y.shape == x.shape and y.device == x.device and y.dtype == x.dtype):
+            continue
+        a, b = mod[0], mod[1]
+        if not (isinstance(getattr(a, "conv", None), torch.nn.Conv2d) and getattr(a, "relu", False) and isinstance(b, torch.nn.Conv2d)
+                and M._inference(mod, x, y)):
+            return False
+        with suspended():
+            bn = a.bn if getattr(a, "use_bn", True) else None
+            h = M.run_conv2d_pair(a, "bc2d", a.conv, bn, x, y, True)
+            z = M.run_conv2d(mod, "cf1", b, None, h, False) if h is not None else None
+        if z is None:
+            return False
+        n = x.shape[0]
+        node._value, other._value = z[:n], z[n:]
+        _fused("concat_feature_pair")
+        return True
+    return False
+
+
 _VALUE_RULES = {
     "softmax": (_rule_strength,),
     "gather": (_rule_att_topk,),
@@ -601,4 +636,5 @@ _VALUE_RULES = {
     "float": (_rule_samples,),
     "sum": (_rule_pred_att,),
     "stem": (_rule_stem,),
+    "cfeat": (_rule_cfeat,),
 }

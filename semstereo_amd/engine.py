@@ -372,6 +372,28 @@ def run_conv2d(owner, key, conv, bn, x, relu):
     return conv2d_bf16s_hip(x, ws, conv.out_channels, scale, shift, relu, nterms)
 
 
+def run_conv2d_pair(owner, key, conv, bn, xa, xb, relu):
+    """run_conv2d on two inputs of one shape in ONE launch (ss_conv2d_bf16s_pair_fwd): -> [2B,Cout,H,W] (first B: xa's), or None."""
+    if not (_conv2d_hip_on() and CONV_ENGINE != "f32" and _is_plain_3x3(conv) and xa.is_cuda and xb.is_cuda
+            and xa.shape == xb.shape and xa.dtype == xb.dtype == torch.float32):
+        return None
+    nterms = _tiled_nterms()
+    srcs = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+    def build():
+        sc, sh = fold_bn(bn) if bn is not None else (None, None)
+        return pack_conv2d_weight_bf16s(conv.weight, nterms), sc, sh
+    ws, scale, shift = _cache(owner).get(key + "/2d_" + CONV_ENGINE, srcs, build)
+    xa, xb = xa.contiguous(), xb.contiguous()
+    dev = _lib.require_device(xa, xb, scale, shift)
+    B, Cin, H, W = xa.shape
+    out = torch.empty((2 * B, conv.out_channels, H, W), dtype=xa.dtype, device=xa.device)
+    with torch.cuda.device(dev):
+        call("ss_conv2d_bf16s_pair_fwd", ptr(xa), ptr(xb), ptr(ws), ptr(scale), ptr(shift), ptr(out), B, Cin, H, W,
+             conv.out_channels, int(relu), int(nterms))
+    return out
+
+
 def pack_head_weight_bf16s(w, nterms=6):
     """[1,Cin,3,3,3] fp32 -> split fragments (taps as matrix rows) for ss_conv3d_head_bf16s_fwd: three bf16 terms (nterms 6 / 3)
     or two scaled fp16 terms + the inverse scale (nterms 19)."""

@@ -32,7 +32,7 @@ from .engine import (PATH_COUNTS, _cache, _conv_geometry, _inference, _is_plain_
                      classifier_cl_hip, conv2d_bf16s_hip, conv3d_bf16s_hip, conv3d_head_bf16s_hip, conv3d_hip,
                      conv3d_pointwise_bf16s_hip, deconv3d_bf16s_hip, deconv3d_hip, fold_bn, pack_conv2d_weight_bf16s,
                      pack_conv_weight, pack_conv_weight_bf16s, pack_deconv_weight_bf16s, pack_head_weight_bf16s,
-                     pack_pointwise_weight_bf16s, run_conv2d, run_convbn, stem_broadcast_half, stem_of_broadcast_and_volume,
+                     pack_pointwise_weight_bf16s, run_conv2d, run_conv2d_pair, run_convbn, stem_broadcast_half, stem_of_broadcast_and_volume,
                      stem_gather_applies, stem_gather_half, stem_presplit_applies, stem_volume_half, stem_volume_half_presplit, _aux_nterms, _deconv_nterms,
                      _head_nterms, _tiled_nterms)
 from .train_layers import (_conv_k3_forward, _deconv_k3_forward, conv3d_train, conv3d_wgrad_hip, deconv3d_train)  # noqa: F401
@@ -150,6 +150,20 @@ class ConcatFeature(nn.Sequential):
         return self
 
     def forward(self, x):
+        x = dfr.real(x)
+        if dfr.on(self, x) and isinstance(x, torch.Tensor) and x.dim() == 4:
+            # the reference applies this module to the left view, then to the right one (models/SemStereo.py:314-315), and needs
+            # neither before the concat volume: a deferred handle each, so that both views go through ONE pair of launches when the
+            # first value is asked for (deferred.py: rule "cfeat"; HotSegment's own composition does the same directly)
+            node = dfr.Deferred.call("cfeat", self._forward_now, x)
+            node.info["module"] = self
+            pend = [r for r in self.__dict__.get("_ss_pending_cf", []) if r() is not None and not r().done]
+            pend.append(__import__("weakref").ref(node))
+            self.__dict__["_ss_pending_cf"] = pend
+            return node
+        return self._forward_now(x)
+
+    def _forward_now(self, x):
         x = dfr.real(x)
         a, b = self[0], self[1]
         if (isinstance(getattr(a, "conv", None), nn.Conv2d) and getattr(a, "relu", False) and not getattr(a, "deconv", False)

@@ -85,6 +85,7 @@ class HotSegment(nn.Module):
     #: `accelerate()` alone, with its forward() untouched.  True: the fused kernels of this file.
     FUSED = os.environ.get("SS_FUSED", "1") != "0"
     STEM_BY_HALVES = os.environ.get("SS_STEM_HALVES", "1") != "0"      # concat_stem's broadcast half by linearity
+    PAIR_VIEWS = os.environ.get("SS_PAIR_VIEWS", "1") != "0"           # concat_feature on both views in one pair of launches
     GWC_PATCH_FUSED = os.environ.get("SS_GWC_PATCH_FUSED", "1") != "0"  # gwc volume -> patch -> gate in one kernel
     #: where the second stream's work (the matching branch's 2-D convolutions and gate) is released: "start" = with the attention
     #: branch (r01-r03), or after a layer of hourglass_att ("c2", "c3", "c4", "att", "u5").  r04: released at the start it ran beside
@@ -223,14 +224,28 @@ class HotSegment(nn.Module):
                     z = M.run_conv2d(cf, "cf1", cf[1], None, y, False)
                     return z if z is not None else cf[1](y)
             return cf(x)
-        # one pair of launches per view: batching the two views needed a 34 MB torch.cat in front (28 us of ATen copy)
-        return {"cl": lambda: one_view(fl4), "cr": lambda: one_view(fr4),
+        def both_views():
+            # r05: the two views in ONE pair of launches -- the first layer reads both inputs through two pointers
+            # (ss_conv2d_bf16s_pair_fwd: no torch.cat in front, which was 28 us of ATen copy), the second is a plain batch-2B call
+            if (len(cf) == 2 and isinstance(cf[1], nn.Conv2d) and isinstance(getattr(cf[0], "conv", None), nn.Conv2d)
+                    and getattr(cf[0], "relu", False) and M._inference(cf, fl4, fr4) and HotSegment.PAIR_VIEWS):
+                bn = cf[0].bn if getattr(cf[0], "use_bn", True) else None
+                y = M.run_conv2d_pair(cf[0], "bc2d", cf[0].conv, bn, fl4, fr4, True)
+                if y is not None:
+                    z = M.run_conv2d(cf, "cf1", cf[1], None, y, False)
+                    if z is not None:
+                        n = fl4.shape[0]
+                        return z[:n], z[n:]
+            return None
+        return {"cl": lambda: one_view(fl4), "cr": lambda: one_view(fr4), "clr": both_views,
                 "gate": lambda: self.concat_feature_att_4.logits(fl4, sigmoid=True)}
 
     def matching_prelude(self, fl4, fr4):
         """The three jobs of prelude_jobs, in order, on the current stream -> (cl, cr, gate4)."""
         jobs = HotSegment.prelude_jobs(self, fl4, fr4)
-        return jobs["cl"](), jobs["cr"](), jobs["gate"]()
+        both = jobs["clr"]()
+        cl, cr = both if both is not None else (jobs["cl"](), jobs["cr"]())
+        return cl, cr, jobs["gate"]()
 
     def matching_branch(self, fl4, fr4, att_topk, samples, prelude=None):
         fast = getattr(self, "FUSED", HotSegment.FUSED) and M._inference(self, fl4, fr4, dfr.real(att_topk))
@@ -306,6 +321,13 @@ def run_segment(owner, fl4, fr4, fl8, fr8, matching=True):
                 return
             side.wait_stream(cur)
             with torch.cuda.stream(side):
+                if "cl" in todo and "cr" in todo:              # both views released together: one pair of launches for the two
+                    both = jobs["clr"]()
+                    if both is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        released["cl"], released["cr"] = _Pending(both[0], ev, cur), _Pending(both[1], ev, cur)
+                        todo = [k for k in todo if k not in ("cl", "cr")]
                 for k in todo:
                     t = jobs[k]()
                     ev = torch.cuda.Event()

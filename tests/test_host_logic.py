@@ -214,3 +214,43 @@ extern "C" __global__ void probe_plain(const float* t, float half_w, float* out)
     assert "v_mul_f32" in rn and "v_floor_f32" in rn and "v_sub_f32" in rn, rn
     assert "v_fma_f32" not in rn and "v_fmac_f32" not in rn, rn
     assert "v_fma_f32" in plain or "v_fmac_f32" in plain, plain
+
+
+def test_cache_generation_and_retained_entries():
+    """engine._ParamCache: every build bumps cache_generation(); while a multi-stream caller retains replaced entries
+    they are parked, not dropped, until drop_retired() -- what PairPipeline relies on to notice a rebuild inside a lane and to
+    keep the replaced tensors alive for the pairs in flight on the other lanes."""
+    import torch
+    from semstereo_amd import engine as E
+    c = E._ParamCache()
+    w = torch.ones(3)
+    g0 = E.cache_generation()
+    a = c.get("k", [w], lambda: w * 2)
+    assert E.cache_generation() == g0 + 1 and c.get("k", [w], lambda: None) is a and E.cache_generation() == g0 + 1
+    w.mul_(2.0)                                     # in-place update: the version stamp changes
+    E.retain_replaced(True)
+    try:
+        b = c.get("k", [w], lambda: w * 2)
+        assert E.cache_generation() == g0 + 2 and b is not a
+        assert any(old[1] is a for old in E._RETIRED), "the replaced entry must stay alive while retained"
+        E.drop_retired()
+        assert not E._RETIRED
+    finally:
+        E.retain_replaced(False)
+    w.mul_(2.0)
+    c.get("k", [w], lambda: w * 2)
+    assert not E._RETIRED                           # nobody retains: replaced entries are simply dropped
+
+
+def test_overlap_override_is_per_thread_and_never_touches_the_module():
+    import threading
+    from semstereo_amd import segment
+    seen = {}
+
+    def other():
+        seen["other"] = getattr(segment._TLS, "overlap", None)
+    with segment.overlap_override(False):
+        t = threading.Thread(target=other); t.start(); t.join()
+        seen["mine"] = segment._TLS.overlap
+    assert seen == {"other": None, "mine": False} and getattr(segment._TLS, "overlap", None) is None
+    assert "OVERLAP" not in segment.HotSegment(64).__dict__

@@ -797,6 +797,35 @@ def test_conv2d_split_bf16(sa, case, nterms):
     assert e <= (1e-5 if nterms != 3 else 4e-5), (e, e_t)
 
 
+@pytest.mark.parametrize("shape", [(1, 128, 64, 64, 96), (2, 64, 32, 9, 37), (1, 128, 64, 256, 256)])
+def test_conv2d_on_both_views_in_one_launch(sa, shape):
+    """ss_conv2d_bf16s_pair_fwd (concat_feature on the left and the right view, models/SemStereo.py:314-315): the launch that reads
+    its batch from two tensors equals the two single-view launches -- element for element where the batch does not change the
+    tile, to 2e-6 where it does (the block-floating scale is per tile) -- and is as close to float64."""
+    if sa.modules.CONV_ENGINE == "f32":
+        pytest.skip("the 2-D layers run on the split engines")
+    import torch.nn.functional as F
+    import torch.nn as nn
+    from oracle import detdata as dd
+    B, Cin, Cout, H, W = shape
+    xa, xb = dd.t_normalish((B, Cin, H, W), 591), dd.t_normalish((B, Cin, H, W), 592) * 2.0
+    conv = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False).cuda().eval()
+    bn = nn.BatchNorm2d(Cout).cuda().eval()
+    with torch.no_grad():
+        conv.weight.copy_(dev(dd.t_uniform((Cout, Cin, 3, 3), 593, -1, 1) * (3.0 / (Cin * 9)) ** 0.5))
+        bn.weight.copy_(dev(dd.t_uniform((Cout,), 594, 0.6, 1.4))); bn.bias.copy_(dev(dd.t_uniform((Cout,), 595, -0.1, 0.1)))
+        bn.running_var.copy_(dev(dd.t_uniform((Cout,), 596, 0.6, 1.4)))
+        y = sa.engine.run_conv2d_pair(conv, "t", conv, bn, dev(xa), dev(xb), True)
+        ya = sa.engine.run_conv2d(conv, "t", conv, bn, dev(xa), True)
+        yb = sa.engine.run_conv2d(conv, "t", conv, bn, dev(xb), True)
+    assert y is not None and y.shape == (2 * B, Cout, H, W)
+    assert float((y[:B] - ya).abs().max()) <= 2e-6 and float((y[B:] - yb).abs().max()) <= 4e-6
+    sc, sh = sa.modules.fold_bn(bn)
+    ref = F.relu(F.conv2d(torch.cat((xa, xb)).double(), conv.weight.detach().cpu().double(), None, 1, 1) * sc.cpu().double().reshape(1, -1, 1, 1)
+                 + sh.cpu().double().reshape(1, -1, 1, 1))
+    assert float((y.double().cpu() - ref).abs().max()) <= 1e-5
+
+
 BF16S_CASES = [
     # (Cin, Cout, D, H, W, relu, residual)
     (32, 32, 5, 9, 37, True, False),
@@ -887,6 +916,7 @@ _NON_DEFAULT = {
     "SS_STEM_LEFT_FUSED=0": ("engine", "STEM_LEFT_FUSED", False),
     "SS_STEM_PRESPLIT=1": ("engine", "STEM_PRESPLIT", True),      # (with the gathered stem off: it has precedence)
     "SS_STEM_GATHER=0": ("engine", "STEM_GATHER", False),
+    "SS_PAIR_VIEWS=0": ("segment.HotSegment", "PAIR_VIEWS", False),
     "SS_ATTENTION=fused": ("engine", "ATTENTION_FORM", "fused"),
     "SS_HEAD_F16=1": ("engine", "HEAD_F16", True),
     "SS_DECONV_F16=0": ("engine", "DECONV_F16", False),
@@ -2026,7 +2056,7 @@ def test_hot_segment_whu_vs_reference_fixture(sa, golden, name, fused, deferral_
         # the statement-by-statement form: the deferred handles recognise the WHU variant's text too (:279 maxdisp//4 planes,
         # :305 no offset -> candidates are the plane indices) and run the same fused kernels on the unsigned ranges
         assert set(dfr.STATS["fused"]) == {"gwc_patch_gate", "upsample_softmax_regression", "sample_strength", "topk_candidates",
-                                            "stem_by_halves"}, dfr.STATS
+                                            "stem_by_halves", "concat_feature_pair"}, dfr.STATS
     g = golden["segment_whu"]
     assert float(r["samples"].min()) >= 0 and float(r["samples"].max()) < maxdisp // 4
     check(f"whu/{name}/{fused}/pred_att0", r["pred_att0"], g[f"{name}/pred_att0"], 1e-3)
