@@ -908,13 +908,13 @@ def main():
                     parity["reference_picks_restored"] = {k_: rp[k_] for k_ in (
                         "epe_vs_reference_fullres_px", "max_err_off_ties_px", "pixels_beyond_1e-3", "hip_vs_truth_epe_off_ties_px",
                         "reference_vs_truth_epe_off_ties_px", "hip_vs_truth_max_off_ties_px", "reference_vs_truth_max_off_ties_px")}
-                plain = [pvs[n_]["epe_vs_reference_fullres_px"] for n_ in names]
-                restored = [(pvs[n_].get("reference_picks_restored") or {}).get("epe_vs_reference_fullres_px") for n_ in names]
+                epe_plain = [pvs[n_]["epe_vs_reference_fullres_px"] for n_ in names]
+                epe_rest = [(pvs[n_].get("reference_picks_restored") or {}).get("epe_vs_reference_fullres_px") for n_ in names]
                 parity["fixtures_1024"] = {
                     "names": [n_.replace("f1024_md128_", "") for n_ in names],
-                    "epe_vs_reference_fullres_px": plain, "mean": sum(plain) / len(plain),
-                    "picks_restored_epe_fullres_px": restored,
-                    "picks_restored_mean": (sum(restored) / len(restored)) if all(r_ is not None for r_ in restored) else None,
+                    "epe_vs_reference_fullres_px": epe_plain, "mean": sum(epe_plain) / len(epe_plain),
+                    "picks_restored_epe_fullres_px": epe_rest,
+                    "picks_restored_mean": (sum(epe_rest) / len(epe_rest)) if all(r_ is not None for r_ in epe_rest) else None,
                     "pixels_with_other_candidates": [pvs[n_]["pixels_with_other_candidates"] for n_ in names]}
             except Exception as e:       # noqa: BLE001
                 parity["reference_fixture_error"] = repr(e)

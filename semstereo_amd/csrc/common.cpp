@@ -14,7 +14,7 @@ thread_local char g_last_error[256] = "";
 int env_int(const char* name) {            // -1: unset; otherwise its integer value (a set but non-numeric variable: 1)
     const char* v = getenv(name);
     if (v == nullptr) return -1;
-    return (v[0] >= '0' && v[0] <= '9') ? atoi(v) : 1;
+    return ((v[0] >= '0' && v[0] <= '9') || (v[0] == '-' && v[1] >= '0' && v[1] <= '9')) ? atoi(v) : 1;      // ("-1": as if unset)
 }
 
 ss::Tuning read_tuning() {

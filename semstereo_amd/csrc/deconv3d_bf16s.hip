@@ -57,6 +57,11 @@ constexpr int KST = 27;           // K-steps per 16-channel chunk
 // hourglass2.conv6 (201 MB written, alone): 128 -> 108 us; sc0 + nt the same; nontemporal loads of the skip tensor 119, both 124
 // (profiles/r05_f_deconv_forms.txt).  The launcher streams outputs of >= 192 MB per launch (the rule of the gwc volume kernel:
 // smaller outputs are handed to the next kernel by the 256 MB Infinity Cache); SS_DECONV_STREAM=0/1 forces it.
+#ifndef SS_DECONV_SKIP_PIPE
+#define SS_DECONV_SKIP_PIPE 0     // 1: skip projection after the main loop with the next batch's loads ahead of this batch's MFMAs (two register buffers).
+                                  // Measured r05 (tools/build_variant.sh): 111.9 / 55.3 / 38.8 us against 109.8 / 55.0 / 38.5 without -- the skip reads are
+                                  // not a per-wave latency problem (the chip's workgroups load together, then compute together); off
+#endif
 #ifndef SS_DECONV_SKIP_AUX
 #define SS_DECONV_SKIP_AUX 0      // ... of the skip tensor's loads
 #endif
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
     for (int p = 0; p < NA; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-    auto skip_phase = [&]() {
+    auto skip_phase = [&](bool pipelined) {
 #ifdef SS_EXP_DECONV_NOSKIP           // (timing experiment, wrong results)
         return;
 #endif
@@ -254,31 +259,24 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
             const_cast<uint4*>(skip_wsplit), 0, nks * swstep, 0x00020000);
         const unsigned lane_s = (unsigned)(((size_t)(2 * jd_) * out_plane + (size_t)(2 * jh_) * Wo + 2 * jw_) * 4);
         const unsigned schan_b = (unsigned)(schan * 4);
-#pragma unroll 1
-        for (int ks = 0; ks < nks; ++ks) {
-            bf16x8 a[SNC];
+        // one batch = two (pd, ph) rows of the cube x 8 channels of this lane's half: 16 eight-byte loads (32 registers)
+        auto batch_load = [&](float2 (&v)[2][8], int ks, auto q0_tag, unsigned dead) {
+            constexpr int q0 = decltype(q0_tag)::value;
 #pragma unroll
-            for (int c = 0; c < SNC; ++c)
-                a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * swstep + c * 2 * Cout * 16, 0));
-            // all 32 eight-byte loads of the K-step first, then the arithmetic: ONE exposed round trip to memory per 16 skip
-            // channels (interleaved by the compiler, each of the four (pd, ph) groups waited for its own 8 loads: four)
-            // (r03: in TWO batches of 16 -- all 32 at once left the kernel 2 VGPRs short: 12 bytes of scratch per lane)
-#pragma unroll
-            for (int q0 = 0; q0 < GP::NQ2; q0 += 2) {
-            float2 v[GP::NQ2][8];
-#pragma unroll
-            for (int q = q0; q < q0 + 2; ++q) {            // row q of the group = (pd, ph); the float2 holds pw = 0, 1
-                const unsigned qo = (unsigned)(((size_t)(GP::q(q) >> 1) * out_plane + (size_t)(GP::q(q) & 1) * Wo) * 4);
+            for (int q = 0; q < 2; ++q) {                  // row q0 + q of the group = (pd, ph); the float2 holds pw = 0, 1
+                const unsigned qo = (unsigned)(((size_t)(GP::q(q0 + q) >> 1) * out_plane + (size_t)(GP::q(q0 + q) & 1) * Wo) * 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int cs = ks * 16 + 8 * half + j;     // channels beyond Cs: a clamped (valid) address, value zeroed
                     v[q][j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
-                                                             sres, (int)(lane_s + qo + (unsigned)min(cs, Cs - 1) * schan_b), 0, SS_DECONV_SKIP_AUX));
+                                                             sres, (int)((lane_s + qo + (unsigned)min(cs, Cs - 1) * schan_b) | dead), 0, SS_DECONV_SKIP_AUX));
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto batch_mfma = [&](float2 (&v)[2][8], int ks, auto q0_tag, const bf16x8 (&a)[SNC]) {
+            constexpr int q0 = decltype(q0_tag)::value;
 #pragma unroll
-            for (int q = q0; q < q0 + 2; ++q) {
+            for (int q = 0; q < 2; ++q) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (ks * 16 + 8 * half + j >= Cs) v[q][j] = make_float2(0.f, 0.f);
@@ -290,7 +288,7 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
                         split3_pk(pw ? v[q][2 * c].y : v[q][2 * c].x, pw ? v[q][2 * c + 1].y : v[q][2 * c + 1].x, bh[c], bm[c], bl[c]);
                     const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
                     const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
-                    const int cls = q * 2 + pw;
+                    const int cls = (q0 + q) * 2 + pw;
                     if (SNT == 6) {
                         const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
                         acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], m8, acc[cls], 0, 0, 0);
@@ -302,6 +300,50 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
                     acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], h8, acc[cls], 0, 0, 0);
                 }
             }
+        };
+        using Q0 = std::integral_constant<int, 0>;
+        using Q2 = std::integral_constant<int, 2>;
+        if constexpr (GP::NQ2 == 4) {
+            if (pipelined) {
+                // AFTER the main loop the chunk prefetch registers and the fragment rings are dead: the next batch's 16 loads are
+                // issued before the current batch's arithmetic (two buffers, 64 registers), so that a wave has 16 KB in flight under
+                // its 24 MFMAs instead of 8 KB and then nothing -- one exposed round trip per workgroup instead of 2 per 16 channels
+                float2 va[2][8], vb[2][8];
+                batch_load(va, 0, Q0{}, 0u);
+#pragma unroll 1
+                for (int ks = 0; ks < nks; ++ks) {
+                    bf16x8 a[SNC];
+#pragma unroll
+                    for (int c = 0; c < SNC; ++c)
+                        a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * swstep + c * 2 * Cout * 16, 0));
+                    batch_load(vb, ks, Q2{}, 0u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    batch_mfma(va, ks, Q0{}, a);
+                    __builtin_amdgcn_sched_barrier(0);
+                    batch_load(va, min(ks + 1, nks - 1), Q0{}, ks + 1 < nks ? 0u : 0x80000000u);      // (past the end: beyond the buffer, no access)
+                    __builtin_amdgcn_sched_barrier(0);
+                    batch_mfma(vb, ks, Q2{}, a);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
+        }
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            bf16x8 a[SNC];
+#pragma unroll
+            for (int c = 0; c < SNC; ++c)
+                a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * swstep + c * 2 * Cout * 16, 0));
+            // all 16 eight-byte loads of a batch first, then its arithmetic: one exposed round trip per batch (interleaved by the
+            // compiler, each (pd, ph) row waited for its own 8 loads)
+            float2 v[2][8];
+            batch_load(v, ks, Q0{}, 0u);
+            __builtin_amdgcn_sched_barrier(0);
+            batch_mfma(v, ks, Q0{}, a);
+            if constexpr (GP::NQ2 == 4) {
+                batch_load(v, ks, Q2{}, 0u);
+                __builtin_amdgcn_sched_barrier(0);
+                batch_mfma(v, ks, Q2{}, a);
             }
         }
     };
@@ -312,7 +354,7 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
     // spread the phases)
     const bool skip_first = !SPLIT && HAS_SKIP && ((unit ^ blockIdx.y) & 1);
     if (HAS_SKIP && skip_first) {
-        skip_phase();
+        skip_phase(false);
         if (F16) {      // the main loop's accumulators carry the channel's weight scale (a power of two: exact)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -494,7 +536,7 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
         }
     }
 
-    if (HAS_SKIP && !skip_first) skip_phase();
+    if (HAS_SKIP && !skip_first) skip_phase(SS_DECONV_SKIP_PIPE != 0);
 
     // ---- epilogue: each lane owns the 2x2x2 output cube of its input position.  Buffer stores: a 32-bit per-lane offset
     // per (plane, row) pair of the cube (positions outside the volume parked beyond the buffer: the store is dropped) and
