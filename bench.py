@@ -797,7 +797,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         # what `value` is: throughput with `lanes_in_flight` pairs in flight on the GPU at once -- NOT the latency of a
         # pair, and not the one-call-at-a-time rate of rounds 1-3 (that one is rates.single_stream_pairs_per_s, same K steps)
-        "value_kind": (f"throughput, {args.streams} pairs in flight (PairPipeline lanes)" if pipelined else "throughput, one call at a time"),
+        "value_kind": (f"throughput, {args.streams} pairs in flight" if pipelined else "throughput, one call at a time"),
         "lanes_in_flight": args.streams if pipelined else 1,
         "config": {"workload": f"BASELINE.json {cfg_name}: {H}x{W} tile, maxdisp={maxdisp}, batch={B} per GPU x {world} GPU(s), features "
                                "[B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity [B,1,H/4,W/4]",
@@ -913,7 +913,6 @@ def main():
                 parity["fixtures_1024"] = {
                     "names": [n_.replace("f1024_md128_", "") for n_ in names],
                     "epe_vs_reference_fullres_px": epe_plain, "mean": sum(epe_plain) / len(epe_plain),
-                    "picks_restored_epe_fullres_px": epe_rest,
                     "picks_restored_mean": (sum(epe_rest) / len(epe_rest)) if all(r_ is not None for r_ in epe_rest) else None,
                     "pixels_with_other_candidates": [pvs[n_]["pixels_with_other_candidates"] for n_ in names]}
             except Exception as e:       # noqa: BLE001
