@@ -550,7 +550,7 @@ def main():
     ap.add_argument("--engine", default=None, help="conv engine of the timed run: f32 | bf16x6 | bf16x3 | f16x3 "
                                                    "(default: semstereo_amd.modules.CONV_ENGINE)")
     ap.add_argument("--input-sets", type=int, default=3, help="distinct synthetic input sets rotated through the timed loop")
-    ap.add_argument("--streams", type=int, default=4, help="consecutive steps are issued round-robin on this many HIP streams "
+    ap.add_argument("--streams", type=int, default=6, help="consecutive steps are issued round-robin on this many HIP streams "
                     "(semstereo_amd.PairPipeline; 1: every step on the calling stream, which is ALSO timed and reported as single_stream)")
     ap.add_argument("--pipelined-only", action="store_true", help="profiling aid: skip the single-stream leg (no per-kernel timers, no roofline)")
     ap.add_argument("--steady-seconds", type=float, default=1.0, help="length of the steady-state leg after the K timed steps (0: skip)")

@@ -594,7 +594,10 @@ STEM_GATHER = os.environ.get("SS_STEM_GATHER", "1") != "0"
 def stem_gather_applies(stem, right, samples):
     return (STEM_GATHER and CONV_ENGINE == "f16x3" and right.shape[1] % 8 == 0 and right.shape[1] >= 16
             and stem.conv.in_channels == 2 * right.shape[1] and _conv_geometry(stem.conv) == (3, 1)
-            and right.dtype == torch.float32 and samples.dtype == torch.float32)
+            and right.dtype == torch.float32 and samples.dtype == torch.float32
+            # (a one-row or one-column map: the reference's coordinate normalisation divides by (H - 1) / 2 = 0 and its warp is NaN,
+            # models/submodule.py:274-279 -- the warp kernel reproduces that, the gather would not)
+            and right.shape[-1] > 1 and right.shape[-2] > 1)
 
 
 def stem_gather_half(stem, right, samples, att, partial, gate=None):

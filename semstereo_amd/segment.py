@@ -384,7 +384,8 @@ class PairPipeline:
     batching, no change to what a call computes: every pair runs the same kernels on its own buffers, so its outputs are bit-identical
     to a plain call (tests/test_parity_gpu.py::test_pair_pipeline_is_bit_identical_to_sequential_calls).  Measured r04 (bench.py
     --streams): batch 1: 497 -> 528 / 531 / 542 / 538 pairs/s on 2 / 3 / 4 / 6 lanes; batch 4: 535 -> 561 (3 lanes); batch 8: 543 -> 560;
-    2048^2 / 192: 120 -> 126.  Inference only.
+    2048^2 / 192: 120 -> 126.  r05 (gathered stem): 2 / 3 / 4 / 5 / 6 / 8 lanes 567 / 551 / 570 / 578 / 580 / 575; interleaved 4 vs 6:
+    567.2 / 562.5 / 563.5 vs 572.9 / 571.8 / 574.1 (batch 8: 589.7 / 588.9 vs 592.7 / 590.4) -> default 6.  Inference only.
 
     `pipe(*inputs)` returns the module's output at once; the tensors are valid after `pipe.synchronize()`, or on another stream
     after `pipe.join(outputs, stream)` (waits for the call's event AND records the consumer stream on the outputs: they live in the
@@ -392,7 +393,7 @@ class PairPipeline:
     module -- a HotSegment (`pipe(fl4, fr4, fl8, fr8)`) or a whole reference model after `install` + `accelerate`
     (`pipe(imgL, imgR)`: its backbone's kernels ride the lanes too)."""
 
-    def __init__(self, segment, lanes=4):
+    def __init__(self, segment, lanes=6):
         assert lanes >= 1 and not segment.training
         self.segment, self.nlanes = segment, int(lanes)
         self.lanes, self.turn, self.last_event, self._primed = None, 0, None, False

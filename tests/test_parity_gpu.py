@@ -682,6 +682,68 @@ def test_stem_gathers_the_warped_half_in_its_staging(sa, shape, gated):
     assert float((y_g0 - y_30).abs().max()) <= 2e-4
 
 
+def test_gathered_stem_is_only_taken_for_integer_candidates(sa, monkeypatch):
+    """The precondition of ss_conv3d_gather_fwd is checked, not assumed: candidates produced by topk_candidates carry the mark,
+    any other tensor is verified on the device; FRACTIONAL candidates (a caller of SpatialTransformer_grid may pass anything,
+    models/submodule.py:265-288 is bilinear) keep the warp launch -- the matching branch then gives, bit for bit, what it gives
+    with the gathered stem switched off."""
+    if sa.modules.CONV_ENGINE != "f16x3":
+        pytest.skip("the gathered stem exists for the f16x3 engine")
+    from oracle import detdata as dd
+    seg, _ = _segment(sa, 64)
+    fl8, fr8 = dd.stereo_features(1, 256, 16, 24, 770, max_shift=3)
+    fl4, fr4 = dd.stereo_features(1, 128, 32, 48, 771, max_shift=6)
+    with torch.no_grad():
+        r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
+        assert getattr(r["samples"], "_ss_integer", False) is True
+        whole = r["samples"].clone()                                   # an unmarked copy: verified on the device
+        assert sa.ops.integer_candidates(whole) is True and whole._ss_integer is True
+        frac = r["samples"] + 0.25
+        assert sa.ops.integer_candidates(frac) is False
+        calls = []
+        real_gather = sa.modules.stem_gather_half
+        monkeypatch.setattr(sa.modules, "stem_gather_half", lambda *a, **k: (calls.append(1), real_gather(*a, **k))[1])
+        p_int = seg.matching_branch(dev(fl4), dev(fr4), r["att_topk"], whole)
+        assert len(calls) == 1 and torch.equal(p_int, r["pred"])
+        p_frac = seg.matching_branch(dev(fl4), dev(fr4), r["att_topk"], frac)
+        assert len(calls) == 1, "fractional candidates must not reach the gather"
+        monkeypatch.setattr(sa.engine, "STEM_GATHER", False)
+        p_frac_3 = seg.matching_branch(dev(fl4), dev(fr4), r["att_topk"], frac)
+    assert torch.equal(p_frac, p_frac_3)
+
+
+def test_gathered_stem_on_degenerate_shapes(sa):
+    """Edge cases of the gather: a two-row image, an image narrower than the 32-column tile, every candidate pointing outside the
+    image (the operand is all zeros: the result is the partial sum through BatchNorm / ReLU / gate), candidates at +-(W - 1)."""
+    if sa.modules.CONV_ENGINE != "f16x3":
+        pytest.skip("the gathered stem exists for the f16x3 engine")
+    from oracle import detdata as dd
+    C = 32
+    stem = sa.modules.BasicConv(2 * C, C, is_3d=True, kernel_size=3, stride=1, padding=1)
+    with torch.no_grad():
+        stem.conv.weight.copy_(dd.t_uniform((C, 2 * C, 3, 3, 3), 346, -1, 1) * (3.0 / (2 * C * 27)) ** 0.5)
+    stem = stem.cuda().eval()
+    # (H = 1: the reference's own warp is NaN there -- division by (H - 1) / 2 -- and the three-launch form keeps reproducing it)
+    assert not sa.modules.stem_gather_applies(stem, torch.zeros(1, C, 1, 70, device="cuda"), torch.zeros(1, 24, 1, 70, device="cuda"))
+    for (B, nd, H, W, lo, hi) in ((1, 24, 2, 70, -40, 40), (2, 6, 5, 9, -8, 9), (1, 24, 6, 40, 41, 90), (1, 4, 3, 33, -32, 33)):
+        cr = dd.t_normalish((B, C, H, W), 347)
+        g = torch.Generator().manual_seed(348)
+        samples = torch.randint(lo, hi, (B, nd, H, W), generator=g).float().sort(dim=1).values
+        att = dd.t_uniform((B, 1, nd, H, W), 349, 0.0, 1.0)
+        partial = dd.t_normalish((B, C, nd, H, W), 350)
+        gate = torch.sigmoid(dd.t_normalish((B, C, H, W), 351))
+        with torch.no_grad():
+            y = sa.modules.stem_gather_half(stem, dev(cr), dev(samples), dev(att), dev(partial), dev(gate))
+            vol = sa.ops.concat_volume_sampled(None, dev(cr), dev(samples), dev(att))
+            y3 = sa.modules.stem_volume_half(stem, vol, dev(partial), dev(gate))
+        assert float((y - y3).abs().max()) <= 2e-4, (B, nd, H, W)
+        if lo > W:                                               # nothing inside the image: exactly the partial sum's path
+            assert float(vol.abs().max()) == 0.0
+            sc, sh = sa.modules.fold_bn(stem.bn)
+            want = dev(gate).unsqueeze(2) * torch.relu(dev(partial) * sc.reshape(1, -1, 1, 1, 1) + sh.reshape(1, -1, 1, 1, 1))
+            assert float((y - want).abs().max()) <= 1e-6
+
+
 HEAD_CASES = [
     # (B, Cin, D, H, W, relu): the 32 -> 1 classifier heads; W not a multiple of 30, both tile shapes, tiny volumes
     (2, 32, 5, 9, 37, False),
