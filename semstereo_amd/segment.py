@@ -95,7 +95,9 @@ class HotSegment(nn.Module):
     #: convs, the right-view convs and the gate their own points (also "cls" / "up" / "st": after classif_att_, the soft-argmax,
     #: the probe); each result is joined where the matching branch first needs it.  Releasing the later two later did not pay
     #: (another box): c4 464.8, "c4,c4,st" 464.8, "c4,cls,st" 461.7, "c4,cls,cls" 462.1, "c4,up,st" 449.5, "att,st,st" 448.3.
-    PRELUDE_AT = os.environ.get("SS_PRELUDE_AT", "c4")
+    #: r05 (the two views in one pair of launches, 110 instead of 173 us of side work; profiles/r05_o_prelude_at.txt, one stream, two sweeps):
+    #: start 519.1 / 519.1, c2 528.1 / 527.3, c3 523.8 / 523.9, c4 523.4 / 523.1, att 521.5 / 520.6, u5 522.3 / 522.5 -> c2.
+    PRELUDE_AT = os.environ.get("SS_PRELUDE_AT", "c2")
 
     def __init__(self, maxdisp, c8=256, c4=128, unsigned=False):
         """unsigned=False: models/SemStereo.py (disparities [-maxdisp, maxdisp), op set models/submodule.py);

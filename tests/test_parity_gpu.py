@@ -972,6 +972,7 @@ _NON_DEFAULT = {
     "SS_FUSED=0": ("segment.HotSegment", "FUSED", False),
     "SS_PRELUDE_AT=start": ("segment.HotSegment", "PRELUDE_AT", "start"),
     "SS_PRELUDE_AT=u5": ("segment.HotSegment", "PRELUDE_AT", "u5"),
+    "SS_PRELUDE_AT=c4": ("segment.HotSegment", "PRELUDE_AT", "c4"),
     "SS_PRELUDE_AT=c2,cls,st": ("segment.HotSegment", "PRELUDE_AT", "c2,cls,st"),
     "SS_GWC_PATCH_FUSED=0": ("segment.HotSegment", "GWC_PATCH_FUSED", False),
     "SS_STEM_HALVES=0": ("segment.HotSegment", "STEM_BY_HALVES", False),
