@@ -522,22 +522,28 @@ def topk_candidates(att_weights, strength, maxdisp, k, _range=None):
     with torch.cuda.device(dev):
         call("ss_topk_candidates_fwd", ptr(att_weights), ptr(strength), ptr(samples), ptr(att_topk), ptr(pred_att),
              B, dmin, nd, H, W, int(k))
-    samples._ss_integer = True           # (index - offset) of :305: integer-valued, see integer_candidates()
+    _mark_integer(samples, True)         # (index - offset) of :305: integer-valued, see integer_candidates()
     return att_topk, samples, pred_att
+
+
+def _mark_integer(samples, verdict):
+    # the verdict is tied to the tensor's version counter: an in-place update afterwards (samples.add_(0.5)) voids it
+    samples._ss_integer = (bool(verdict), samples._version)
 
 
 def integer_candidates(samples):
     """True when every disparity candidate of `samples` is an integer -- the precondition of the gathered stem
     (ss_conv3d_gather_fwd).  The candidates of topk_candidates carry a mark and cost nothing; any other tensor is checked on
-    the device once (one reduction + a host sync) and then carries the verdict."""
+    the device once (one reduction + a host sync) and then carries the verdict for as long as it is not modified in place."""
     mark = getattr(samples, "_ss_integer", None)
-    if mark is None:
-        mark = bool(torch.equal(samples, torch.trunc(samples)))
-        try:
-            samples._ss_integer = mark
-        except Exception:
-            pass
-    return mark
+    if mark is not None and mark[1] == samples._version:
+        return mark[0]
+    verdict = bool(torch.equal(samples, torch.trunc(samples)))
+    try:
+        _mark_integer(samples, verdict)
+    except Exception:       # noqa: BLE001  (an object that takes no attributes: checked again next time)
+        pass
+    return verdict
 
 
 def channel_gate(att_logits, cv):

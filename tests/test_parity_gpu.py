@@ -695,11 +695,17 @@ def test_gathered_stem_is_only_taken_for_integer_candidates(sa, monkeypatch):
     fl4, fr4 = dd.stereo_features(1, 128, 32, 48, 771, max_shift=6)
     with torch.no_grad():
         r = seg(dev(fl4), dev(fr4), dev(fl8), dev(fr8))
-        assert getattr(r["samples"], "_ss_integer", False) is True
+        assert r["samples"]._ss_integer == (True, r["samples"]._version)
         whole = r["samples"].clone()                                   # an unmarked copy: verified on the device
-        assert sa.ops.integer_candidates(whole) is True and whole._ss_integer is True
+        assert sa.ops.integer_candidates(whole) is True and whole._ss_integer[0] is True
         frac = r["samples"] + 0.25
         assert sa.ops.integer_candidates(frac) is False
+        moved = r["samples"].clone()
+        assert sa.ops.integer_candidates(moved) is True
+        moved.add_(0.5)                                                # in place: the earlier verdict must not survive
+        assert sa.ops.integer_candidates(moved) is False
+        moved.sub_(0.5)
+        assert sa.ops.integer_candidates(moved) is True
         calls = []
         real_gather = sa.modules.stem_gather_half
         monkeypatch.setattr(sa.modules, "stem_gather_half", lambda *a, **k: (calls.append(1), real_gather(*a, **k))[1])
