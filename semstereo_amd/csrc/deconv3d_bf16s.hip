@@ -397,9 +397,14 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
         const int ci0 = ck * 16;
         // ---- split + transpose: registers -> [term][half][position] ----
         if (F16) {          // this chunk's weights: wave w issues the (K-step, term) pairs i = w, w + 4, ...; lane -> (half, channel)
+            // (the wave index as a SCALAR made opaque once per chunk: the slab entries' LDS addresses and source offsets are then
+            // scalar arithmetic recomputed here -- as per-lane values they are loop invariants the compiler hoists out of the chunk
+            // loop and, under the register pressure of the class-blocked loop, spills: 130 registers, 112 -> 450 us)
+            int wv = __builtin_amdgcn_readfirstlane(wave);
+            asm volatile("" : "+s"(wv));
 #pragma unroll
             for (int k = 0; k < (NS * 2 + 3) / 4; ++k) {
-                const int i = wave + 4 * k;                    // wave-uniform; slab entry i = (the group's step i / 2, term i & 1)
+                const int i = wv + 4 * k;                      // wave-uniform; slab entry i = (the group's step i / 2, term i & 1)
                 if (i < NS * 2) {
                     const int sg = GRP < 0 ? i / 2 : __builtin_amdgcn_readfirstlane(kGroupSteps.s[GRP < 0 ? 0 : GRP][i / 2]);
                     lds_dma16(wres, &lds[WL + i * 64], wlane, (g0 + sg) * wstep + (i & 1) * 2 * Cout * 16);
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
 #pragma unroll
             for (int c = 0; c < NC; ++c) dst[c] = lds[(c * 2 + half) * C::CS + slot];
         };
+        constexpr int QSG = (NQ + (NS * 20 / 27) - 1) / (NS * 20 / 27);     // the next chunk's loads: over the first ~3/4 of the steps
         read_b(bcur, off_of(GP::T.step[0]));
         if (F16) {
 #pragma unroll
@@ -471,7 +477,6 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tacc[p][r] = 0.f;
         }
-        constexpr int QSG = (NQ + (NS * 20 / 27) - 1) / (NS * 20 / 27);     // the next chunk's loads: over the first ~3/4 of the steps
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int s = GP::T.step[k];                       // (compile-time after unrolling)
