@@ -402,9 +402,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     for (int ci0 = 0, g0 = 0; ci0 < Cin; ci0 += 8, g0 += KSTEPS) {
         // ---- split + transpose: registers -> [term][position][8 ch] ----
         if constexpr (WLDS) {         // this chunk's weights: wave w issues the (K-step, term) pairs i = w, w + 4, ...; lane -> (half, channel)
+            // (the wave index as a scalar, opaque once per chunk: the entries' LDS addresses and source offsets are scalar arithmetic
+            // done here instead of per-lane loop invariants hoisted out of the chunk loop -- deconv3d_bf16s.hip, r05)
+            int wv = __builtin_amdgcn_readfirstlane(wave);
+            asm volatile("" : "+s"(wv));
 #pragma unroll
             for (int k = 0; k < (KSTEPS * 2 + 3) / 4; ++k) {
-                const int i = wave + 4 * k;                    // wave-uniform
+                const int i = wv + 4 * k;                      // wave-uniform
                 if (i < KSTEPS * 2)
                     lds_dma16(wres, &lds[WL + i * 64], wlane[0], (g0 + i / 2) * wstep + (i & 1) * 2 * Cout * 16);
             }
