@@ -403,6 +403,15 @@ int ss_batchnorm_train_res_fwd(const float* x, const float* residual, const floa
 int ss_batchnorm_train_res_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
                                const float* weight, float* grad_x, float* grad_residual, double* work, int B, int C, long long N,
                                int relu, ss_stream_t stream);
+/* BatchNorm on its RUNNING statistics under autograd (a module in eval() whose inputs / parameters require gradients; the reference's
+ * training loop never freezes BatchNorm, main_us3d.py:186-222, PyTorch allows it): forward with the caller's per-channel mean and
+ * invstd = 1 / sqrt(running_var + eps), optional residual (joins before the ReLU) and ReLU; backward: grad_x = w * invstd * g'
+ * (g' = grad_y behind the ReLU mask), grad_residual = g' when not NULL, grad_bias[c] = work[2c], grad_weight[c] = work[2c + 1]. */
+int ss_batchnorm_eval_fwd(const float* x, const float* residual, const float* mean, const float* invstd, const float* weight,
+                          const float* bias, float* y, int B, int C, long long N, int relu, ss_stream_t stream);
+int ss_batchnorm_eval_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                          const float* weight, float* grad_x, float* grad_residual, double* work, int B, int C, long long N,
+                          int relu, ss_stream_t stream);
 /* Weight gradient of the 1x1(x1) convolutions (redir1 / redir2 `models/SemStereo.py:131-132`, attention_block.qkv_3d /
  * final1x1 `models/submodule_other.py:799-800`, channelAtt.im_att `models/SemStereo.py:92-95`):
  * grad_out [B,Cout,npos], in [B,Cin,npos] -> grad_w [Cout,Cin]. */

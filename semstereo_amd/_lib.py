@@ -78,6 +78,8 @@ _SIGNATURES = {
     "ss_batchnorm_train_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],
     "ss_batchnorm_train_res_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, ctypes.c_float, _I, _P],
     "ss_batchnorm_train_res_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],
+    "ss_batchnorm_eval_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],
+    "ss_batchnorm_eval_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],
     "ss_channel_sum_fwd": [_P, _P, _I, _I, ctypes.c_longlong, _P],
     "ss_conv_k1_wgrad_fwd": [_P, _P, _P, _I, _I, _I, ctypes.c_longlong, _P],
     "ss_depthwise_patch_wgrad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

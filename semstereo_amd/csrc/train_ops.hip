@@ -321,6 +321,39 @@ extern "C" int ss_batchnorm_train_res_bwd(const float* grad_y, const float* x, c
     return batchnorm_train_bwd_impl(grad_y, x, y, mean, invstd, weight, grad_x, grad_residual, work, B, C, N, relu, stream);
 }
 
+// ---- BatchNorm on its RUNNING statistics under autograd (a module in eval() whose inputs or parameters need gradients: fine-tuning
+// with frozen statistics; main_us3d.py never does this, PyTorch allows it) ----
+// forward: y = (x - mean) * invstd * w + b [+ residual] [ReLU] with the caller's per-channel mean / invstd (= 1 / sqrt(running_var + eps))
+extern "C" int ss_batchnorm_eval_fwd(const float* x, const float* residual, const float* mean, const float* invstd, const float* weight,
+                                     const float* bias, float* y, int B, int C, long long N, int relu, ss_stream_t stream) {
+    SS_REQUIRE(x && y && mean && invstd && B > 0 && C > 0 && N > 0);
+    const long long total = (long long)B * C * N;
+    const long long blocks = ss::ceil_div_ll(total, 256);
+    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, ss::as_stream(stream), x, residual, mean, invstd, weight, bias, y,
+                       C, N, total, relu);
+    return ss::check_launch();
+}
+// backward: the statistics are constants, so grad_x = w * invstd * g' (g' = grad_y behind the ReLU mask; also grad_residual when asked for),
+// grad_bias[c] = work[2c] = sum g', grad_weight[c] = work[2c + 1] = sum g' * xhat -- the batch-statistics backward without its two mean terms
+extern "C" int ss_batchnorm_eval_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                                     const float* weight, float* grad_x, float* grad_residual, double* work, int B, int C, long long N,
+                                     int relu, ss_stream_t stream) {
+    SS_REQUIRE(grad_y && x && mean && invstd && grad_x && work && B > 0 && C > 0 && N > 0 && (y || !relu) && C <= 65535 && B <= 65535);
+    hipStream_t st = ss::as_stream(stream);
+    if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
+    long long per_block;
+    const int gx = reduce_grid(N, per_block);
+    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(gx, C, B), dim3(256), 0, st, grad_y, x, y, mean, invstd, work, C, N, per_block, relu);
+    const long long total = (long long)B * C * N;
+    const long long blocks = ss::ceil_div_ll(total, 256);
+    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    // (an infinite element count zeroes the two mean terms of the apply kernel: sum / count == 0)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x,
+                       grad_residual, C, N, total, (double)INFINITY, relu);
+    return ss::check_launch();
+}
+
 // sums[c] (double) = sum over batch and positions of a[b, c, :]  (bias gradients of the 1x1x1 projections)
 extern "C" int ss_channel_sum_fwd(const float* a, double* sums, int B, int C, long long N, ss_stream_t stream) {
     SS_REQUIRE(a && sums && B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535);

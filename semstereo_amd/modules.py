@@ -122,7 +122,7 @@ class BasicConv(nn.Module):
         else:
             x = T.conv2d_k3(self.conv, x)
         if self.use_bn:
-            x = T.batchnorm_train(self.bn, x, relu=bool(self.relu)) if self.bn.training else (F.relu(self.bn(x)) if self.relu else self.bn(x))
+            x = T.batchnorm_train(self.bn, x, relu=bool(self.relu))      # (train(): batch statistics; eval() under autograd: the running ones, r05)
         elif self.relu:
             x = F.relu(x)
         if gate_logits is not None:
@@ -351,7 +351,7 @@ class hourglass(nn.Module):
         if not _inference(self, x):
             def cbr(seq, t):                       # nn.Sequential(convbn_3d, ReLU): conv -> BatchNorm (batch statistics) -> ReLU fused
                 cb = seq[0]
-                return cb.train_forward(t, relu=True) if isinstance(cb, _ConvBN3d) and cb[1].training else seq(t)
+                return cb.train_forward(t, relu=True) if isinstance(cb, _ConvBN3d) else seq(t)
             conv1 = cbr(self.conv1, x)
             conv2 = cbr(self.conv2, conv1)
             conv3 = cbr(self.conv3, conv2)
@@ -359,9 +359,7 @@ class hourglass(nn.Module):
             # F.relu(self.conv5(conv4) + self.redir2(conv2)), models/SemStereo.py:141-142: the add and the ReLU inside the
             # BatchNorm apply of the transposed conv (forward and backward), not two PyTorch element-wise kernels
             def up(seq, t, skip):
-                if seq[1].training:
-                    return T.batchnorm_train(seq[1], deconv3d_train(seq[0], t), relu=True, residual=skip)
-                return F.relu(seq[1](deconv3d_train(seq[0], t)) + skip)
+                return T.batchnorm_train(seq[1], deconv3d_train(seq[0], t), relu=True, residual=skip)
             conv5 = up(self.conv5, conv4, self.redir2(conv2))
             return up(self.conv6, conv5, self.redir1(x))
         PATH_COUNTS["hip"] += 1

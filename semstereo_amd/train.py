@@ -91,9 +91,50 @@ class _BatchNormTrain(torch.autograd.Function):
         return gx, gw, gb, None, None, gres
 
 
+class _BatchNormEval(torch.autograd.Function):
+    """y = bn(x) [+ residual] [-> ReLU] on the RUNNING statistics with autograd on (a module in eval() whose inputs or parameters
+    need gradients): the statistics are constants of the graph."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean, invstd, relu, residual):
+        x = _c(x)
+        B, C = x.shape[0], x.shape[1]
+        N = x[0, 0].numel()
+        y = torch.empty_like(x)
+        residual = None if residual is None else _c(residual)
+        with torch.cuda.device(x.device):
+            call("ss_batchnorm_eval_fwd", ptr(x), ptr(residual), ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(y), B, C, N, int(relu))
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
+        ctx.relu, ctx.has_bias, ctx.has_res = bool(relu), bias is not None, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, mean, invstd, weight = ctx.saved_tensors
+        g = _c(g)
+        B, C = x.shape[0], x.shape[1]
+        N = x[0, 0].numel()
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if ctx.has_res else None
+        work = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            call("ss_batchnorm_eval_bwd", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(gres), ptr(work),
+                 B, C, N, int(ctx.relu))
+        sums = work.reshape(C, 2)
+        gw = sums[:, 1].float() if weight is not None else None
+        gb = sums[:, 0].float() if ctx.has_bias else None
+        return gx, gw, gb, None, None, None, gres
+
+
 def batchnorm_train(bn, x, relu=False, residual=None):
-    """bn(x) [+ residual] [-> ReLU] for a BatchNorm2d / 3d in train(): batch statistics, running statistics updated as
-    F.batch_norm does."""
+    """bn(x) [+ residual] [-> ReLU] for a BatchNorm2d / 3d under autograd: in train() on batch statistics, running statistics updated
+    as F.batch_norm does; in eval() (frozen statistics, r05) on the running statistics as constants of the graph."""
+    if (_on(x) and isinstance(bn, nn.modules.batchnorm._BatchNorm) and not bn.training and bn.running_mean is not None
+            and x.shape[1] <= 65535):
+        _count("hip_train")
+        with torch.no_grad():
+            invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        return _BatchNormEval.apply(x, bn.weight, bn.bias, bn.running_mean.float(), invstd, relu, residual)
     if not (_on(x) and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training and x.shape[1] <= 65535):
         _count("torch")
         y = bn(x)

@@ -1837,6 +1837,37 @@ def test_training_kernels_vs_float64_autograd(sa):
             lambda x, w, b_, r_: F.relu(F.batch_norm(x, None, None, w, b_, True, 0.0, 1e-5) + r_),
             [dd.t_normalish(shape, 705) * 2 + 0.3, dd.t_uniform((C,), 706, 0.5, 1.5), dd.t_uniform((C,), 707, -0.3, 0.3),
              dd.t_normalish(shape, 708)], 2e-5, f"bn_res{shape}")
+    # BatchNorm in eval() under autograd (r05: frozen running statistics, learnable affine, gradients to the input and the residual):
+    # against F.batch_norm(training=False) in float64; and through batchnorm_train on a module in eval(), which must not move its
+    # running statistics and must not take a PyTorch layer
+    for relu, shape, with_res in ((True, (2, 8, 3, 5, 7), True), (False, (3, 4, 6, 9), False), (True, (1, 32, 4, 16, 20), False)):
+        C = shape[1]
+        rm, rv = dd.t_uniform((C,), 731, -0.4, 0.4), dd.t_uniform((C,), 732, 0.5, 2.0)
+
+        def hip_e(x, w, b_, *r_):
+            inv = torch.rsqrt(dev(rv) + 1e-5)
+            return T._BatchNormEval.apply(x, w, b_, dev(rm), inv, relu, r_[0] if r_ else None)
+
+        def ref_e(x, w, b_, *r_):
+            y_ = F.batch_norm(x, rm.double(), rv.double(), w, b_, False, 0.0, 1e-5)
+            if r_:
+                y_ = y_ + r_[0]
+            return F.relu(y_) if relu else y_
+        ins = [dd.t_normalish(shape, 733) * 2 + 0.3, dd.t_uniform((C,), 734, 0.5, 1.5), dd.t_uniform((C,), 735, -0.3, 0.3)]
+        if with_res:
+            ins.append(dd.t_normalish(shape, 736))
+        run(hip_e, ref_e, ins, 2e-5, f"bn_eval{shape}{relu}")
+        bn = (nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d)(C).cuda().eval()
+        with torch.no_grad():
+            bn.running_mean.copy_(dev(rm)); bn.running_var.copy_(dev(rv))
+        x = dev(dd.t_normalish(shape, 737)).requires_grad_(True)
+        before = dict(sa.modules.PATH_COUNTS)
+        y = T.batchnorm_train(bn, x, relu)
+        assert sa.modules.PATH_COUNTS["torch"] == before["torch"] and sa.modules.PATH_COUNTS["hip_train"] > before.get("hip_train", 0)
+        want = F.relu(bn(x)) if relu else bn(x)
+        assert _rel(y, want) <= 1e-6 and torch.equal(bn.running_mean, dev(rm)) and int(bn.num_batches_tracked) == 0
+        y.sum().backward()
+        assert x.grad is not None and bn.weight.grad is not None and bn.bias.grad is not None
     # 1x1 convolutions: redir (32 -> 32, no bias, 5-D), qkv (128 -> 384, bias), im_att (256 -> 128 on a 2-D map, bias)
     for (cin, cout, shp, bias) in ((32, 32, (2, 3, 6, 9), False), (128, 384, (1, 4, 8, 8), True), (256, 128, (2, 12, 20), True), (64, 32, (1, 7, 5), True)):
         ins = [dd.t_normalish((shp[0], cin) + shp[1:], 711), dd.t_uniform((cout, cin) + (1,) * (len(shp) - 1), 712, -0.2, 0.2)]
