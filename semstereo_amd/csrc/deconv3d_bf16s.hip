@@ -57,14 +57,6 @@ constexpr int KST = 27;           // K-steps per 16-channel chunk
 // hourglass2.conv6 (201 MB written, alone): 128 -> 108 us; sc0 + nt the same; nontemporal loads of the skip tensor 119, both 124
 // (profiles/r05_f_deconv_forms.txt).  The launcher streams outputs of >= 192 MB per launch (the rule of the gwc volume kernel:
 // smaller outputs are handed to the next kernel by the 256 MB Infinity Cache); SS_DECONV_STREAM=0/1 forces it.
-#ifndef SS_DECONV_SKIP_PIPE
-#define SS_DECONV_SKIP_PIPE 0     // 1: skip projection after the main loop with the next batch's loads ahead of this batch's MFMAs (two register buffers).
-                                  // Measured r05 (tools/build_variant.sh): 111.9 / 55.3 / 38.8 us against 109.8 / 55.0 / 38.5 without -- the skip reads are
-                                  // not a per-wave latency problem (the chip's workgroups load together, then compute together); off
-#endif
-#ifndef SS_DECONV_SKIP_MIX
-#define SS_DECONV_SKIP_MIX 0      // 1: nks + 1 populations of workgroups (0 .. nks skip steps before the main loop) instead of two
-#endif
 #ifndef SS_DECONV_SKIP_AUX
 #define SS_DECONV_SKIP_AUX 0      // ... of the skip tensor's loads
 #endif
@@ -247,7 +239,7 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
     for (int p = 0; p < NA; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-    auto skip_phase = [&](bool pipelined, int ks_begin, int ks_end) {       // 16-channel steps [ks_begin, ks_end) of the skip projection
+    auto skip_phase = [&]() {
 #ifdef SS_EXP_DECONV_NOSKIP           // (timing experiment, wrong results)
         return;
 #endif
@@ -306,33 +298,8 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
         };
         using Q0 = std::integral_constant<int, 0>;
         using Q2 = std::integral_constant<int, 2>;
-        if constexpr (GP::NQ2 == 4) {
-            if (pipelined) {
-                // AFTER the main loop the chunk prefetch registers and the fragment rings are dead: the next batch's 16 loads are
-                // issued before the current batch's arithmetic (two buffers, 64 registers), so that a wave has 16 KB in flight under
-                // its 24 MFMAs instead of 8 KB and then nothing -- one exposed round trip per workgroup instead of 2 per 16 channels
-                float2 va[2][8], vb[2][8];
-                batch_load(va, ks_begin, Q0{}, ks_begin < ks_end ? 0u : 0x80000000u);
 #pragma unroll 1
-                for (int ks = ks_begin; ks < ks_end; ++ks) {
-                    bf16x8 a[SNC];
-#pragma unroll
-                    for (int c = 0; c < SNC; ++c)
-                        a[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(swres, wlane, ks * swstep + c * 2 * Cout * 16, 0));
-                    batch_load(vb, ks, Q2{}, 0u);
-                    __builtin_amdgcn_sched_barrier(0);
-                    batch_mfma(va, ks, Q0{}, a);
-                    __builtin_amdgcn_sched_barrier(0);
-                    batch_load(va, min(ks + 1, nks - 1), Q0{}, ks + 1 < ks_end ? 0u : 0x80000000u);   // (past the end: beyond the buffer, no access)
-                    __builtin_amdgcn_sched_barrier(0);
-                    batch_mfma(vb, ks, Q2{}, a);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                return;
-            }
-        }
-#pragma unroll 1
-        for (int ks = ks_begin; ks < ks_end; ++ks) {
+        for (int ks = 0; ks < nks; ++ks) {
             bf16x8 a[SNC];
 #pragma unroll
             for (int c = 0; c < SNC; ++c)
@@ -355,13 +322,11 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
     // (SPLIT: always after the main loop -- before it the prefetched first chunk is live beside the skip operands, 92 spilled
     // registers at the 168 of three workgroups per CU; the two class groups of a tile and the third workgroup of the CU already
     // spread the phases)
-    // SS_DECONV_SKIP_MIX: how many of the nks 16-channel steps of the skip projection a workgroup runs BEFORE its main loop --
-    // 0 / all alternating (r02: two populations), or (unit + channel tile) mod (nks + 1) (nks + 1 populations whose HBM phases differ)
-    const int nks_all = HAS_SKIP ? (Cs + 15) / 16 : 0;
-    const int nfirst = (SPLIT || !HAS_SKIP) ? 0 : (SS_DECONV_SKIP_MIX ? (int)((unit + blockIdx.y) % (unsigned)(nks_all + 1)) : (((unit ^ blockIdx.y) & 1) ? nks_all : 0));
-    const bool skip_first = nfirst > 0;
+    // (more than two populations -- some of the skip steps before the main loop, the rest after -- and the next batch's loads ahead of
+    // this batch's MFMAs were both measured in r05 and change nothing: profiles/EXPERIMENTS.md part E)
+    const bool skip_first = !SPLIT && HAS_SKIP && ((unit ^ blockIdx.y) & 1);
     if (HAS_SKIP && skip_first) {
-        skip_phase(false, 0, nfirst);
+        skip_phase();
         if (F16) {      // the main loop's accumulators carry the channel's weight scale (a power of two: exact)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -548,7 +513,7 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
         }
     }
 
-    if (HAS_SKIP && nfirst < nks_all) skip_phase(SS_DECONV_SKIP_PIPE != 0 && nfirst == 0, nfirst, nks_all);
+    if (HAS_SKIP && !skip_first) skip_phase();
 
     // ---- epilogue: each lane owns the 2x2x2 output cube of its input position.  Buffer stores: a 32-bit per-lane offset
     // per (plane, row) pair of the cube (positions outside the volume parked beyond the buffer: the store is dropped) and
