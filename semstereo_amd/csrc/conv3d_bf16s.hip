@@ -62,7 +62,9 @@ constexpr int SS_IN_AUX = 0;      // cache policy bits of the activation loads (
 #endif
 constexpr int SS_ROW_PAIR = 1;    // rows whose MFMAs alternate; 2 measured 1 % slower: the other wave of the SIMD already fills the gaps
 constexpr int SS_A_AHEAD = 2;     // K-steps between the load of a weight fragment and its MFMAs
-constexpr int SS_F16_WGS = 2;     // workgroups per CU the fp16 form is compiled for (3 = 168 VGPRs: spills, +29 %)
+#ifndef SS_F16_WGS
+#define SS_F16_WGS 2              // workgroups per CU the fp16 form is compiled for (3 = 168 VGPRs: spills, +29 %)
+#endif
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {       // finite inputs
     unsigned u = __float_as_uint(x);
