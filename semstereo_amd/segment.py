@@ -437,6 +437,8 @@ class PairPipeline:
         lane = self.lanes[self.turn % self.nlanes]
         self.turn += 1
         lane.wait_stream(torch.cuda.current_stream(dev))
+        if M.E._RETIRED and all(st.query() for st in self.lanes):
+            M.E.drop_retired()              # entries replaced by calls OUTSIDE the pipeline (a plain call between two pipelined ones): nothing in flight reads them
         gen = M.E.cache_generation()
         # the lanes ARE the concurrency: the within-pair second stream on top of them costs 0.8 % (4 lanes: 525.7 vs 521.4 pairs/s);
         # passed down per thread (overlap_override), the shared module is not written to
