@@ -43,7 +43,9 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
 constexpr int KSTEPS = 14;        // ceil(27 taps / 2): the 3-D kernels (BCfg::KSTEPS is the general form)
 // measured-best settings (each was swept on the bench shapes)
-constexpr int SS_IN_STEPS = 10;   // K-steps over which the next chunk's input loads are issued
+#ifndef SS_IN_STEPS
+#define SS_IN_STEPS 10            // K-steps over which the next chunk's input loads are issued
+#endif
 #ifndef SS_IN_STEPS_S2
 #define SS_IN_STEPS_S2 10         // ... in the stride-2 form (tools/build_variant.sh sweeps: 5: 94.0, 7: 89.1, 10: 87.9, 14: 86.5 us)
 #endif
