@@ -465,6 +465,36 @@ def side_rooflines(res, seg, M, timer, H, W, maxdisp, B, device):
             "traffic": None if tb is None else tb * B, "fetch_size_multiplier": mult, "traffic_note": tnote}
     except Exception as e:       # noqa: BLE001
         res["roofline_classifier_head"] = {"error": repr(e)}
+    # The dominant launch ALONE, back to back for ~1.5 s, with the socket power and shader clock sampled beside it (r05): the
+    # launch by itself sits at the package power cap with the clock throttled (tools/kernel_power.sh: 1401 W of 1400, 1.89 GHz;
+    # classif.0 1.82, the largest transposed conv 2.0, the largest stride-2 conv 2.13), so what bounds it is neither the nominal
+    # MFMA peak nor HBM but joules per launch -- which is why launch-level scheduling variants measure flat (EXPERIMENTS.md part E).
+    try:
+        if semstereo_amd.engine.CONV_ENGINE == "f16x3" and hasattr(M, "stem_gather_half"):
+            gk = torch.Generator(device=device).manual_seed(11)
+            stem = M.BasicConv(64, 32, is_3d=True, kernel_size=3, stride=1, padding=1).to(device).eval()
+            cr = torch.randn(B, 32, H4, W4, generator=gk, device=device)
+            m4 = maxdisp // 4
+            smp = torch.rand(B, 2 * m4, H4, W4, generator=gk, device=device).argsort(dim=1)[:, :24].sort(dim=1).values.float() - m4
+            att = torch.rand(B, 1, 24, H4, W4, generator=gk, device=device)
+            part = torch.randn(B, 32, 24, H4, W4, generator=gk, device=device)
+            gate = torch.rand(B, 32, H4, W4, generator=gk, device=device)
+            def run_g():
+                with torch.no_grad():
+                    return M.stem_gather_half(stem, cr, smp, att, part, gate)
+            msg = steady_ms(run_g)
+
+            def spin():
+                t0 = time.time()
+                while time.time() - t0 < 1.5:
+                    for _ in range(20):
+                        run_g()
+                    torch.cuda.synchronize()
+            pw = power_under_load(spin)
+            res["dominant_launch_alone"] = {"kernel": "conv3d_bf16s<1,4,4,4,19,true,1,3,1,false,true> (gathered concat_stem)", "launch_ms": msg,
+                                            "under_load": pw}
+    except Exception as e:       # noqa: BLE001
+        res["dominant_launch_alone"] = {"error": repr(e)}
 
 
 def cpu_per_op_rows(oops, cpu_in, ref, maxdisp, H4, W4, nthreads):
@@ -857,6 +887,11 @@ def main():
             # the north star's ">= 50 % of the HBM roofline on the cost-volume build kernel" at the config it is stated for
             line["roofline"]["cost_volume"] = {k_: cv[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_cold", "launch_ms",
                                                                       "algorithmic_bytes_per_launch", "traffic", "fetch_size_multiplier")}
+            dla = side.get("dominant_launch_alone") or {}
+            if dla.get("under_load"):          # the dominant launch by itself: socket power / cap and the shader clock it is left with
+                ul = dla["under_load"]
+                line["roofline"]["alone_under_load"] = {"socket_w": round(ul["socket_w"], 1), "cap_w": ul["cap_w"], "sclk_mhz": round(ul["sclk_mhz"]),
+                                                        "launch_ms": dla["launch_ms"]}
             fcv = side.get("roofline_cost_volume_fused_b8")
             if fcv and "frac" in fcv:
                 line["roofline"]["cost_volume"]["fused_with_patch_and_gate_frac"] = fcv["frac"]

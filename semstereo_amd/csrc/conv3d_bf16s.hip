@@ -63,7 +63,9 @@ constexpr int SS_IN_AUX = 0;      // cache policy bits of the activation loads (
 #define SS_IN_AUX_GATED 0         // ... of the gated launch (concat_stem), whose inputs -- warped half, partial sum -- are dead after it (nt / sc0+nt measured on the whole step: 479.5 / 476 against 489.6 pairs/s on one box: the launch itself 284 -> 334 / 344 us)
 #endif
 constexpr int SS_ROW_PAIR = 1;    // rows whose MFMAs alternate; 2 measured 1 % slower: the other wave of the SIMD already fills the gaps
-constexpr int SS_A_AHEAD = 2;     // K-steps between the load of a weight fragment and its MFMAs
+#ifndef SS_A_AHEAD
+#define SS_A_AHEAD 2              // K-steps between the load of a weight fragment and its MFMAs
+#endif
 #ifndef SS_F16_WGS
 #define SS_F16_WGS 2              // workgroups per CU the fp16 form is compiled for (3 = 168 VGPRs: spills, +29 %)
 #endif
@@ -116,8 +118,11 @@ struct BCfg {
     static_assert(TD * TH * MS == 4 * NT && TH % NT == 0 && (MS == 1 || MS == 2), "4 / MS wave groups x NT rows tile TD x TH");
 };
 
+#ifndef SS_WLDS_NT4
+#define SS_WLDS_NT4 0             // 1: the 4-row tile also takes its weight fragments through LDS (variant builds)
+#endif
 constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
-    return NTERMS == 19 && S == 1 && NT == 1 && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
+    return NTERMS == 19 && S == 1 && (NT == 1 || (SS_WLDS_NT4 && NT == 4)) && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
 }
 // gather form: per halo position one candidate word and two attention words (this tile's, the next tile's), each thread's
 // own positions p = tid + 256 i -> 3 x NPOS x 256 floats
@@ -453,8 +458,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                 if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
             }
         };
+#ifdef SS_EXP_CONV_NOSTAGE        // (timing experiment, wrong results: the split / transpose / LDS writes done once per workgroup)
+        if (tile == (int)blockIdx.x && ci0 == 0)
+#endif
+        {
         if (nlive == 8) stage(std::true_type{});
         else stage(std::false_type{});
+        }
         if (WLDS) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the LDS-DMA weight loads have landed
         __syncthreads();
         const bool more = ci0 + 8 < Cin;                       // another chunk of THIS tile follows
@@ -522,10 +532,12 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
                 for (int c = 0; c < NC; ++c) aq[(s + 1) % AR][0][c] = lds[WL + ((s + 1) * 2 + c) * 64 + lane];
             }
+#ifndef SS_EXP_CONV_KEEP          // (timing experiment, wrong results: no input loads after a workgroup's first chunk -- the staged data keeps its statistics)
 #pragma unroll
             for (int q = s * QS; q < (s + 1) * QS && q < NQ; ++q)
                 rin[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                        ires, (int)(poff[q % C::NPOS] | nomore), (ch_next + min(q / C::NPOS, max(nlive_next, 1) - 1)) * chan_b, GATED ? SS_IN_AUX_GATED : SS_IN_AUX));
+#endif
             uint4 a[MT][NC];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -687,6 +699,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                 const bool cok = ALLC || cb + 4 * half < Cout;
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
+#ifdef SS_EXP_CONV_NOSTORE        // (timing experiment: one store per lane instead of 64)
+                    if (r0 + q + i == 0)
+#endif
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[q][i]), ores,
                                                           (int)(cok ? vout[i] : 0x80000000u), cb * (int)ochan_b, 0);
             }
