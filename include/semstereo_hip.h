@@ -316,6 +316,20 @@ int ss_conv3d_bf16s_cl_fwd(const float* in, const void* wsplit, const float* sca
 int ss_conv3d_head_bf16s_cl_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                                 float* out, int B, int Cin, int D, int H, int W, int relu, int nterms,
                                 ss_stream_t stream);
+/* The same classifier in ONE pass over the volume (r05): the 32-channel intermediate never leaves the CU.  The first layer's
+ * tile (4 planes x 4 rows x 32 columns x 32 channels) contracts its ReLU(BN(conv)) with the head's 27 x 32 weights on the matrix
+ * core as soon as its K loop ends, sums the 27 shifted tap images over the tile in a fixed order and writes the tile's
+ * contribution to the 6 x 6 x 34 output positions it touches -- a PATCH -- into `patches`
+ * ([B][ceil(W/32) * ceil(H/4) * D/4][6*6*34] floats, caller-allocated scratch); a second small launch adds the <= 8 patches that
+ * hold an output position, again in a fixed order: deterministic, and a pair gets the same bits at every batch size.
+ *   head_w: ss_pack_classifier_head_weights(w2 [1,32,3,3,3]) -> 6144 bytes, 16-byte aligned.
+ * Cin % 8 == 0, 32 intermediate channels, nterms = 19, D % 4 == 0 and a layer of at least 512 (2 x 8 x 32) tiles per pair;
+ * anything else returns SS_ERR_UNSUPPORTED (the caller keeps the two-launch form above).  y is the two-launch form's y bit for
+ * bit; the head's 864 products per output are summed in another order (within fp32 rounding of it). */
+int ss_pack_classifier_head_weights(const float* w2, void* out, ss_stream_t stream);
+int ss_conv3d_classifier_fused_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                   const void* head_w, float* patches, float* out, int B, int Cin, int D, int H, int W,
+                                   int nterms, ss_stream_t stream);
 /* 1x1x1 Conv3d / per-position Linear (+ per-channel affine: bias; ReLU) on the split-bf16 engine:
  * qkv_3d and final1x1 of attention_block (models/submodule_other.py:804, 835).
  *   out [B,Cout,npos] = relu?(scale * (W in) + shift), in [B,Cin,npos], npos = D*H*W, W [Cout,Cin];

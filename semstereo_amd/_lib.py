@@ -57,6 +57,8 @@ _SIGNATURES = {
     "ss_conv3d_head_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_head_bf16s_cl_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_bf16s_cl_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_pack_classifier_head_weights": [_P, _P, _P],
+    "ss_conv3d_classifier_fused_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_head_weights_bf16s": [_P, _P, _I, _P],
     "ss_pack_conv3d_head_weights_f16s": [_P, _P, _I, _P],
     "ss_conv3d_pointwise_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_longlong, _I, _I, _P],

@@ -129,6 +129,9 @@ constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
 constexpr int gather_slots(bool gather, int S, int TD, int TH, int KD) {
     return gather ? 3 * ((((TD - 1) * S + KD) * ((TH - 1) * S + 3) * (31 * S + 3) + 255) / 256) * 64 : 0;
 }
+// head form (HEAD of the kernel): the 32 -> 1 head's weight fragments, [3 bf16 terms][2 K-steps][64 lanes] 16-byte slots
+constexpr int HEAD_WSLOTS = 3 * 2 * 64;
+constexpr int HEAD_PATCH = 6 * 6 * 34;        // a 4 x 4 x 32 tile's contributions to the head's output: its positions and one ring around them
 
 // Chunk-blocked accumulation (ACCB of the kernel) is a property of the LAYER, never of the tile a launch happens to get: the
 // tile candidates depend on the batch size, and a pair must get the same bits alone and in a batch
@@ -160,7 +163,18 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // are fetched once per TILE by LDS-DMA (no registers: each thread's own positions, parked in LDS) a chunk ahead of their
 // first use; the gathered loads take the place of the volume loads one for one (same prefetch registers, same slices).
 // D = the number of candidates.  Cin % 8 == 0 and Cin >= 16 (the look-ahead needs two chunks per tile).
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false, bool GATHER = false>
+//
+// HEAD (r05, late): nn.Sequential(convbn_3d(32,32,3,1,1), ReLU, Conv3d(32,1,3,p1)) -- `classif` / `classif_att_`, models/SemStereo.py:228-234 -- in
+// ONE pass over the volume: the 32-channel intermediate never leaves the CU.  After a tile's K loop its y = ReLU(BN(conv)) sits in the
+// accumulators in exactly the B-operand layout of the next contraction (lane = position, 8 consecutive registers = 8 channels of a
+// K-step), so t[tap][position] = sum_c w2[c][tap] y[c][position] is 12 more MFMAs per row (27 taps as matrix rows, three bf16 terms, six
+// products); the 27 shifted sums out[q] = sum_tap t[tap][q + tap - 1] are done in three deterministic stages: over kh in registers
+// (a wave owns 4 rows of one plane, a lane half whole kh-triples), over (kd, kw) through a 30 KB LDS buffer that reuses the dead
+// activation tile -- giving the tile's contribution to the 6 x 6 x 34 output positions it touches, written to `out` as a PATCH
+// [B][tiles][6][6][34] -- and over the <= 8 tiles that touch an output position in classifier_patch_sum_kernel.  201 MB written +
+// 288 MB read per classifier become 15 + 15 MB; the head's own launch disappears.  `cand` carries the head's fragments
+// (ss_pack_classifier_head_weights), `out` the patch buffer.
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false, bool GATHER = false, bool HEAD = false>
 __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3d_bf16s(const float* __restrict__ in, const uint4* __restrict__ wsplit,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ residual, const float* __restrict__ gate,
@@ -170,6 +184,8 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                                                         const float* __restrict__ cand, const float* __restrict__ catt,
                                                         const float* __restrict__ in2, int bsplit) {
     static_assert(!GATHER || (S == 1 && MT == 1 && KD == 3 && MS == 1), "gather form: plain stride-1 3-D tiles");
+    static_assert(!HEAD || (S == 1 && NT == 4 && TD == 4 && TH == 4 && MT == 1 && KD == 3 && MS == 1 && !GATED && !GATHER && NTERMS == F16X3),
+                  "head form: the 4 x 4 x 32 tile of the fp16 engine, one wave per plane");
     constexpr bool F16 = (NTERMS == F16X3);
     constexpr int NC = (NTERMS == 6) ? 3 : 2;                  // operand terms actually read
     constexpr int NCW = F16 ? 2 : 3;                           // terms in the packed weights
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     constexpr bool WLDS = wlds_form(S, NT, NTERMS, MT, KD);
     static_assert(!ACCB || NTERMS == F16X3, "chunk-blocked accumulation: fp16 form only");
     static_assert(!WLDS || MS == 1, "the LDS copy of the weights is one channel tile's");
-    using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS, gather_slots(GATHER, S, TD, TH, KD)>;
+    using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS, gather_slots(GATHER, S, TD, TH, KD) + (HEAD ? HEAD_WSLOTS : 0)>;
     constexpr int WL = NC * C::CS + 2 + 48;                    // first slot of the weight fragments
     constexpr int KSTEPS = C::KSTEPS;                          // shadows the 3-D constant
     constexpr int ZSLOT = NC * C::CS;                          // the all-zero slot; ZSLOT + 1: the four waves' maxima
@@ -329,6 +345,10 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // per-channel epilogue constants, fetched now and parked in LDS: read after the K loop they cost two exposed round
     // trips to L2/HBM per workgroup (tools/wg_phases.py).  aff[c] = scale, aff[64 + c] = shift, aff[128 + c] = 2^-(weight scale)
     float* aff = reinterpret_cast<float*>(&lds[ZSLOT + 2]);
+    if constexpr (HEAD) {             // the head's weight fragments: parked in LDS once per workgroup
+        const uint4* hw = reinterpret_cast<const uint4*>(cand);
+        for (int i = tid; i < HEAD_WSLOTS; i += 256) lds[C::XS0 + i] = hw[i];
+    }
     if (tid < 32 * MT * MS) {
         const int co = min(co0 + tid, Cout - 1);
         aff[tid] = scale ? scale[co] : 1.0f;
@@ -609,6 +629,85 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     }
 
     SS_STAMP(2);
+    if constexpr (HEAD) {
+        int ow0, oh0, od0;
+        tile_origin(tile, ow0, oh0, od0);
+        const float hunscale = __uint_as_float((unsigned)(127 - E_ONE + e_cur) << 23);
+        const float hfloor = (relu & 1) ? 0.f : -__builtin_inff();
+        const bool colok = ow0 + l31 < Wo && od0 + dzw < Do;
+        // ---- t[tap row][position] of this wave's rows: the accumulators become the B operand as they are ----
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const bool ok = colok && oh0 + hy0 + i < Ho;
+            float y[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = fmaxf(ss::add_rn(ss::mul_rn(acc[i][r] * (aff[128 + cl] * hunscale), aff[cl]), aff[64 + cl]), hfloor);
+                y[r] = ok ? v : 0.f;            // positions outside the volume: the head's zero padding
+            }
+            f32x16 tt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tt[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) split3_pk(y[8 * ks + 2 * c], y[8 * ks + 2 * c + 1], bh[c], bm[c], bl[c]);
+                const bf16x8 h8 = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                const bf16x8 m8 = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+                const bf16x8 l8 = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, lds[C::XS0 + (0 * 2 + ks) * 64 + lane]);
+                const bf16x8 am = __builtin_bit_cast(bf16x8, lds[C::XS0 + (1 * 2 + ks) * 64 + lane]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, lds[C::XS0 + (2 * 2 + ks) * 64 + lane]);
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, m8, tt, 0, 0, 0);      // smallest cross terms first
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l8, tt, 0, 0, 0);
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h8, tt, 0, 0, 0);
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, m8, tt, 0, 0, 0);
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, h8, tt, 0, 0, 0);
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h8, tt, 0, 0, 0);
+            }
+            acc[i] = tt;                        // register 3 * ps + kh of this lane half: (kd, kw) pair ps + 5 * half, tap row kh
+            __builtin_amdgcn_sched_barrier(0);  // one row at a time (all four interleaved: 43 spilled registers)
+        }
+        // ---- over kh, in registers: U[ps][ph] = sum_row t[row][3 ps + (row + 2 - ph)], ph = 0..5 the patch row (fixed order) ----
+        float* ubuf = reinterpret_cast<float*>(lds);      // [10 pairs][6 patch rows][4 planes][32 columns], over the dead activation tile
+        float* ub = ubuf + (5 * half * 6 * 4 + wave) * 32 + l31;      // (one per-lane address, the rest immediate offsets)
+#pragma unroll
+        for (int ps = 0; ps < 5; ++ps) {
+#pragma unroll
+            for (int ph = 0; ph < 6; ++ph) {
+                float u = 0.f;
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    const int kh = row + 2 - ph;
+                    if (kh >= 0 && kh < 3) u = ss::add_rn(u, acc[row][3 * ps + kh]);
+                }
+                ub[(ps * 6 + ph) * 4 * 32] = u;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // ---- over (kd, kw): each thread owns patch positions q = tid + 256 i ----
+        float* pout = out + ((size_t)b * ntiles + tile) * HEAD_PATCH;
+#pragma unroll
+        for (int i = 0; i < (HEAD_PATCH + 255) / 256; ++i) {
+            const int q = tid + 256 * i;
+            if (q < HEAD_PATCH) {
+                const int pw = q % 34, ph = (q / 34) % 6, pd = q / (34 * 6);
+                float pv = 0.f;
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int pl = pd - 2 + kd, n = pw - 2 + kw;
+                        if ((unsigned)pl < 4u && (unsigned)n < 32u) pv = ss::add_rn(pv, ubuf[(((kd * 3 + kw) * 6 + ph) * 4 + pl) * 32 + n]);
+                    }
+                pout[q] = pv;
+            }
+        }
+        __syncthreads();               // the next tile's first chunk is staged over ubuf
+    } else {
     set_outputs(tile);                 // (output addressing is derived here, not kept live through the K loop)
     // ---- epilogue: 32x32 D layout (col = lane & 31 = output column, row = channel, see cbase) ----
     // f16 form: 2^-(activation scale); the per-channel 2^-(weight scale) is stored behind the packed weights
@@ -710,6 +809,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     };
     if (co0 + 32 * MT * MS <= Cout) epilogue(std::true_type{});
     else epilogue(std::false_type{});
+    }       // !HEAD
     SS_STAMP(3);
     }       // tiles of this workgroup (the next one's first chunk is already in the prefetch registers)
     SS_STAMP_FINISH();
@@ -777,17 +877,17 @@ __global__ void pack_weights_f16s_kernel(const float* __restrict__ w, unsigned s
 
 #endif  // !SS_CONV_GATHER_TU
 
-template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false, bool GATHER = false>
+template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD = 3, int MS = 1, bool ACCB = false, bool GATHER = false, bool HEAD = false>
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st,
               const float* cand = nullptr, const float* catt = nullptr, const float* in2 = nullptr, int bsplit = 0) {
     using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2, wlds_form(S, NT, NTERMS, MT, KD) ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS,
-                   gather_slots(GATHER, S, TD, TH, KD)>;
+                   gather_slots(GATHER, S, TD, TH, KD) + (HEAD ? HEAD_WSLOTS : 0)>;
     const int Do = (D + 2 * (KD / 2) - KD) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
     const long long nt = (long long)tiles_w * tiles_h * tiles_d;
     if (nt > 0x7fffffffLL || B > 65535) return SS_ERR_UNSUPPORTED;
-    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD, MS, ACCB, GATHER>;
+    auto kern = conv3d_bf16s<S, NT, TD, TH, NTERMS, GATED, MT, KD, MS, ACCB, GATHER, HEAD>;
     if (C::LDS_BYTES > 64 * 1024) {
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES) != SS_OK) return SS_ERR_LAUNCH;
     }

@@ -1,0 +1,94 @@
+// The classifiers of the model -- nn.Sequential(convbn_3d(32,32,3,1,1), ReLU, Conv3d(32,1,3,p1)): `classif` and `classif_att_`, reference
+// models/SemStereo.py:228-234, called at :278 and :322 -- as ONE pass over the volume: the HEAD form of conv3d_bf16s (see the kernel's
+// header comment in conv3d_bf16s.hip), instantiated in its own translation unit, plus the packing of the head's weights and the
+// sum of the tiles' patches.
+#define SS_CONV_GATHER_TU 1
+#include "conv3d_bf16s.hip"
+
+namespace {
+
+// matrix row m of the head's A operand -> tap (kd * 9 + kh * 3 + kw), or -1: a lane half of the MFMA's result holds rows
+// m = (r & 3) + 8 * (r >> 2) + 4 * half in register r; register 3 * ps + kh is tap row kh of the (kd, kw) pair ps + 5 * half, so that
+// the sum over kh happens inside a lane (conv3d_bf16s.hip, HEAD)
+__host__ __device__ inline int head_tap_of_row(int m) {
+    const int hf = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
+    const int ps = r / 3, kh = r % 3, pair = ps + 5 * hf;
+    if (r >= 15 || pair >= 9) return -1;
+    return (pair / 3) * 9 + kh * 3 + (pair % 3);
+}
+
+// w2 [1,32,3,3,3] fp32 -> [3 bf16 terms][2 K-steps][64 lanes][8]: lane (m, hf) of K-step ks holds channels
+// (j & 3) + 4 hf + 8 (j >> 2) + 16 ks, j = 0..7 -- the order in which the conv's accumulators hold them
+__global__ void pack_classifier_head_kernel(const float* __restrict__ w2, unsigned short* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HEAD_WSLOTS * 8) return;
+    const int j = i % 8, lane = (i / 8) % 64, ks = (i / 512) % 2, term = i / 1024;
+    const int m = lane & 31, hf = lane >> 5;
+    const int ch = (j & 3) + 4 * hf + 8 * (j >> 2) + 16 * ks;
+    const int tap = head_tap_of_row(m);
+    const float x = tap >= 0 ? w2[ch * 27 + tap] : 0.f;
+    unsigned h, mm, l;
+    split3(x, h, mm, l);
+    out[i] = (unsigned short)(term == 0 ? h : (term == 1 ? mm : l));
+}
+
+// out[b][d][h][w] = the sum of the (at most 8) tiles' patches that hold that position, in a fixed order (planes, rows, columns ascending)
+__global__ __launch_bounds__(256) void classifier_patch_sum_kernel(const float* __restrict__ patches, float* __restrict__ out, int D, int H,
+                                                                    int W, int tiles_w, int tiles_h, int tiles_d, long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int w = (int)(i % W);
+    long long r = i / W;
+    const int h = (int)(r % H); r /= H;
+    const int d = (int)(r % D);
+    const int b = (int)(r / D);
+    const int ntiles = tiles_w * tiles_h * tiles_d;
+    const float* pb = patches + (size_t)b * ntiles * HEAD_PATCH;
+    float v = 0.f;
+    for (int td = d / 4 - 1; td <= d / 4 + 1; ++td) {
+        const int pd = d - 4 * td + 1;
+        if (td < 0 || td >= tiles_d || pd < 0 || pd >= 6) continue;
+        for (int th = h / 4 - 1; th <= h / 4 + 1; ++th) {
+            const int ph = h - 4 * th + 1;
+            if (th < 0 || th >= tiles_h || ph < 0 || ph >= 6) continue;
+            for (int tw = w / 32 - 1; tw <= w / 32 + 1; ++tw) {
+                const int pw = w - 32 * tw + 1;
+                if (tw < 0 || tw >= tiles_w || pw < 0 || pw >= 34) continue;
+                v = ss::add_rn(v, pb[(size_t)((td * tiles_h + th) * tiles_w + tw) * HEAD_PATCH + (pd * 6 + ph) * 34 + pw]);
+            }
+        }
+    }
+    out[i] = v;
+}
+
+}  // namespace
+
+extern "C" int ss_pack_classifier_head_weights(const float* w2, void* out, ss_stream_t stream) {
+    SS_REQUIRE(w2 && out);
+    hipLaunchKernelGGL(pack_classifier_head_kernel, dim3(ss::ceil_div(HEAD_WSLOTS * 8, 256)), dim3(256), 0, ss::as_stream(stream), w2,
+                       reinterpret_cast<unsigned short*>(out));
+    return ss::check_launch();
+}
+
+extern "C" int ss_conv3d_classifier_fused_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
+                                              const void* head_w, float* patches, float* out, int B, int Cin, int D, int H, int W,
+                                              int nterms, ss_stream_t stream) {
+    SS_REQUIRE(in && wsplit && head_w && patches && out);
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0);
+    SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0 && (reinterpret_cast<uintptr_t>(head_w) & 15) == 0);
+    if (nterms != F16X3 || D % 4 != 0) return SS_ERR_UNSUPPORTED;
+    if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    // the form of the LAYER, whatever the batch (a pair gets the same bits alone and in a batch): layers too small for the
+    // 4-row tile at batch 1 keep the two-launch form
+    const long long per_pair = (long long)ss::ceil_div(W, 32) * ss::ceil_div(H, 8) * ss::ceil_div(D, 2);
+    if (per_pair < 512) return SS_ERR_UNSUPPORTED;
+    hipStream_t st = ss::as_stream(stream);
+    const int rc = launch_bgm<1, 4, 4, 4, F16X3, false, 1, 3, 1, false, false, true>(
+        in, wsplit, scale, shift, nullptr, nullptr, patches, B, Cin, D, H, W, 32, 1, st, reinterpret_cast<const float*>(head_w));
+    if (rc != SS_OK) return rc;
+    const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, 4), tiles_d = D / 4;
+    const long long total = (long long)B * D * H * W;
+    hipLaunchKernelGGL(classifier_patch_sum_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0, st, patches, out, D, H, W,
+                       tiles_w, tiles_h, tiles_d, total);
+    return ss::check_launch();
+}

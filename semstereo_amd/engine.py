@@ -312,6 +312,42 @@ def classifier_cl_hip(x, ws0, scale0, shift0, nterms0, ws2, nterms2):
     return out
 
 
+def classifier_fused_applies(x, nterms0):
+    """The one-pass form of a classifier (ss_conv3d_classifier_fused_fwd) serves this input: decided by the LAYER (what one pair of
+    it offers the chip), never by the batch, so that a pair gets the same bits alone and in a batch."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and nterms0 == 19):
+        return False
+    _, C, D, H, W = x.shape
+    return C % 8 == 0 and D % 4 == 0 and ((W + 31) // 32) * ((H + 7) // 8) * ((D + 1) // 2) >= 512 and C * D * H * W * 4 < 0x7fffffff
+
+
+def pack_classifier_head_weight(w2):
+    """[1,32,3,3,3] fp32 -> the head's fragments for ss_conv3d_classifier_fused_fwd (three bf16 terms, 6144 bytes)."""
+    w2 = w2.detach().float().contiguous()
+    _lib.require_device(w2)
+    assert tuple(w2.shape) == (1, 32, 3, 3, 3)
+    out = torch.empty(3 * 2 * 64 * 8, dtype=torch.int16, device=w2.device)
+    with torch.cuda.device(w2.device):
+        call("ss_pack_classifier_head_weights", ptr(w2), ptr(out))
+    return out
+
+
+def classifier_fused_hip(x, ws0, scale0, shift0, nterms0, head_w):
+    """nn.Sequential(convbn_3d(C,32,3,1,1), ReLU, Conv3d(32,1,3,p1)) (models/SemStereo.py:228-234) in one pass over the volume: the
+    32-channel intermediate stays in the accumulators, each tile writes a 6 x 6 x 34 patch of head outputs, a second small launch
+    adds the patches (conv3d_classifier.hip)."""
+    x = x if x.is_contiguous() else x.contiguous()
+    dev = _lib.require_device(x, scale0, shift0)
+    B, C, D, H, W = x.shape
+    ntiles = ((W + 31) // 32) * ((H + 3) // 4) * (D // 4)
+    patches = torch.empty((B, ntiles, 6 * 6 * 34), dtype=x.dtype, device=x.device)
+    out = torch.empty((B, 1, D, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(dev):
+        call("ss_conv3d_classifier_fused_fwd", ptr(x), ptr(ws0), ptr(scale0), ptr(shift0), ptr(head_w), ptr(patches), ptr(out),
+             B, C, D, H, W, int(nterms0))
+    return out
+
+
 def pack_conv2d_weight_bf16s(w, nterms=6):
     """[Cout,Cin,3,3] fp32 -> split fragments for ss_conv2d_bf16s_fwd (three bf16 terms, or two scaled fp16 terms: nterms 19)."""
     w = w.detach().float().contiguous()
@@ -506,6 +542,9 @@ def run_convbn(owner, key, conv, bn, x, relu, residual=None, gate=None):
 
 TRAIN_HIP = os.environ.get("SS_TRAIN_HIP", "1") != "0"      # 0: the stock PyTorch layers whenever autograd / batch statistics are needed
 CLASSIFIER_CL = os.environ.get("SS_CLASSIFIER_CL", "1") != "0"    # 0: plain-layout intermediate inside the classifiers (two generic launches)
+#: the classifiers in ONE pass over the volume (the 32-channel intermediate never leaves the CU: conv3d_classifier.hip) where the
+#: layer is large enough for the 4-row tile at batch 1; SS_CLASSIFIER_FUSED=0: the two-launch forms above
+CLASSIFIER_FUSED = os.environ.get("SS_CLASSIFIER_FUSED", "1") != "0"
 
 
 STEM_LEFT_FUSED = os.environ.get("SS_STEM_LEFT_FUSED", "1") != "0"     # Q of the broadcast half on the fly (one launch) or through HBM (two)
@@ -636,5 +675,5 @@ def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate=None):
 ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launches) | "fused" (one kernel per window)
 
 #: the names tests / tools may SET on this module; `modules.X` forwards reads of them here
-SWITCHES = ("CONV_ENGINE", "DECONV_F16", "DECONV_MIN_WORKGROUPS", "DECONV_BF16S", "CLASSIFIER_CL", "TRAIN_HIP", "ATTENTION_FORM",
+SWITCHES = ("CONV_ENGINE", "DECONV_F16", "DECONV_MIN_WORKGROUPS", "DECONV_BF16S", "CLASSIFIER_CL", "CLASSIFIER_FUSED", "TRAIN_HIP", "ATTENTION_FORM",
             "STEM_LEFT_FUSED", "STEM_PRESPLIT", "STEM_GATHER", "HEAD_F16", "CONV2D_HIP")

@@ -29,7 +29,7 @@ from ._lib import call, ptr
 # the functional layer (engine.py) and the training convolutions (train_layers.py) under their historical names: `modules.X`
 # keeps resolving for every function; the SWITCHES are engine.py's (see __getattr__ at the end of this file)
 from .engine import (PATH_COUNTS, _cache, _conv_geometry, _inference, _is_plain_3x3, _ParamCache, _ReplicaCache,  # noqa: F401
-                     classifier_cl_hip, conv2d_bf16s_hip, conv3d_bf16s_hip, conv3d_head_bf16s_hip, conv3d_hip,
+                     classifier_cl_hip, classifier_fused_applies, classifier_fused_hip, pack_classifier_head_weight, conv2d_bf16s_hip, conv3d_bf16s_hip, conv3d_head_bf16s_hip, conv3d_hip,
                      conv3d_pointwise_bf16s_hip, deconv3d_bf16s_hip, deconv3d_hip, fold_bn, pack_conv2d_weight_bf16s,
                      pack_conv_weight, pack_conv_weight_bf16s, pack_deconv_weight_bf16s, pack_head_weight_bf16s,
                      pack_pointwise_weight_bf16s, run_conv2d, run_conv2d_pair, run_convbn, stem_broadcast_half, stem_of_broadcast_and_volume,
@@ -415,6 +415,14 @@ class Classifier(nn.Sequential):
             if (E.CLASSIFIER_CL and E.CONV_ENGINE != "f32" and c0.in_channels == c0.out_channels == c2.in_channels == 32
                     and _conv_geometry(c0) == (3, 1) and _conv_geometry(c2) == (3, 1) and c2.out_channels == 1):
                 nt0, nt2 = _tiled_nterms(), _head_nterms()
+                if E.CLASSIFIER_FUSED and classifier_fused_applies(x, nt0):
+
+                    def build_fused():
+                        sc, sh = fold_bn(bn0)
+                        return pack_conv_weight_bf16s(c0.weight, nt0), sc, sh, pack_classifier_head_weight(c2.weight)
+                    srcs = [c0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, c2.weight]
+                    ws0, sc, sh, hw = _cache(self).get("fused/%d" % nt0, srcs, build_fused)
+                    return classifier_fused_hip(x, ws0, sc, sh, nt0, hw)
 
                 def build():
                     sc, sh = fold_bn(bn0)
