@@ -821,6 +821,65 @@ def test_classifier_channels_last_handoff_is_bit_identical(sa, shape, monkeypatc
     assert torch.equal(outs[0], outs[1])
 
 
+def _det_classifier(sa, seed=900):
+    from oracle import detdata as dd
+    m = sa.modules.Classifier(32).cuda().eval()
+    with torch.no_grad():
+        for i, p in enumerate(m.parameters()):
+            p.copy_(dev(dd.t_uniform(tuple(p.shape), seed + i, -1, 1) * (0.05 if p.dim() > 1 else 1.0)))
+        m[0][1].running_mean.copy_(dev(dd.t_uniform((32,), seed + 10, -0.1, 0.1)))
+        m[0][1].running_var.copy_(dev(dd.t_uniform((32,), seed + 11, 0.6, 1.4)))
+    return m
+
+
+@pytest.mark.parametrize("shape", [(1, 12, 134, 200), (2, 8, 140, 250), (1, 4, 300, 260), (1, 32, 128, 128)])
+def test_classifier_one_pass_form_against_the_two_launch_form_and_float64(sa, shape, monkeypatch):
+    """`classif` / `classif_att_` (models/SemStereo.py:228-234) in ONE pass over the volume (ss_conv3d_classifier_fused_fwd: the
+    32-channel intermediate stays in the accumulators, tiles write patches of head outputs, a second launch adds them): ragged
+    rows and columns (partial tiles), batch 2, a single 4-plane slab; against the two-launch form (same y bit for bit, the head's
+    864 products summed in another order) and against float64 -- no further from it than the two-launch form is."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    B, D, H, W = shape
+    m = _det_classifier(sa)
+    x = dev(dd.t_normalish((B, 32, D, H, W), 912))
+    assert sa.engine.classifier_fused_applies(x, 19)
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(sa.engine, "CLASSIFIER_FUSED", flag)
+        with torch.no_grad():
+            outs.append(m(x))
+    assert outs[0].shape == (B, 1, D, H, W)
+    scale = float(outs[1].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * scale
+    md = _det_classifier(sa).double().cpu()
+    with torch.no_grad():
+        ref = F.conv3d(F.relu(md[0][1](F.conv3d(x.double().cpu(), md[0][0].weight, padding=1))), md[2].weight, padding=1)
+    rms = [float((o.double().cpu() - ref).pow(2).mean().sqrt()) for o in outs]
+    REPORT[f"classifier_one_pass/{shape}"] = rms
+    assert rms[0] <= 1.1 * rms[1] + 1e-9 and rms[0] <= 2e-6 * float(ref.abs().max())
+
+
+def test_classifier_one_pass_form_is_batch_invariant_and_decided_by_the_layer(sa, monkeypatch):
+    """A pair gets the same bits alone and in a batch: the one-pass form is chosen by what ONE pair of the layer offers the chip
+    (>= 512 tiles of 2 x 8 x 32), never by the batch; layers below that keep the two-launch form at every batch size."""
+    from oracle import detdata as dd
+    m = _det_classifier(sa, 930)
+    x = dev(dd.t_normalish((3, 32, 12, 134, 200), 931))
+    with torch.no_grad():
+        whole = m(x)
+        for i in range(3):
+            assert torch.equal(m(x[i:i + 1].contiguous()), whole[i:i + 1])
+    small = dev(dd.t_normalish((8, 32, 8, 64, 64), 932))          # 2 x 8 x 4 = 64 tiles per pair: 512 only with the batch counted
+    assert not sa.engine.classifier_fused_applies(small, 19)
+    assert not sa.engine.classifier_fused_applies(x[:, :, :10].contiguous(), 19)      # depth not a multiple of 4
+    hw = sa.engine.pack_classifier_head_weight(m[2].weight)
+    ws0 = sa.engine.pack_conv_weight_bf16s(m[0][0].weight, 19)
+    sc, sh = sa.engine.fold_bn(m[0][1])
+    with pytest.raises(sa._lib.SemStereoHipError):                 # the C ABI refuses what the rule refuses (no silent other path)
+        sa.engine.classifier_fused_hip(small, ws0, sc, sh, 19, hw)
+
+
 @pytest.mark.parametrize("nterms", [6, 19])
 @pytest.mark.parametrize("case", [(64, 128, 4, 7, 40), (32, 64, 6, 10, 34), (20, 40, 3, 5, 9), (64, 128, 16, 64, 64),
                                   # >= 256 workgroups: the form whose waves split the 64 channels of a workgroup (ragged channel groups, odd sizes)
@@ -991,6 +1050,7 @@ _NON_DEFAULT = {
     "SS_DECONV_F16=0": ("engine", "DECONV_F16", False),
     "SS_DECONV_MIN_WGS=256": ("engine", "DECONV_MIN_WORKGROUPS", 256),
     "SS_CLASSIFIER_CL=0": ("engine", "CLASSIFIER_CL", False),
+    "SS_CLASSIFIER_FUSED=0": ("engine", "CLASSIFIER_FUSED", False),
     "SS_CONV2D_HIP=0": ("engine", "CONV2D_HIP", False),
 }
 

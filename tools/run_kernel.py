@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs ONE kernel of the path back to back (live shapes of the 1024 x 1024 / maxdisp 128 pair) so that rocprofv3 kernel-trace /
 PMC passes see nothing else, and prints its time and algorithmic-byte rate.
-usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_plain head_cl conv_s1_cl conv_mid conv_low conv_mid_att conv_low_att attn attn_att warp ssr ssr2048 strength topk
+usage: run_kernel.py <kernel> [batch] [iters]        kernels: gwc gwc_fused patch head head_att classif classif_cl classif_plain classif_att head_cl conv_s1_cl conv_mid conv_low conv_mid_att conv_low_att attn attn_att warp ssr ssr2048 strength topk
                                                                catt8 catt4 upsoft stem_left stem stem_gather stem_gather_smooth conv_s1 conv_s2 conv_s2_att deconv deconv5 deconv_att6 deconv_att5"""
 import os
 import sys
@@ -38,12 +38,13 @@ elif name in ("head", "head_att"):
     ws = M.pack_head_weight_bf16s(R(1, 32, 3, 3, 3))
     fn = lambda: M.conv3d_head_bf16s_hip(x, ws, None, None, False, 6)          # noqa: E731
     nbytes = 4.0 * B * 33 * D * H * H
-elif name in ("classif", "classif_plain"):                # the whole classifier: conv 32->32 + BN + ReLU, then the 32->1 head
-    sa.engine.CLASSIFIER_CL = name == "classif"
+elif name in ("classif", "classif_cl", "classif_plain", "classif_att"):   # the whole classifier: conv 32->32 + BN + ReLU, then the 32->1 head (one pass / channels-last hand-off / plain pair)
+    sa.engine.CLASSIFIER_FUSED = name in ("classif", "classif_att")
+    sa.engine.CLASSIFIER_CL = name != "classif_plain"
     cl = M.Classifier(32).to(dev).eval()
-    x = torch.relu(R(B, 32, 24, 256, 256))
+    x = torch.relu(R(B, 32, 24, 256, 256)) if name != "classif_att" else torch.relu(R(B, 32, 32, 128, 128))
     fn = lambda: cl(x)                                                         # noqa: E731
-    nbytes = 4.0 * B * (32 + 32 + 32 + 1) * 24 * 256 * 256
+    nbytes = 4.0 * B * ((32 + 1) if sa.engine.CLASSIFIER_FUSED else (32 + 32 + 32 + 1)) * x[0, 0].numel()
 elif name == "warp":
     cr, smp = R(B, 32, 256, 256), torch.randint(-32, 32, (B, 24, 256, 256), device=dev).float().sort(dim=1).values
     att = torch.rand(B, 24, 256, 256, device=dev)
