@@ -690,18 +690,30 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         __syncthreads();
         // ---- over (kd, kw): each thread owns patch positions q = tid + 256 i ----
         float* pout = out + ((size_t)b * ntiles + tile) * HEAD_PATCH;
+        int ptid = tid;                // (opaque: the positions' index arithmetic is redone here per tile instead of living in registers -- or scratch -- through the K loop)
+        asm volatile("" : "+v"(ptid));
 #pragma unroll
         for (int i = 0; i < (HEAD_PATCH + 255) / 256; ++i) {
-            const int q = tid + 256 * i;
+            const int q = ptid + 256 * i;
             if (q < HEAD_PATCH) {
                 const int pw = q % 34, ph = (q / 34) % 6, pd = q / (34 * 6);
+                // (all nine reads issued before the first add, from clamped -- always valid -- addresses: under a branch each the reads
+                // were 37 dependent LDS round trips per thread)
+                float uv[9];
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int pl = min(max(pd - 2 + kd, 0), 3), n = min(max(pw - 2 + kw, 0), 31);
+                        uv[kd * 3 + kw] = ubuf[(((kd * 3 + kw) * 6 + ph) * 4 + pl) * 32 + n];
+                    }
                 float pv = 0.f;
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        const int pl = pd - 2 + kd, n = pw - 2 + kw;
-                        if ((unsigned)pl < 4u && (unsigned)n < 32u) pv = ss::add_rn(pv, ubuf[(((kd * 3 + kw) * 6 + ph) * 4 + pl) * 32 + n]);
+                        const bool in = (unsigned)(pd - 2 + kd) < 4u && (unsigned)(pw - 2 + kw) < 32u;
+                        pv = ss::add_rn(pv, in ? uv[kd * 3 + kw] : 0.f);
                     }
                 pout[q] = pv;
             }
