@@ -395,6 +395,14 @@ class PairPipeline:
     module -- a HotSegment (`pipe(fl4, fr4, fl8, fr8)`) or a whole reference model after `install` + `accelerate`
     (`pipe(imgL, imgR)`: its backbone's kernels ride the lanes too)."""
 
+    #: calls issued on EVERY lane when the pipeline is first used, before anything is returned to the caller: a lane's stream has its
+    #: own pool in PyTorch's caching allocator, and the first calls on a cold lane pay a hipMalloc per temporary (~40 per pair)
+    #: -- measured r05 with bench.py --steps 20 --warmup 5 on 6 lanes (the sixth lane saw its first call inside the timed steps):
+    #: 577-582 pairs/s, 589 with 6 warm-up steps, 596 with 12, 602-609 with 30; with 2 / 4 throw-away calls per lane here the 5-step
+    #: warm-up reads 595-597 / 598-600 (`profiles/r05_ab_warmup_k20.txt`).  One-time set-up like the weight packing of the priming
+    #: call; what it costs is 4 x lanes forward passes at construction.
+    LANE_WARM_CALLS = 4
+
     def __init__(self, segment, lanes=6):
         assert lanes >= 1 and not segment.training
         self.segment, self.nlanes = segment, int(lanes)
@@ -412,6 +420,17 @@ class PairPipeline:
             if self.nlanes > 1:
                 M.E.retain_replaced(True)
         M.E.drop_retired()
+        if self.nlanes > 1:             # every lane's allocator pool filled by throw-away calls (see LANE_WARM_CALLS)
+            cur = torch.cuda.current_stream(dev)
+            for _ in range(self.LANE_WARM_CALLS):
+                for lane in self.lanes:
+                    lane.wait_stream(cur)
+                    with torch.cuda.stream(lane), torch.no_grad(), overlap_override(False):
+                        self.segment(*inputs)
+                    for t in inputs:
+                        if isinstance(t, torch.Tensor):
+                            t.record_stream(lane)
+            torch.cuda.synchronize(dev)
         self._primed = True
 
     def close(self):
