@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void stem_left_fused(const float* __restric
                                                            int Cout, int H, int W) {
     constexpr int NC = (NTERMS == 6) ? 3 : 2, KS = 2, C = 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float (*atile)[HH][HW] = reinterpret_cast<float (*)[HH][HW]>(smem);              // [ND][6][34]
-    float (*qtile)[QCOLS] = reinterpret_cast<float (*)[QCOLS]>(smem + ND * HH * HW);   // [64][224]
+    float (*atile)[HH][HW] = reinterpret_cast<float (*)[HH][HW]>(smem) + 1;          // [-1 .. ND][6][34]: planes -1 and ND are zero (the padding along the candidates)
+    float (*qtile)[QCOLS] = reinterpret_cast<float (*)[QCOLS]>(smem + (ND + 2) * HH * HW);   // [64][224]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int w0 = blockIdx.x * FTW, h0 = blockIdx.y * FTH, b = blockIdx.z;
@@ -173,6 +173,10 @@ __global__ __launch_bounds__(256, 2) void stem_left_fused(const float* __restric
         for (int k = 0; k < NE; ++k) {
             const int e = tid + 256 * k;
             if (e < ND * NPOSH) (&atile[0][0][0])[e] = av[k];
+        }
+        if (tid < NPOSH) {
+            (&atile[-1][0][0])[tid] = 0.f;
+            (&atile[ND][0][0])[tid] = 0.f;
         }
     }
 
@@ -204,7 +208,12 @@ __global__ __launch_bounds__(256, 2) void stem_left_fused(const float* __restric
         }
     }
 
-    const int cl = tid >> 7, pos = tid & 127, ty = pos >> 5, tx = pos & 31;     // multiply-add phase: (channel of the pair, position)
+    // multiply-add phase: a thread owns one position, BOTH channels of the pair and half of the candidates (r05: it owned one channel and
+    // all candidates -- the same 24 accumulators, but the two channels of a position share the attention operand, so their 27 x 12
+    // multiply-adds are v_pk_fma_f32 pairs: half the VALU instructions, 180 instead of 243 LDS reads per thread, same sums in the same order)
+    const int jh = tid >> 7, pos = tid & 127, ty = pos >> 5, tx = pos & 31;
+    constexpr int NJ = ND / 2;                       // candidates per thread
+    static_assert(ND % 2 == 0, "the candidates split over two thread halves");
     const int h = h0 + ty, w = w0 + tx;
     const bool inside = h < H && w < W;
     const int npairs = Cout / 2;
@@ -246,29 +255,32 @@ __global__ __launch_bounds__(256, 2) void stem_left_fused(const float* __restric
         }
         __syncthreads();
         // ---- 27 multiply-adds per output: Q row of (tap, channel cl of the pair) = tap * 2 + cl ----
-        float o[ND];
+        f32x2_t o[NJ];                   // (channel 2 g, channel 2 g + 1) of candidate jh * NJ + j
 #pragma unroll
-        for (int j = 0; j < ND; ++j) o[j] = 0.f;
+        for (int j = 0; j < NJ; ++j) o[j] = f32x2_t{0.f, 0.f};
+        const int j0 = jh * NJ;
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int kh = s / 3, kw = s % 3;
             const int hp = (ty + kh) * HW + tx + kw;
-            float av[ND + 2];
-            av[0] = 0.f;
-            av[ND + 1] = 0.f;
+            float av[NJ + 2];            // av[1 + j] = att[j0 + j]; av[0], av[NJ + 1]: the neighbours (zero padding along the candidates)
 #pragma unroll
-            for (int j = 0; j < ND; ++j) av[1 + j] = atile[j][ty + kh][tx + kw];
+            for (int j = -1; j <= NJ; ++j) av[1 + j] = atile[j0 + j][ty + kh][tx + kw];
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd) {
-                const float v = qtile[((kd * 3 + kh) * 3 + kw) * 2 + cl][hp];
+                const int qrow = ((kd * 3 + kh) * 3 + kw) * 2;
+                const f32x2_t v = {qtile[qrow][hp], qtile[qrow + 1][hp]};
 #pragma unroll
-                for (int j = 0; j < ND; ++j) o[j] = fmaf(av[j + kd], v, o[j]);
+                for (int j = 0; j < NJ; ++j) o[j] = __builtin_elementwise_fma(f32x2_t{av[j + kd], av[j + kd]}, v, o[j]);
             }
         }
         if (inside) {
-            float* ob = out + (((size_t)b * Cout + 2 * g + cl) * ND) * plane + (size_t)h * W + w;
+            float* ob = out + (((size_t)b * Cout + 2 * g) * ND + j0) * plane + (size_t)h * W + w;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) ob[(size_t)j * plane] = o[j];
+            for (int j = 0; j < NJ; ++j) {
+                ob[(size_t)j * plane] = o[j][0];
+                ob[((size_t)ND + j) * plane] = o[j][1];
+            }
         }
     }
 }
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void stem_left_fused(const float* __restric
 template <int ND>
 int launch_fused(const float* left, const void* wsplit, const float* att, float* out, int B, int Cout, int H, int W,
                  int nterms, hipStream_t st) {
-    const size_t lds = ((size_t)ND * HH * HW + 64 * QCOLS) * sizeof(float);
+    const size_t lds = ((size_t)(ND + 2) * HH * HW + 64 * QCOLS) * sizeof(float);
     dim3 grid(ss::ceil_div(W, FTW), ss::ceil_div(H, FTH), B);
     if (nterms == 6) {
         auto kern = stem_left_fused<ND, 6>;
