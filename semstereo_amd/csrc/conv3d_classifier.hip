@@ -43,24 +43,23 @@ __device__ __forceinline__ int patch_candidates(int x, int ts, int ntile, int (&
     if (r == ts - 1 && t0 + 1 < ntile) { t[n] = t0 + 1; p[n] = 0; ++n; }
     return n;
 }
+// grid (ceil(W / 256), H, B * D): the plane and row candidates are wave-uniform (scalar arithmetic), a lane owns one column
 __global__ __launch_bounds__(256) void classifier_patch_sum_kernel(const float* __restrict__ patches, float* __restrict__ out, int D, int H,
-                                                                    int W, int tiles_w, int tiles_h, int tiles_d, long long total) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int w = (int)(i % W);
-    long long r = i / W;
-    const int h = (int)(r % H); r /= H;
-    const int d = (int)(r % D);
-    const int b = (int)(r / D);
+                                                                    int W, int tiles_w, int tiles_h, int tiles_d) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    const int d = blockIdx.z % D, b = blockIdx.z / D;
+    if (w >= W) return;
     const float* pb = patches + (size_t)b * tiles_w * tiles_h * tiles_d * HEAD_PATCH;
     int td[2], pd[2], th[2], ph[2], tw[2], pw[2];
     const int nd = patch_candidates(d, 4, tiles_d, td, pd), nh = patch_candidates(h, 4, tiles_h, th, ph), nw = patch_candidates(w, 32, tiles_w, tw, pw);
     float v = 0.f;
     for (int a = 0; a < nd; ++a)
-        for (int c = 0; c < nh; ++c)
-            for (int e = 0; e < nw; ++e)
-                v = ss::add_rn(v, pb[(size_t)((td[a] * tiles_h + th[c]) * tiles_w + tw[e]) * HEAD_PATCH + (pd[a] * 6 + ph[c]) * 34 + pw[e]]);
-    out[i] = v;
+        for (int c = 0; c < nh; ++c) {
+            const float* row = pb + (size_t)((td[a] * tiles_h + th[c]) * tiles_w) * HEAD_PATCH + (pd[a] * 6 + ph[c]) * 34;
+            for (int e = 0; e < nw; ++e) v = ss::add_rn(v, row[tw[e] * HEAD_PATCH + pw[e]]);
+        }
+    out[(((size_t)b * D + d) * H + h) * W + w] = v;
 }
 
 }  // namespace
@@ -84,13 +83,13 @@ extern "C" int ss_conv3d_classifier_fused_fwd(const float* in, const void* wspli
     // 4-row tile at batch 1 keep the two-launch form
     const long long per_pair = (long long)ss::ceil_div(W, 32) * ss::ceil_div(H, 8) * ss::ceil_div(D, 2);
     if (per_pair < 512) return SS_ERR_UNSUPPORTED;
+    if (H > 65535 || (long long)B * D > 65535) return SS_ERR_UNSUPPORTED;     // (the patch sum's grid)
     hipStream_t st = ss::as_stream(stream);
     const int rc = launch_bgm<1, 4, 4, 4, F16X3, false, 1, 3, 1, false, false, true>(
         in, wsplit, scale, shift, nullptr, nullptr, patches, B, Cin, D, H, W, 32, 1, st, reinterpret_cast<const float*>(head_w));
     if (rc != SS_OK) return rc;
     const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, 4), tiles_d = D / 4;
-    const long long total = (long long)B * D * H * W;
-    hipLaunchKernelGGL(classifier_patch_sum_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0, st, patches, out, D, H, W,
-                       tiles_w, tiles_h, tiles_d, total);
+    hipLaunchKernelGGL(classifier_patch_sum_kernel, dim3(ss::ceil_div(W, 256), H, B * D), dim3(256), 0, st, patches, out, D, H, W, tiles_w,
+                       tiles_h, tiles_d);
     return ss::check_launch();
 }

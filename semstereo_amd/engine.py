@@ -317,8 +317,9 @@ def classifier_fused_applies(x, nterms0):
     it offers the chip), never by the batch, so that a pair gets the same bits alone and in a batch."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and nterms0 == 19):
         return False
-    _, C, D, H, W = x.shape
-    return C % 8 == 0 and D % 4 == 0 and ((W + 31) // 32) * ((H + 7) // 8) * ((D + 1) // 2) >= 512 and C * D * H * W * 4 < 0x7fffffff
+    B, C, D, H, W = x.shape
+    return (C % 8 == 0 and D % 4 == 0 and ((W + 31) // 32) * ((H + 7) // 8) * ((D + 1) // 2) >= 512 and C * D * H * W * 4 < 0x7fffffff
+            and H <= 65535 and B * D <= 65535)
 
 
 def pack_classifier_head_weight(w2):
