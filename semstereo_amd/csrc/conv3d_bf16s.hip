@@ -646,9 +646,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                 const float v = fmaxf(ss::add_rn(ss::mul_rn(acc[i][r] * (aff[128 + cl] * hunscale), aff[cl]), aff[64 + cl]), hfloor);
                 y[r] = ok ? v : 0.f;            // positions outside the volume: the head's zero padding
             }
-            f32x16 tt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tt[r] = 0.f;
+            f32x16 tt = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 unsigned bh[4], bm[4], bl[4];
