@@ -636,6 +636,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         const float hfloor = (relu & 1) ? 0.f : -__builtin_inff();
         const bool colok = ow0 + l31 < Wo && od0 + dzw < Do;
         // ---- t[tap row][position] of this wave's rows: the accumulators become the B operand as they are ----
+#ifndef SS_EXP_HEAD_NOT           // (timing experiment, wrong results: the head's contraction skipped)
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const bool ok = colok && oh0 + hy0 + i < Ho;
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             acc[i] = tt;                        // register 3 * ps + kh of this lane half: (kd, kw) pair ps + 5 * half, tap row kh
             __builtin_amdgcn_sched_barrier(0);  // one row at a time (all four interleaved: 43 spilled registers)
         }
+#endif
         // ---- over kh, in registers: U[ps][ph] = sum_row t[row][3 ps + (row + 2 - ph)], ph = 0..5 the patch row (fixed order) ----
         float* ubuf = reinterpret_cast<float*>(lds);      // [10 pairs][6 patch rows][4 planes][32 columns], over the dead activation tile
         float* ub = ubuf + (5 * half * 6 * 4 + wave) * 32 + l31;      // (one per-lane address, the rest immediate offsets)
@@ -686,6 +688,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+#ifndef SS_EXP_HEAD_NOP           // (timing experiment, wrong results: the patch positions' sums skipped)
         // ---- over (kd, kw): each thread owns patch positions q = tid + 256 i ----
         float* pout = out + ((size_t)b * ntiles + tile) * HEAD_PATCH;
         int ptid = tid;                // (opaque: the positions' index arithmetic is redone here per tile instead of living in registers -- or scratch -- through the K loop)
@@ -716,6 +719,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                 pout[q] = pv;
             }
         }
+#endif
         __syncthreads();               // the next tile's first chunk is staged over ubuf
     } else {
     set_outputs(tile);                 // (output addressing is derived here, not kept live through the K loop)
