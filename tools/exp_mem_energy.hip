@@ -1,6 +1,6 @@
 // What does a byte cost?  One streaming pattern for ~4 s over a 1 GiB window (far beyond L2 and the 256 MiB Infinity Cache) while
 // tools/power_of.sh samples the socket power beside it: read-only (16 B per lane), write-only (4 / 16 B per lane, default / nontemporal),
-// copy.  usage (GPU box): tools/_build/exp_mem_energy <read|write4|write16|write16nt|copy|idle>      prints the achieved rate
+// copy.  usage (GPU box): tools/_build/exp_mem_energy <read|read4|write4|write16|write16nt|copy|idle>      prints the achieved rate
 // build: hipcc -O3 --offload-arch=gfx950 tools/exp_mem_energy.hip -o tools/_build/exp_mem_energy
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -13,6 +13,11 @@ __global__ __launch_bounds__(256) void k_read(const f32x4* __restrict__ in, floa
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) s += __builtin_nontemporal_load(in + i);
     if (s.x + s.y + s.z + s.w == 12345.678f) *sink = s.x;
+}
+__global__ __launch_bounds__(256) void k_read4(const float* __restrict__ in, float* __restrict__ sink, size_t n) {
+    float s = 0.f;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += __builtin_nontemporal_load(in + i);
+    if (s == 12345.678f) *sink = s;
 }
 __global__ __launch_bounds__(256) void k_write4(float* __restrict__ out, size_t n) {
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)i;
@@ -46,7 +51,8 @@ int main(int argc, char** argv) {
     double per_launch = strcmp(mode, "copy") == 0 ? 2.0 * bytes : (double)bytes;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 4.0) {
         for (int r = 0; r < 10; ++r) {
-            if (!strcmp(mode, "read")) hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, (const f32x4*)a, sink, n4);
+            if (!strcmp(mode, "read4")) hipLaunchKernelGGL(k_read4, dim3(grid), dim3(256), 0, 0, (const float*)a, sink, n);
+            else if (!strcmp(mode, "read")) hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, (const f32x4*)a, sink, n4);
             else if (!strcmp(mode, "write4")) hipLaunchKernelGGL(k_write4, dim3(grid), dim3(256), 0, 0, b, n);
             else if (!strcmp(mode, "write16")) hipLaunchKernelGGL(k_write16<false>, dim3(grid), dim3(256), 0, 0, (f32x4*)b, n4);
             else if (!strcmp(mode, "write16nt")) hipLaunchKernelGGL(k_write16<true>, dim3(grid), dim3(256), 0, 0, (f32x4*)b, n4);
