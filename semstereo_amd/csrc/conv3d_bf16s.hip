@@ -121,8 +121,9 @@ struct BCfg {
 #ifndef SS_WLDS_NT4
 #define SS_WLDS_NT4 0             // 1: the 4-row tile also takes its weight fragments through LDS (variant builds)
 #endif
-constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD) {
-    return NTERMS == 19 && S == 1 && (NT == 1 || (SS_WLDS_NT4 && NT == 4)) && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
+constexpr bool wlds_form(int S, int NT, int NTERMS, int MT, int KD, bool gather = false) {
+    // (the gather form's tile has no LDS left for the 28 KB slab at two workgroups per CU)
+    return NTERMS == 19 && S == 1 && (NT == 1 || (SS_WLDS_NT4 && NT == 4 && !gather)) && MT == 1 && KD == 3;       // (NT = 2: 43 B/clk, measured +3 %: left alone)
 }
 // gather form: per halo position one candidate word and two attention words (this tile's, the next tile's), each thread's
 // own positions p = tid + 256 i -> 3 x NPOS x 256 floats
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // step's 2 KB of weight fragments every 96-192 cycles ask the vector L1 for 43-85 B/clk of its 64.  The chunk's fragments
     // (14 steps x 2 terms, 28 KB) are then brought into LDS once per workgroup by LDS-DMA loads (no registers) and read
     // from there by the four waves (deconv3d_bf16s.hip has the measurement: -11 %).
-    constexpr bool WLDS = wlds_form(S, NT, NTERMS, MT, KD);
+    constexpr bool WLDS = wlds_form(S, NT, NTERMS, MT, KD, GATHER);
     static_assert(!ACCB || NTERMS == F16X3, "chunk-blocked accumulation: fp16 form only");
     static_assert(!WLDS || MS == 1, "the LDS copy of the weights is one channel tile's");
     using C = BCfg<S, NT, TD, TH, KD, NC, WLDS ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS, gather_slots(GATHER, S, TD, TH, KD) + (HEAD ? HEAD_WSLOTS : 0)>;
@@ -895,7 +896,7 @@ template <int S, int NT, int TD, int TH, int NTERMS, bool GATED, int MT, int KD 
 int launch_bgm(const float* in, const void* wsplit, const float* scale, const float* shift, const float* residual,
               const float* gate, float* out, int B, int Cin, int D, int H, int W, int Cout, int relu, hipStream_t st,
               const float* cand = nullptr, const float* catt = nullptr, const float* in2 = nullptr, int bsplit = 0) {
-    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2, wlds_form(S, NT, NTERMS, MT, KD) ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS,
+    using C = BCfg<S, NT, TD, TH, KD, (NTERMS == 6) ? 3 : 2, wlds_form(S, NT, NTERMS, MT, KD, GATHER) ? ((KD * 9 + 1) / 2) * 2 * 64 : 0, MS,
                    gather_slots(GATHER, S, TD, TH, KD) + (HEAD ? HEAD_WSLOTS : 0)>;
     const int Do = (D + 2 * (KD / 2) - KD) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     const int tiles_w = ss::ceil_div(Wo, 32), tiles_h = ss::ceil_div(Ho, TH), tiles_d = ss::ceil_div(Do, TD);
