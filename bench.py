@@ -470,7 +470,8 @@ def side_rooflines(res, seg, M, timer, H, W, maxdisp, B, device):
     # classif.0 1.82, the largest transposed conv 2.0, the largest stride-2 conv 2.13), so what bounds it is neither the nominal
     # MFMA peak nor HBM but joules per launch -- which is why launch-level scheduling variants measure flat (EXPERIMENTS.md part E).
     try:
-        if semstereo_amd.engine.CONV_ENGINE == "f16x3" and hasattr(M, "stem_gather_half"):
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1      # (N = 1 only: every rank would call rocm-smi)
+        if semstereo_amd.engine.CONV_ENGINE == "f16x3" and hasattr(M, "stem_gather_half") and not multi:
             gk = torch.Generator(device=device).manual_seed(11)
             stem = M.BasicConv(64, 32, is_3d=True, kernel_size=3, stride=1, padding=1).to(device).eval()
             cr = torch.randn(B, 32, H4, W4, generator=gk, device=device)
