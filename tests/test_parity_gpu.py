@@ -860,6 +860,25 @@ def test_classifier_one_pass_form_against_the_two_launch_form_and_float64(sa, sh
     assert rms[0] <= 1.1 * rms[1] + 1e-9 and rms[0] <= 2e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(1, 24, 256, 256), (1, 32, 128, 128), (2, 36, 128, 160)])
+def test_classifier_one_pass_form_at_the_live_shapes(sa, shape, monkeypatch):
+    """The two classifiers of the 1024^2 / maxdisp 128 pair at their live shapes (`classif` on [32,24,256,256], `classif_att_` on
+    [32,32,128,128]) and a 36-plane slab at batch 2 (the 2048^2 pair's depth): one pass against two launches, every output."""
+    from oracle import detdata as dd
+    B, D, H, W = shape
+    m = _det_classifier(sa, 940)
+    x = torch.relu(dev(dd.t_normalish((B, 32, D, H, W), 941)))
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(sa.engine, "CLASSIFIER_FUSED", flag)
+        with torch.no_grad():
+            outs.append(m(x))
+    scale = float(outs[1].abs().max())
+    err = float((outs[0] - outs[1]).abs().max())
+    REPORT[f"classifier_one_pass_live/{shape}"] = err / scale
+    assert err <= 4e-6 * scale
+
+
 def test_classifier_one_pass_form_is_batch_invariant_and_decided_by_the_layer(sa, monkeypatch):
     """A pair gets the same bits alone and in a batch: the one-pass form is chosen by what ONE pair of the layer offers the chip
     (>= 512 tiles of 2 x 8 x 32), never by the batch; layers below that keep the two-launch form at every batch size."""
