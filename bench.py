@@ -266,7 +266,8 @@ def parity_vs_reference(sa, fixture_path, name, device):
         r = seg(fl4.to(device), fr4.to(device), fl8.to(device), fr8.to(device))
     err = (r["pred"].cpu().squeeze(1) - torch.as_tensor(g[f"{name}/pred_map"])).abs()
     mine = cases.candidate_set_hash(r["samples"].cpu().numpy(), md // 4)
-    out = {"fixture": f"tests/golden/segment_full.npz:{name} (reference outputs; closed-form input, calibrated BatchNorm statistics)",
+    out = {"fixture": f"tests/golden/segment_full.npz:{name} (reference outputs; closed-form input, "
+                      + ("calibrated" if "_cal" in name else "DEFAULT (uncalibrated)") + " BatchNorm statistics)",
            "epe_vs_reference_px": float(err.mean()), "epe_vs_reference_fullres_px": 4.0 * float(err.mean()),
            "median_abs_err_px": float(err.median()), "max_abs_err_px": float(err.max()),
            "pixels_beyond_1e-3": int((err > 1e-3).sum()), "pixels": int(err.numel()),
@@ -297,21 +298,40 @@ def seeded_pairs_parity(seg, M, engines, n_pairs, H, W, maxdisp, device, threads
         fl4, fr4 = synth_features(1, 128, H // 4, W // 4, 12, 301 + 2 * i, device)
         c4l, c4r, c8l, c8r = fl4.cpu(), fr4.cpu(), fl8.cpu(), fr8.cpu()
         t0 = time.perf_counter()
-        ref = oseg.hot_segment(P, c4l, c4r, c8l, c8r, maxdisp)
+        ref = oseg.hot_segment(P, c4l, c4r, c8l, c8r, maxdisp, keep=True)
         _, smp64, _ = oseg.attention_branch(P64, c8l.double(), c8r.double(), c4l.double(), c4r.double(), maxdisp)
         smp64 = smp64.float()
         secs.append(time.perf_counter() - t0)
         rows["oracle_fp32"].append({"picks_differing_from_float64": int((ref["samples"] != smp64).any(dim=1).sum())})
+        # the oracle's own margin at the second hard pick (2 of 24 costs, models/submodule.py:436-437): where its 2nd / 3rd largest
+        # costs are within 1e-4 another fp32 evaluation may keep the other candidate and move the pixel by whole disparities
+        csort = ref["cost"].squeeze(1).sort(dim=1, descending=True).values
+        tie2 = ((csort[:, 1] - csort[:, 2]) < 1e-4).unsqueeze(1)
+        ref_smp_d, ref_att_d = ref["samples"].to(device), ref["att_topk"].to(device)
         for e in engines:
             semstereo_amd.engine.CONV_ENGINE = e
             with torch.no_grad():
                 o = seg(fl4, fr4, fl8, fr8)
+                # r06: the same pair with the ORACLE's top-24 picks put back wherever the HIP attention branch chose
+                # otherwise (the strict form of tests/strict.py, against the oracle instead of a fixture): what is left is the
+                # arithmetic of the matching branch alone
+                att, smp_h, _, _ = seg.attention_branch(fl4, fr4, fl8, fr8)
+                other = (smp_h != ref_smp_d).any(dim=1, keepdim=True)                      # [B,1,H4,W4]
+                smp_r = torch.where(other, ref_smp_d, smp_h)
+                att_r = torch.where(other.unsqueeze(1), ref_att_d, att)
+                pred_r = seg.matching_branch(fl4, fr4, att_r.contiguous(), smp_r.contiguous())
             err = (o["pred"].cpu() - ref["pred"]).abs()
+            err_r = (pred_r.cpu() - ref["pred"]).abs()
             smp = o["samples"].cpu()
             rows[e].append({"epe_vs_oracle_px": float(err.mean()), "pixels_abs_err_gt_1e-3": float((err > 1e-3).float().mean()),
                             "pixels_with_other_candidates": int((smp != ref["samples"]).any(dim=1).sum()),
                             "picks_differing_from_float64": int((smp != smp64).any(dim=1).sum()),
+                            "epe_picks_restored_px": float(err_r.mean()),
+                            "epe_picks_restored_off_top2_ties_px": float(err_r[~tie2].mean()),
+                            "pixels_at_top2_ties": int(tie2.sum()),
+                            "pixels_gt_1e-3_picks_restored_off_ties": int(((err_r > 1e-3) & ~tie2).sum()),
                             "median_abs_err_px": float(err.median())})
+        del ref
     semstereo_amd.engine.CONV_ENGINE, oseg.GWC_CLOSED_FORM = keep, keep_cf
 
     def ms(vals):
@@ -319,6 +339,49 @@ def seeded_pairs_parity(seg, M, engines, n_pairs, H, W, maxdisp, device, threads
         return [round(float(t.mean()), 7), round(float(t.std(unbiased=False)), 7)]
     stats = {e: {k_: ms([r[k_] for r in rows[e]]) for k_ in rows[e][0] if k_ != "median_abs_err_px"} for e in rows}
     return stats, rows, secs
+
+
+def side_config_leg(seg, B2, H2, W2, md2, streams, steps, device):
+    """One more workload of BASELINE.json timed beside the headline: `steps` steps of batch B2 at H2 x W2 / md2 on one
+    stream, then round-robin on `streams` lanes -- the same two legs as the headline, between device-wide synchronisations, rotating
+    two input sets.  The weights are the headline segment's (the parameters do not depend on maxdisp or the image size)."""
+    seg2 = seg
+    if md2 != seg.maxdisp:
+        seg2 = semstereo_amd.HotSegment(md2).to(device).eval()
+        seg2.load_state_dict(seg.state_dict())
+    sets = []
+    for s_ in range(2):
+        fl8, fr8 = synth_features(B2, 256, H2 // 8, W2 // 8, 6, 7100 + 1000 * s_, device)
+        fl4, fr4 = synth_features(B2, 128, H2 // 4, W2 // 4, 12, 7200 + 1000 * s_, device)
+        sets.append((fl4, fr4, fl8, fr8))
+    rec = {"workload": f"{H2}x{W2} maxdisp={md2} batch={B2}", "steps": steps}
+
+    def timed(call, nwarm):
+        for i in range(nwarm):
+            call(*sets[i % 2])
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            call(*sets[i % 2])
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    def plain(*fs):
+        with torch.no_grad():
+            return seg2(*fs)
+    dt = timed(plain, 3)
+    rec["single_stream_pairs_per_s"], rec["single_stream_ms_per_step"] = B2 * steps / dt, 1e3 * dt / steps
+    if streams > 1:
+        pipe2 = semstereo_amd.PairPipeline(seg2, streams)
+        dt = timed(pipe2, 2 * streams)
+        rec["pairs_per_s"], rec["ms_per_step"], rec["lanes_in_flight"] = B2 * steps / dt, 1e3 * dt / steps, streams
+        pipe2.close()
+        del pipe2
+    else:
+        rec["pairs_per_s"], rec["ms_per_step"], rec["lanes_in_flight"] = rec["single_stream_pairs_per_s"], rec["single_stream_ms_per_step"], 1
+    del sets, seg2
+    torch.cuda.empty_cache()
+    return rec
 
 
 def power_under_load(run_steps):
@@ -594,6 +657,8 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-side-rooflines", action="store_true", help="skip the bandwidth kernels measured beside the step")
     ap.add_argument("--power-seconds", type=float, default=2.5, help="seconds of the step loop sampled with rocm-smi (socket power, shader clock; N = 1 only; 0: skip)")
+    ap.add_argument("--side-config-steps", type=int, default=12, help="timed steps of each side leg (configs[2]: batch 8; configs[4] per GPU: "
+                    "2048^2 / 192 batch 1) run at N = 1 beside the configs[1] headline; 0: skip")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), help="where the forensics go")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (one launch per step instead "
                     "of ~45 from Python); the per-kernel HIP-event timers are off in this mode")
@@ -745,6 +810,17 @@ def main():
     if args.power_seconds > 0 and world == 1 and not dry:
         n_power = int(args.power_seconds / max(tmax / args.steps, 1e-6)) + 1
         power = power_under_load(lambda: timed_run(n_power, 0))
+
+    # the other single-GPU workloads of BASELINE.json, driver-timed in the same run (N = 1 only; a few hundred ms each):
+    # configs[2] (1024^2 / 128, batch 8) and the per-GPU workload of configs[4] (2048^2 / 192, batch 1)
+    side_cfg = {}
+    if world == 1 and not dry and not graphed and args.side_config_steps > 0 and (H, W, maxdisp, B) == (1024, 1024, 128, 1):
+        for key, (B2, H2, W2, md2) in (("configs2", (8, 1024, 1024, 128)), ("configs4_per_gpu", (1, 2048, 2048, 192))):
+            try:
+                side_cfg[key] = side_config_leg(seg, B2, H2, W2, md2, args.streams, args.side_config_steps, device)
+            except Exception as e:       # noqa: BLE001  (never lose the headline to a side leg)
+                side_cfg[key] = {"error": repr(e)[:200]}
+        assert M.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside a side leg"
 
     # what a SCALE run must show to be self-verifying -- the group's size as torch.distributed sees it, every rank's
     # own rate, and the bytes of the one collective that follows the forward (the padded all_gather of the [b,1,H/4,W/4] disparities)
@@ -899,6 +975,14 @@ def main():
     line["steady_state"] = steady
     line["rates"]["steady_state_pairs_per_s"] = steady["pairs_per_s"] if steady else None
     line["rates"]["power_under_load"] = power
+    for key, rec in side_cfg.items():          # rates.configs2_pairs_per_s / rates.configs4_per_gpu_pairs_per_s (+ ms per step, one-stream rate)
+        if "error" in rec:
+            line["rates"][f"{key}_error"] = rec["error"]
+            continue
+        line["rates"][f"{key}_pairs_per_s"] = rec["pairs_per_s"]
+        line["rates"][f"{key}_ms_per_step"] = rec["ms_per_step"]
+        line["rates"][f"{key}_single_stream_pairs_per_s"] = rec["single_stream_pairs_per_s"]
+    detail["side_configs"] = side_cfg
     line["dist"] = dist_rec
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and parity: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the same workload: about 10 s of CPU
@@ -944,6 +1028,21 @@ def main():
                     parity["reference_picks_restored"] = {k_: rp[k_] for k_ in (
                         "epe_vs_reference_fullres_px", "max_err_off_ties_px", "pixels_beyond_1e-3", "hip_vs_truth_epe_off_ties_px",
                         "reference_vs_truth_epe_off_ties_px", "hip_vs_truth_max_off_ties_px", "reference_vs_truth_max_off_ties_px")}
+                # r06: the record with DEFAULT (uncalibrated) BatchNorm statistics -- the state of the random-init weights
+                # the timed step and the seeded pairs run on: 13 % of its pixels sit within 1e-4 (relative) of a top-24 tie and 7 % within
+                # 1e-4 of a top-2 tie in the REFERENCE's own evaluation.  Plain run, and with the reference's picks restored.
+                if "f1024_md128/pred_map" in np.load(fx).files:
+                    pu = parity_vs_reference(semstereo_amd, fx, "f1024_md128", device)
+                    detail["parity_vs_reference_uncalibrated"] = pu
+                    rp_u = pu.get("reference_picks_restored") or {}
+                    parity["fixture_uncal"] = {
+                        "epe_plain_fullres_px": pu["epe_vs_reference_fullres_px"], "pixels_with_other_candidates": pu["pixels_with_other_candidates"],
+                        "unexplained_candidate_differences": rp_u.get("unexplained_candidate_differences"),
+                        "epe_picks_restored_fullres_px": rp_u.get("epe_vs_reference_fullres_px"),
+                        "epe_picks_restored_off_ties_fullres_px": (4.0 * rp_u["epe_vs_reference_off_ties_px"]) if rp_u else None,
+                        "max_err_off_ties_px": rp_u.get("max_err_off_ties_px"), "pixels_at_top2_ties": rp_u.get("pixels_at_top2_ties"),
+                        "hip_vs_truth_epe_off_ties_px": rp_u.get("hip_vs_truth_epe_off_ties_px"),
+                        "reference_vs_truth_epe_off_ties_px": rp_u.get("reference_vs_truth_epe_off_ties_px")}
                 epe_plain = [pvs[n_]["epe_vs_reference_fullres_px"] for n_ in names]
                 epe_rest = [(pvs[n_].get("reference_picks_restored") or {}).get("epe_vs_reference_fullres_px") for n_ in names]
                 parity["fixtures_1024"] = {

@@ -161,7 +161,8 @@ SEGMENT_WHU = {
     "whu96x160_md256_b2": (2, 96, 160, 256),     # D8 = 32, D4 = 64
 }
 _SEGMENT_SEED = {"whu128_md128": 828, "whu96x160_md256_b2": 832, "s128": 800, "s96x160_b2": 804, "s256_md128": 808, "s192x256_md192": 812,
-                 "s256_md128_cal": 816, "f1024_md128_cal": 820, "f2048_md192_cal": 824, "f1024_md128_cal_b": 836, "f1024_md128_cal_c": 840}
+                 "s256_md128_cal": 816, "f1024_md128_cal": 820, "f2048_md192_cal": 824, "f1024_md128_cal_b": 836, "f1024_md128_cal_c": 840,
+                 "f1024_md128": 844}
 
 # "_cal": BatchNorm running statistics CALIBRATED on the fixture's own input (one pass of the reference with batch
 # statistics, momentum 1), as a trained network has them: every layer's activations are normalised, so the costs of a
@@ -181,6 +182,10 @@ SEGMENT_FULL = {
     # figure of one record is one toss of the near-tied top-24 picks; three records are three
     "f1024_md128_cal_b": (1, 1024, 1024, 128),
     "f1024_md128_cal_c": (1, 1024, 1024, 128),
+    # r06: the same size with the DEFAULT (uncalibrated) BatchNorm statistics -- running_mean 0, running_var 1, the state of
+    # random-init weights, which is what bench.py's seeded pairs run on: the costs of a pixel's 24 candidates spread over ~0.05 instead of
+    # O(1), so many more pixels sit near a tie at either hard pick.  The record says what the REFERENCE does there.
+    "f1024_md128": (1, 1024, 1024, 128),
 }
 FULL_SAMPLES = 2048
 # The explained-deviation criterion of the hot-segment tests (tests/test_parity_gpu.py, tests/test_fullsize_gpu.py,

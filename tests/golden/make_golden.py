@@ -363,8 +363,9 @@ def gen_segment_full(ms, only=None):
         net, P = build_ref_net(ms, maxdisp)
         fl4, fr4, fl8, fr8, _ = cases.segment_inputs(n)
         feats = (fl4, fr4, fl8, fr8)
-        for key, v in calibrate_batchnorm(ms, net, B, H, W, feats).items():
-            out[f"{n}/bn/{key}"] = f32(v)
+        if "_cal" in n:                        # (a name without "_cal": the default statistics of random-init weights, r06)
+            for key, v in calibrate_batchnorm(ms, net, B, H, W, feats).items():
+                out[f"{n}/bn/{key}"] = f32(v)
         cap = run_reference_segment(ms, net, B, H, W, feats)
         (cost_sq, samples, k), pred = cap["regression_topk"][0]
         H4, W4 = H // 4, W // 4

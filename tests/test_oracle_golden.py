@@ -137,10 +137,11 @@ def test_param_table_matches_reference_names():
     assert all(v.dtype == torch.float32 for v in P.values())
 
 
-def test_hot_segment_full_size_checksums(golden):
+@pytest.mark.parametrize("name", ["f1024_md128_cal", "f1024_md128"])
+def test_hot_segment_full_size_checksums(golden, name):
     """BASELINE.json configs[1]'s size (1024 x 1024, maxdisp 128): the oracle against the reference's checksum record
-    (per-stage sums and sampled voxels; pred, pred_att, candidates and margins at 2048 sampled pixels).  ~25 s of CPU."""
-    name = "f1024_md128_cal"
+    (per-stage sums and sampled voxels; pred, pred_att, candidates and margins at 2048 sampled pixels).  ~25 s of CPU each:
+    with calibrated BatchNorm statistics and (r06) with the default ones of random-init weights."""
     g = golden["segment_full"]
     B, H, W, maxdisp = cases.segment_shape(name)
     P = cases.segment_params(name, g)
