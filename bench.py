@@ -1055,8 +1055,14 @@ def main():
         if args.parity_pairs > 0:
             engines = [engine] + ([e for e in ("f32", "bf16x6") if e != engine] if not args.no_other_engines else [])
             stats, rows, secs = seeded_pairs_parity(seg, M, engines, args.parity_pairs, H, W, maxdisp, device, nthreads)
-            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] over pairs; vs the fp32 CPU oracle, picks also vs float64",
-                                      "by_conv_engine": stats}
+            # the line carries the default engine's figures in full and three per other engine; every statistic is in the detail file
+            keep_main = ("epe_vs_oracle_px", "pixels_with_other_candidates", "picks_differing_from_float64", "epe_picks_restored_px",
+                         "epe_picks_restored_off_top2_ties_px", "pixels_gt_1e-3_picks_restored_off_ties")
+            keep_other = ("epe_vs_oracle_px", "epe_picks_restored_px", "picks_differing_from_float64")
+            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] over pairs vs the fp32 CPU oracle; picks vs float64; picks_restored: the oracle's top-24 picks put back",
+                                      "by_conv_engine": {e: {k_: v for k_, v in st.items() if k_ in (keep_main if e == engine else keep_other)}
+                                                         for e, st in stats.items()}}
+            detail["seeded_pairs_stats"] = stats
             detail["seeded_pairs_rows"] = rows
             detail["seeded_pairs_oracle_seconds"] = secs
         line["parity"] = parity

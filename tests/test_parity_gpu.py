@@ -2064,7 +2064,7 @@ def test_attention_tail_training_functions_vs_float64_autograd(sa, m):
     grads_close([lh, sh], [lr, sr], 5e-5, "topk")
 
 
-@pytest.mark.parametrize("name", ["s128", "s96x160_b2"])
+@pytest.mark.parametrize("name", ["s128", "s96x160_b2", "t256_md64"])
 def test_hot_segment_training_step_runs_on_the_hip_stack(sa, name):
     """A training-mode pass of the hot segment (BatchNorm with batch statistics, autograd on: main_us3d.py:186-222): every
     module of the 3-D stack runs HIP autograd functions (no PyTorch layer: PATH_COUNTS["torch"] does not move), every
@@ -2131,10 +2131,53 @@ def test_hot_segment_training_step_runs_on_the_hip_stack(sa, name):
     # (s96x160_b2 with the fused attention tail: the matching-branch gradients sit at 3e-3 of their scale with classif.2 at 1e-6 -- the
     # signature of ONE classif.0 pre-activation on the other side of zero (tools/err_train_step.py s96x160_b2 [notail]: with the
     # statement-by-statement tail the same pass is at 1e-5 ... 4e-4); the per-kernel tests above hold every function to 5e-5)
-    if same_picks and sa.modules.CONV_ENGINE in ("f16x3", "bf16x6") and name == "s128":
+    # (r06, VERDICT r5 #5: `t256_md64` -- 256 x 256 at the reference's training default maxdisp 64, main_us3d.py:54 -- is held to the
+    # TIGHT bound as well: its closed-form input was chosen so that no ReLU lands on the other side of zero)
+    if same_picks and sa.modules.CONV_ENGINE in ("f16x3", "bf16x6") and name in ("s128", "t256_md64"):
         assert med <= 1e-4 and worst <= 5e-3, (med, worst, max(errs, key=errs.get))
     else:
         assert med <= 5e-3 and worst <= 5e-2, (med, worst, max(errs, key=errs.get), float(same.double().mean()))
+
+
+def test_hot_segment_training_step_full_size_smoke(sa):
+    """one training step at the size the reference trains at (1024 x 1024 tiles, maxdisp 64: main_us3d.py:54, 74,
+    186-222), batch 1: every parameter and every feature map receives a finite gradient, no PyTorch layer runs in the 3-D stack
+    (PATH_COUNTS["torch"] does not move), and a second pass without a weight update reproduces the gradients to rounding (the
+    scatter / statistics kernels sum through atomics, whose order differs between runs).  tools/bench_train.py times this step."""
+    if sa.modules.CONV_ENGINE == "bf16x3":
+        pytest.skip("SS_CONV_ENGINE=bf16x3")
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    H = W = 1024
+    maxdisp = 64
+    seg, _ = _segment(sa, maxdisp)
+    seg.train()
+    fl8, fr8 = dd.stereo_features(1, 256, H // 8, W // 8, 870, max_shift=3)
+    fl4, fr4 = dd.stereo_features(1, 128, H // 4, W // 4, 871, max_shift=6)
+    feats = [dev(t).requires_grad_(True) for t in (fl4, fr4, fl8, fr8)]
+    gt = dev(dd.t_uniform((1, H // 4, W // 4), 872, -15.0, 15.0))
+    before = dict(sa.modules.PATH_COUNTS)
+    torch.cuda.reset_peak_memory_stats()
+
+    def grads_of_a_pass():
+        for p_ in seg.parameters():
+            p_.grad = None
+        for t in feats:
+            t.grad = None
+        r = seg(*feats)
+        (F.smooth_l1_loss(r["pred"].squeeze(1), gt) + F.smooth_l1_loss(r["pred_att"], gt)).backward()
+        return {k: v.grad.detach().clone() for k, v in seg.named_parameters() if v.grad is not None}, [t.grad.detach().clone() for t in feats]
+    g1, f1 = grads_of_a_pass()
+    assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "a PyTorch layer ran in the training pass of the 3-D stack"
+    assert sa.modules.PATH_COUNTS.get("hip_train", 0) - before.get("hip_train", 0) >= 60
+    assert len(g1) > 60 and all(bool(torch.isfinite(g_).all()) for g_ in g1.values()) and all(bool(torch.isfinite(g_).all()) for g_ in f1)
+    assert all(float(g_.abs().max()) > 0 for g_ in f1), "a feature map received no gradient"
+    REPORT["segment_train/full_size_peak_allocated_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
+    g2, f2 = grads_of_a_pass()
+    worst = max(float((g2[k] - g1[k]).abs().max()) / (float(g1[k].abs().max()) + 1e-30) for k in g1 if k not in ("gamma", "beta"))
+    worst_f = max(float((a - b).abs().max()) / (float(a.abs().max()) + 1e-30) for a, b in zip(f1, f2))
+    REPORT["segment_train/full_size_rerun_rel_diff"] = [worst, worst_f]
+    assert worst <= 1e-4 and worst_f <= 1e-4, (worst, worst_f)
 
 
 # --------------------------------------------------------------------------------------
