@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (13 since round 6; 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -374,6 +374,13 @@ int ss_pack_conv3d_weights(const float* w, float* wpack, int Cout, int Cin, int 
  * forward entry points: ss_conv3d_bf16s_fwd on flipped weights / ss_deconv3d_fwd / the stride-2 convolution.) */
 int ss_conv3d_wgrad_fwd(const float* grad_out, const float* in, float* grad_w, int B, int Cin, int D, int H, int W,
                         int Cout, int stride, ss_stream_t stream);
+/* The same weight gradient on the bf16 matrix core (r06; conv3d_wgrad_bf16s.hip): both operands split exactly into three bf16
+ * terms, six cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation (error below the exact-fp32 MFMA's, any magnitude
+ * of gradient: bf16 has fp32's exponent range).  `workspace`: ceil(Cout/32) * ceil(Cin/32) * 27 * 1024 floats of scratch
+ * (zeroed here; the waves' accumulator tiles are summed into it with coalesced fp32 atomics and re-ordered into grad_w, which is
+ * written, not accumulated).  Same arguments and the same ConvTranspose3d convention as ss_conv3d_wgrad_fwd. */
+int ss_conv3d_wgrad_bf16s_fwd(const float* grad_out, const float* in, float* grad_w, float* workspace, int B, int Cin, int D, int H,
+                              int W, int Cout, int stride, ss_stream_t stream);
 
 /* `patch` (models/SemStereo.py:219, 274): depthwise Conv3d kernel (1,3,3), pad (0,1,1), no bias,
  * optionally fused with the channelAtt gate that follows it (:276):

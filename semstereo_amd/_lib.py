@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -69,6 +69,7 @@ _SIGNATURES = {
     "ss_pack_deconv3d_weights_bf16s": [_P, _P, _I, _I, _I, _P],
     "ss_pack_conv3d_weights": [_P, _P, _I, _I, _I, _I, _P],
     "ss_conv3d_wgrad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ss_conv3d_wgrad_bf16s_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_depthwise_patch_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_window_attention_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -1,0 +1,298 @@
+// Weight gradient of the 3x3x3 convolutions of the aggregation stack on the bf16 matrix core (training: main_us3d.py:186-222
+// back-propagates through convbn_3d / BasicConv / the hourglasses' ConvTranspose3d layers, models/SemStereo.py:106-182, 228-236):
+//
+//   dW[co, ci, kd, kh, kw] = sum_{b, od, oh, ow} gout[b, co, od, oh, ow] * in[b, ci, od*S + kd - 1, oh*S + kh - 1, ow*S + kw - 1]
+//
+// (zero padding 1, stride S = 1 or 2; ConvTranspose3d(k3, s2, p1, op1): the S = 2 form with the roles swapped, see
+// conv3d_wgrad.hip, whose exact-fp32 kernel this one replaces: measured r06 at 13 TFLOP/s, 66 % of the training step).
+//
+// A GEMM with M = Cout, N = Cin per tap and K = every output position.  Both operands are rows of an NCDHW tensor, so "8
+// consecutive k per lane" -- what v_mfma_f32_32x32x16_bf16 wants of A (lane = output channel) and B (lane = input channel) -- are 8
+// consecutive W positions of one channel row: the natural layout.  fp32 is kept by the split of conv3d_bf16s.hip: x = hi + mid +
+// lo bf16 terms, six cross products, fp32 accumulation (error below the exact-fp32 MFMA's; bf16 has fp32's exponent range, so
+// gradients of any magnitude need no scaling).
+//
+// One WAVE is one unit of work, nothing is shared between waves (no barrier in the kernel): a (32 co x 32 ci) tile pair, ONE
+// kernel row (kd, kh) (3 taps = 3 accumulator tiles: 48 registers, so three waves share a SIMD and one's staging hides under the
+// others' MFMAs -- all 9 taps of a depth plane in one wave need 144 and spilled) and a contiguous range of 32-position chunks of
+// output rows.  Per chunk:
+//   * A (gout): each lane loads its channel's 2 x 8 positions straight from global memory and splits them in registers -- the two
+//     fragments serve the 3 taps x 6 products;
+//   * B (in): the wave stages its input row's 32 ci x (32 + halo) positions -- coalesced 4-byte loads
+//     along W, register-prefetched one chunk ahead, split, written as bf16 pairs -- into its private LDS tile [term][ci][w] and reads
+//     the fragments of the three kw taps from it: kw = 1 is the aligned 16-byte word, kw = 0 / 2 are that word shifted by one
+//     element (v_alignbit on the word and one neighbouring dword).  Stride 2: even and odd input columns are staged as two rows, so
+//     kw = 1 / 2 are aligned words of the even / odd row and kw = 0 the odd row shifted by one.
+// Row strides of 112 / 80 bytes make the lane = channel fragment reads conflict-free.  The 3 x 16 accumulator registers of a wave
+// are added into a workspace laid out [tile][tap][register][lane] (coalesced fp32 atomics: 256 bytes per instruction; lanes of dW
+// itself would be 108 bytes apart), which a second small kernel re-orders into dW [Cout, Cin, 27].
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x2_w = __attribute__((ext_vector_type(2))) float;
+using bf16x2_w = __attribute__((ext_vector_type(2))) __bf16;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16_w(float x0, float x1) {     // lo16 = bf16(x0), hi16 = bf16(x1), RNE
+    const f32x2_w v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_w));
+}
+__device__ __forceinline__ void split3_pk_w(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16_w(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16_w(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16_w(s0, s1);
+}
+
+constexpr int CW = 32;                                    // output positions per chunk (two K-steps of 16)
+template <int S>
+struct WG {
+    // S = 1: one row [8 pad | 32 | 8 pad] bf16 per (term, ci): 96 bytes, stride 112; S = 2: rows E [32] and O [8 pad | 32]: stride 80
+    static constexpr int RS = (S == 1) ? 112 : 80;
+    static constexpr int PLANE = 32 * RS;                 // bytes per (row kind, term)
+    static constexpr int NPL = (S == 1) ? 3 : 6;
+    static constexpr int TILE = NPL * PLANE;              // bytes per wave
+    static constexpr int NLD = (S == 1) ? 2 : 4;          // loads per lane and channel iteration of the staging
+};
+
+template <int S>
+__global__ __launch_bounds__(256, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const float* __restrict__ gout, const float* __restrict__ in,
+                                                              float* __restrict__ ws, int Cin, int Cout, int D, int H, int W, int Do,
+                                                              int Ho, int Wo, int chunks_per_row, int total_chunks, int chunks_per_unit,
+                                                              int nsplit, int ci_tiles) {
+    using C = WG<S>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int unit = blockIdx.x * 4 + wave;
+    const int kd = (unit % 9) / 3, kh = unit % 3, split = unit / 9;      // a wave = (kernel-depth plane, kernel row, chunk range)
+    if (split >= nsplit) return;                           // (no barrier anywhere: a wave may leave)
+    const int c_begin = split * chunks_per_unit, c_end = min(c_begin + chunks_per_unit, total_chunks);
+    const int co0 = (blockIdx.y / ci_tiles) * 32, ci0 = (blockIdx.y % ci_tiles) * 32;
+    const int b = blockIdx.z;
+    unsigned char* tile = lds_raw + wave * C::TILE;
+
+    const long long ochan = (long long)Do * Ho * Wo, ichan = (long long)D * H * W;
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(gout + (long long)b * Cout * ochan), 0, (int)min((long long)Cout * ochan * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in + (long long)b * Cin * ichan), 0, (int)min((long long)Cin * ichan * 4, 0x7fffffffLL), 0x00020000);
+    // A: lane = (output channel l31, positions 8 * half ..)
+    const unsigned a_lane = (co0 + l31 < Cout) ? (unsigned)((co0 + l31) * ochan * 4) + 32u * half : 0x80000000u;
+    // B staging: lane = (position pair q = lane & 15, channel 4 i + (lane >> 4))
+    const int q = lane & 15, csub = lane >> 4;
+    // B fragments: lane = (input channel l31, word half)
+    const int frag_base = l31 * C::RS;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float rin[8 * C::NLD], rhalo = 0.f;
+    // ---- issue the loads of input row (id, ih), chunk at output column w0 (values outside the row: masked when they are used) ----
+    auto issue_in = [&](int id, int ih, int w0) {
+        const unsigned row_b = (unsigned)((((long long)id * H + ih) * W) * 4);
+        const int iw0 = (w0 + 2 * q) * S;                  // first input column of this lane's pair
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = ci0 + 4 * i + csub;
+            const unsigned ch = (c < Cin) ? (unsigned)(c * ichan * 4) : 0x80000000u;
+#pragma unroll
+            for (int e = 0; e < C::NLD; ++e)
+                rin[i * C::NLD + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(ch + (unsigned)((iw0 + e) * 4)), (int)row_b, 0));
+        }
+        // halo: S = 1: columns w0 - 1 (lanes 0-31) and w0 + 32 (lanes 32-63) of channel l31; S = 2: column 2 w0 - 1 (lanes 0-31)
+        const int hw = (S == 1) ? (half ? w0 + CW : w0 - 1) : 2 * w0 - 1;
+        const bool hok = (ci0 + l31 < Cin) && hw >= 0 && hw < W && (S == 1 || half == 0);
+        rhalo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              ires, (int)(hok ? (unsigned)((ci0 + l31) * ichan * 4) + (unsigned)(hw * 4) : 0x80000000u), (int)row_b, 0));
+    };
+    // ---- split the loaded row and write it to this wave's LDS tile ----
+    auto store_in = [&](int w0) {
+        const int iw0 = (w0 + 2 * q) * S;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v[C::NLD];
+#pragma unroll
+            for (int e = 0; e < C::NLD; ++e) v[e] = (iw0 + e < W) ? rin[i * C::NLD + e] : 0.f;      // (beyond the row: the next row's data)
+            const int c = 4 * i + csub;
+            if (S == 1) {
+                unsigned h, m, l;
+                split3_pk_w(v[0], v[1], h, m, l);
+                unsigned char* p = tile + c * C::RS + 16 + 4 * q;
+                *reinterpret_cast<unsigned*>(p) = h;
+                *reinterpret_cast<unsigned*>(p + C::PLANE) = m;
+                *reinterpret_cast<unsigned*>(p + 2 * C::PLANE) = l;
+            } else {
+                unsigned h, m, l;
+                split3_pk_w(v[0], v[2], h, m, l);          // even columns: E[j], E[j + 1]
+                unsigned char* p = tile + c * C::RS + 4 * q;
+                *reinterpret_cast<unsigned*>(p) = h;
+                *reinterpret_cast<unsigned*>(p + C::PLANE) = m;
+                *reinterpret_cast<unsigned*>(p + 2 * C::PLANE) = l;
+                split3_pk_w(v[1], v[3], h, m, l);          // odd columns: O[j], O[j + 1]
+                p = tile + 3 * C::PLANE + c * C::RS + 16 + 4 * q;
+                *reinterpret_cast<unsigned*>(p) = h;
+                *reinterpret_cast<unsigned*>(p + C::PLANE) = m;
+                *reinterpret_cast<unsigned*>(p + 2 * C::PLANE) = l;
+            }
+        }
+        if (S == 1 || half == 0) {                         // the halo element(s) of channel l31: element 7 (left) / 40 (right) of the row
+            unsigned h, m, l;
+            split3_pk_w(rhalo, 0.f, h, m, l);
+            unsigned char* p = tile + (S == 1 ? 0 : 3 * C::PLANE) + l31 * C::RS + ((S == 1 && half) ? 80 : 14);
+            *reinterpret_cast<unsigned short*>(p) = (unsigned short)h;
+            *reinterpret_cast<unsigned short*>(p + C::PLANE) = (unsigned short)m;
+            *reinterpret_cast<unsigned short*>(p + 2 * C::PLANE) = (unsigned short)l;
+        }
+    };
+    auto rd128 = [&](int off) { return *reinterpret_cast<const uint4*>(tile + off); };
+    auto rd32 = [&](int off) { return *reinterpret_cast<const unsigned*>(tile + off); };
+
+    // the chunks of this unit whose input row exists, walked with the loads one chunk ahead
+    int nc = c_begin - 1, nod = 0, noh = 0, nw0 = 0;        // the NEXT chunk to be loaded
+    auto advance = [&]() -> bool {                          // -> nc (and nod, noh, nw0) at the next chunk with an input row, false: none left
+        for (++nc; nc < c_end; ++nc) {
+            const int row = nc / chunks_per_row;
+            nod = row / Ho; noh = row - nod * Ho; nw0 = (nc - row * chunks_per_row) * CW;
+            if ((unsigned)(nod * S + kd - 1) < (unsigned)D && (unsigned)(noh * S + kh - 1) < (unsigned)H) return true;
+        }
+        return false;
+    };
+    float av[2][8];                                         // A of the chunk loaded last: 2 K-steps x 8 positions of channel l31
+    auto issue_a = [&]() {
+        const unsigned a_row = (unsigned)((((long long)nod * Ho + noh) * Wo + nw0) * 4);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                av[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gres, (int)(a_lane + (unsigned)((16 * s + e) * 4)), (int)a_row, 0));
+    };
+    bool have = advance();
+    if (have) { issue_a(); issue_in(nod * S + kd - 1, noh * S + kh - 1, nw0); }
+    while (have) {
+        const int w0 = nw0;
+        // ---- A fragments of this chunk: 2 K-steps x 8 positions of channel l31, split in registers (loaded a chunk ago) ----
+        uint4 af[2][3];                                     // [K-step][term]
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int w = w0 + 16 * s + 8 * half + 2 * e;
+                split3_pk_w(w < Wo ? av[s][2 * e] : 0.f, w + 1 < Wo ? av[s][2 * e + 1] : 0.f, h[e], m[e], l[e]);
+            }
+            af[s][0] = make_uint4(h[0], h[1], h[2], h[3]);
+            af[s][1] = make_uint4(m[0], m[1], m[2], m[3]);
+            af[s][2] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+        store_in(w0);
+        __builtin_amdgcn_wave_barrier();
+        // the next chunk's loads fly under this chunk's MFMAs
+        have = advance();
+        if (have) { issue_a(); issue_in(nod * S + kd - 1, noh * S + kh - 1, nw0); }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 bfr[3][3];                                // [kw][term]
+            if (S == 1) {
+                const int off = frag_base + 16 * (1 + 2 * s + half);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const uint4 x = rd128(t * C::PLANE + off);
+                    const unsigned pl = rd32(t * C::PLANE + off - 4), nf = rd32(t * C::PLANE + off + 16);
+                    const unsigned a0 = __builtin_amdgcn_alignbit(x.x, pl, 16), a1 = __builtin_amdgcn_alignbit(x.y, x.x, 16);
+                    const unsigned a2 = __builtin_amdgcn_alignbit(x.z, x.y, 16), a3 = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+                    const unsigned a4 = __builtin_amdgcn_alignbit(nf, x.w, 16);
+                    bfr[0][t] = make_uint4(a0, a1, a2, a3);
+                    bfr[1][t] = x;
+                    bfr[2][t] = make_uint4(a1, a2, a3, a4);
+                }
+            } else {
+                const int offe = frag_base + 16 * (2 * s + half), offo = 3 * C::PLANE + frag_base + 16 * (1 + 2 * s + half);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const uint4 xe = rd128(t * C::PLANE + offe), xo = rd128(t * C::PLANE + offo);
+                    const unsigned pl = rd32(t * C::PLANE + offo - 4);
+                    bfr[0][t] = make_uint4(__builtin_amdgcn_alignbit(xo.x, pl, 16), __builtin_amdgcn_alignbit(xo.y, xo.x, 16),
+                                           __builtin_amdgcn_alignbit(xo.z, xo.y, 16), __builtin_amdgcn_alignbit(xo.w, xo.z, 16));
+                    bfr[1][t] = xe;
+                    bfr[2][t] = xo;
+                }
+            }
+            // six cross products per tap, smallest first: (m,m) (h,l) (l,h) (h,m) (m,h) (h,h)
+            constexpr int pa[6] = {1, 0, 2, 0, 1, 0}, pb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][pa[p]]), __builtin_bit_cast(bf16x8, bfr[kw][pb[p]]),
+                                                                      acc[kw], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the wave's 3 tiles -> workspace [tile][tap][register][lane] ----
+    float* wt = ws + ((long long)blockIdx.y * 27 + kd * 9 + kh * 3) * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
+}
+
+// workspace [tile][tap][register][lane] -> dW [Cout][Cin][27]: register r of lane (l31, half) = row (r & 3) + 8 (r >> 2) + 4 half
+// (output channel), column l31 (input channel)
+__global__ void wgrad_reorder_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int ci_tiles, long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int tap = (int)(i % 27);
+    const long long r_ = i / 27;
+    const int ci = (int)(r_ % Cin), co = (int)(r_ / Cin);
+    const int tile = (co / 32) * ci_tiles + ci / 32, row = co % 32;
+    const int half = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+    dw[i] = ws[(((long long)tile * 27 + tap) * 16 + r) * 64 + half * 32 + (ci % 32)];
+}
+
+}  // namespace
+
+extern "C" int ss_conv3d_wgrad_bf16s_fwd(const float* grad_out, const float* in, float* grad_w, float* workspace, int B, int Cin, int D,
+                                         int H, int W, int Cout, int stride, ss_stream_t stream) {
+    SS_REQUIRE(grad_out && in && grad_w && workspace);
+    SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && (stride == 1 || stride == 2));
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    if ((long long)Cin * D * H * W * 4 >= 0x7fffffffLL || (long long)Cout * Do * Ho * Wo * 4 >= 0x7fffffffLL || B > 65535)
+        return SS_ERR_UNSUPPORTED;                                          // 32-bit buffer offsets per batch element
+    hipStream_t st = ss::as_stream(stream);
+    const int ci_tiles = ss::ceil_div(Cin, 32), tiles = ci_tiles * ss::ceil_div(Cout, 32);
+    if (tiles > 65535) return SS_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(workspace, 0, (size_t)tiles * 27 * 1024 * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    const int chunks_per_row = ss::ceil_div(Wo, CW);
+    const long long total_ll = (long long)Do * Ho * chunks_per_row;
+    if (total_ll > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    const int total = (int)total_ll;
+    // ~8 waves per CU on 256 CUs; a unit (= wave) is (kernel-depth plane, tile pair, batch element, chunk range)
+    int nsplit = std::max(1, 3072 / (9 * tiles * B));
+    int per_unit = std::max(chunks_per_row >= 4 ? 4 : 1, ss::ceil_div(total, nsplit));
+    nsplit = ss::ceil_div(total, per_unit);
+    const dim3 grid(ss::ceil_div(9 * nsplit, 4), tiles, B);
+    if (stride == 1) {
+        auto kern = conv3d_wgrad_bf16s<1>;
+        hipLaunchKernelGGL(kern, grid, dim3(256), 4 * WG<1>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
+                           total, per_unit, nsplit, ci_tiles);
+    } else {
+        auto kern = conv3d_wgrad_bf16s<2>;
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 4 * WG<2>::TILE) != SS_OK) return SS_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(256), 4 * WG<2>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
+                           total, per_unit, nsplit, ci_tiles);
+    }
+    if (ss::check_launch() != SS_OK) return SS_ERR_LAUNCH;
+    const long long n = (long long)Cout * Cin * 27;
+    hipLaunchKernelGGL(wgrad_reorder_kernel, dim3((unsigned)ss::ceil_div_ll(n, 256)), dim3(256), 0, st, workspace, grad_w, Cout, Cin, ci_tiles, n);
+    return ss::check_launch();
+}

@@ -17,15 +17,26 @@ from .engine import (PATH_COUNTS, conv3d_bf16s_hip, conv3d_head_bf16s_hip, conv3
 
 
 
+#: weight-gradient engine of the 3x3x3 layers: "bf16x6" (default, r06: three bf16 terms, six products on the bf16 matrix core,
+#: conv3d_wgrad_bf16s.hip) or "f32" (the exact-fp32 MFMA kernel of rounds 2-5, conv3d_wgrad.hip: 13 TFLOP/s, two thirds of the
+#: training step).  SS_WGRAD_ENGINE; read at call time like the other Python-level switches.
+WGRAD_ENGINE = os.environ.get("SS_WGRAD_ENGINE", "bf16x6")
+
+
 def conv3d_wgrad_hip(grad_out, x, Cout, Cin, stride):
-    """dW [Cout,Cin,3,3,3] of a 3x3x3, padding-1 Conv3d: grad_out [B,Cout,Do,Ho,Wo], x [B,Cin,D,H,W] (conv3d_wgrad.hip)."""
+    """dW [Cout,Cin,3,3,3] of a 3x3x3, padding-1 Conv3d: grad_out [B,Cout,Do,Ho,Wo], x [B,Cin,D,H,W] (conv3d_wgrad_bf16s.hip;
+    WGRAD_ENGINE = "f32": conv3d_wgrad.hip)."""
     grad_out = grad_out if grad_out.is_contiguous() else grad_out.contiguous()
     x = x if x.is_contiguous() else x.contiguous()
     dev = _lib.require_device(grad_out, x)
     B, _, D, H, W = x.shape
     gw = torch.empty((Cout, Cin, 3, 3, 3), dtype=x.dtype, device=x.device)
     with torch.cuda.device(dev):
-        call("ss_conv3d_wgrad_fwd", ptr(grad_out), ptr(x), ptr(gw), B, Cin, D, H, W, Cout, int(stride))
+        if WGRAD_ENGINE == "f32":
+            call("ss_conv3d_wgrad_fwd", ptr(grad_out), ptr(x), ptr(gw), B, Cin, D, H, W, Cout, int(stride))
+        else:
+            ws = torch.empty(((Cout + 31) // 32) * ((Cin + 31) // 32) * 27 * 1024, dtype=x.dtype, device=x.device)
+            call("ss_conv3d_wgrad_bf16s_fwd", ptr(grad_out), ptr(x), ptr(gw), ptr(ws), B, Cin, D, H, W, Cout, int(stride))
     return gw
 
 

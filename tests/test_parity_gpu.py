@@ -1793,6 +1793,9 @@ CONV_TRAIN_CASES = [
     (1, 64, 32, 3, 7, 33, 1),           # W odd, ragged tile
     (1, 40, 48, 2, 6, 20, 1),           # channels not multiples of 32
     (1, 64, 128, 4, 6, 16, 2),
+    (1, 32, 32, 5, 21, 150, 1),         # r06: rows of several 32-position chunks, ragged last chunk (the bf16 weight-gradient kernel's K loop)
+    (2, 32, 64, 6, 22, 138, 2),         # ... stride 2 (even / odd column rows), batch 2
+    (1, 8, 1, 3, 9, 70, 1),             # ... a single output channel (the classifiers' heads run this kernel too)
 ]
 
 
