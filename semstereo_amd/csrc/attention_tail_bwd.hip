@@ -118,74 +118,93 @@ __device__ __forceinline__ Taps4 bilinear_taps(float disp, int h, int w, int H, 
     return t;
 }
 
-// One thread per pixel.  Pass 1 recomputes corr[t] = mean_c left * warp_t(right) and the softmax; pass 2 walks the channels
-// again for the feature gradients.  g_left is owned by the pixel; g_right, g_pred0, g_var are scattered with atomics (zeroed by
-// the launcher); g_gamma / g_beta are block-reduced, then one atomic per block.
-__global__ __launch_bounds__(256) void sample_strength_bwd_kernel(const float* __restrict__ left, const float* __restrict__ right,
+// A workgroup = 64 pixels (lanes along x) x NW waves that split the channels (wave w owns channels w, w + NW, ...).  Pass 1
+// recomputes corr[t] = mean_c left * warp_t(right) -- each wave its channels, summed through LDS in a fixed order -- and every wave
+// redoes the small softmax backward for its lanes' pixels; pass 2 walks the wave's channels again for the feature gradients.  g_left is
+// owned by (pixel, channel); g_right, g_pred0, g_var are scattered with atomics (zeroed by the launcher; taps of weight zero -- the
+// south row wherever the row coordinate is exact, three rows in four -- are skipped); g_gamma / g_beta are reduced over wave 0, one
+// atomic pair per workgroup.  (Rounds 4-5: ONE thread per pixel walked all C channels twice -- 1 024 waves on the whole chip, 168 M
+// unconditional atomics: 3.6 ms of the 1024^2 training step, measured r06.)
+constexpr int SSB_NW = 8;
+__global__ __launch_bounds__(64 * SSB_NW) void sample_strength_bwd_kernel(const float* __restrict__ left, const float* __restrict__ right,
                                                                    const float* __restrict__ pred0, const float* __restrict__ var,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    const float* __restrict__ g_strength, float* __restrict__ g_left,
                                                                    float* __restrict__ g_right, float* __restrict__ g_pred0,
                                                                    float* __restrict__ g_var, float* __restrict__ g_gb, int C, int H, int W,
                                                                    float half_w, float half_h, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    constexpr int NW = SSB_NW;
+    __shared__ float red[NW][5][64], gred[NW][5][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
     const bool active = i < total;
     const long long plane = (long long)H * W;
     const long long ii = active ? i : 0;
     const int x = (int)(ii % W), y = (int)((ii / W) % H);
     const long long b = ii / plane, pix = (long long)y * W + x;
-    float dgamma = 0.f, dbeta = 0.f;
-    if (active) {
-        Taps4 tp[5];
-        long long nbs[5];
+    Taps4 tp[5];
+    long long nbs[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);
+        nbs[t] = b * plane + (long long)yy * W + xx;
+        tp[t] = bilinear_taps(pred0[nbs[t]], y, x, H, W, half_w, half_h);
+    }
+    auto sample4 = [&](const float* rp, const Taps4& t, float& a, float& bq, float& c, float& d) {
+        a = (t.o_nw >= 0) ? rp[t.o_nw] : 0.f; bq = (t.o_ne >= 0) ? rp[t.o_ne] : 0.f;
+        c = (t.o_sw >= 0) ? rp[t.o_sw] : 0.f; d = (t.o_se >= 0) ? rp[t.o_se] : 0.f;
+    };
+    float corr[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = wave; c < C; c += NW) {
+        const float l = left[(b * C + c) * plane + pix];
+        const float* rp = right + (b * C + c) * plane;
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
-            const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);
-            nbs[t] = b * plane + (long long)yy * W + xx;
-            tp[t] = bilinear_taps(pred0[nbs[t]], y, x, H, W, half_w, half_h);
+            float a, bq, cq, d;
+            sample4(rp, tp[t], a, bq, cq, d);
+            corr[t] += l * (a * tp[t].w_nw + bq * tp[t].w_ne + cq * tp[t].w_sw + d * tp[t].w_se);
         }
-        auto sample4 = [&](const float* rp, const Taps4& t, float& a, float& bq, float& c, float& d) {
-            a = (t.o_nw >= 0) ? rp[t.o_nw] : 0.f; bq = (t.o_ne >= 0) ? rp[t.o_ne] : 0.f;
-            c = (t.o_sw >= 0) ? rp[t.o_sw] : 0.f; d = (t.o_se >= 0) ? rp[t.o_se] : 0.f;
-        };
-        float corr[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < C; ++c) {
-            const float l = left[(b * C + c) * plane + pix];
-            const float* rp = right + (b * C + c) * plane;
+    }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                float a, bq, cq, d;
-                sample4(rp, tp[t], a, bq, cq, d);
-                corr[t] += l * (a * tp[t].w_nw + bq * tp[t].w_ne + cq * tp[t].w_sw + d * tp[t].w_se);
-            }
-        }
-        const float g = gamma[0], bt = beta[0];
-        float gate[5], z[5], mx = -INFINITY;
+    for (int t = 0; t < 5; ++t) red[wave][t][lane] = corr[t];
+    __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            corr[t] /= (float)C;
-            gate[t] = 1.0f / (1.0f + expf(-(bt + g * var[nbs[t]])));
-            z[t] = corr[t] * gate[t];
-            mx = fmaxf(mx, z[t]);
-        }
-        float sum = 0.f, dot = 0.f;
+    for (int t = 0; t < 5; ++t) {
+        float s = 0.f;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) { z[t] = expf(z[t] - mx); sum += z[t]; }
-        float gs[5];
+        for (int w = 0; w < NW; ++w) s += red[w][t][lane];
+        corr[t] = s;
+    }
+    const float g = gamma[0], bt = beta[0];
+    float gate[5], z[5], mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) { z[t] /= sum; gs[t] = g_strength[(b * 5 + t) * plane + pix]; dot += z[t] * gs[t]; }
-        float dcorr[5];
+    for (int t = 0; t < 5; ++t) {
+        corr[t] /= (float)C;
+        gate[t] = 1.0f / (1.0f + expf(-(bt + g * var[nbs[t]])));
+        z[t] = corr[t] * gate[t];
+        mx = fmaxf(mx, z[t]);
+    }
+    float sum = 0.f, dot = 0.f;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const float dz = z[t] * (gs[t] - dot);
-            dcorr[t] = dz * gate[t] / (float)C;
+    for (int t = 0; t < 5; ++t) { z[t] = expf(z[t] - mx); sum += z[t]; }
+    float gs[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { z[t] /= sum; gs[t] = g_strength[(b * 5 + t) * plane + pix]; dot += z[t] * gs[t]; }
+    float dcorr[5], dgamma = 0.f, dbeta = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const float dz = z[t] * (gs[t] - dot);
+        dcorr[t] = dz * gate[t] / (float)C;
+        if (wave == 0 && active) {                           // (wave-uniform) the per-pixel scalars: once per pixel
             const float dv = dz * corr[t] * gate[t] * (1.0f - gate[t]);
             dbeta += dv;
             dgamma += dv * var[nbs[t]];
             if (g_var) unsafeAtomicAdd(&g_var[nbs[t]], dv * g);
         }
-        float gix[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < C; ++c) {
+    }
+    float gix[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (int c = wave; c < C; c += NW) {
             const float l = left[(b * C + c) * plane + pix];
             const float* rp = right + (b * C + c) * plane;
             float* grp = g_right ? g_right + (b * C + c) * plane : nullptr;
@@ -197,30 +216,36 @@ __global__ __launch_bounds__(256) void sample_strength_bwd_kernel(const float* _
                 gl += dcorr[t] * (a * tp[t].w_nw + bq * tp[t].w_ne + cq * tp[t].w_sw + d * tp[t].w_se);
                 const float gr = dcorr[t] * l;
                 if (grp) {
-                    if (tp[t].o_nw >= 0) unsafeAtomicAdd(&grp[tp[t].o_nw], gr * tp[t].w_nw);
-                    if (tp[t].o_ne >= 0) unsafeAtomicAdd(&grp[tp[t].o_ne], gr * tp[t].w_ne);
-                    if (tp[t].o_sw >= 0) unsafeAtomicAdd(&grp[tp[t].o_sw], gr * tp[t].w_sw);
-                    if (tp[t].o_se >= 0) unsafeAtomicAdd(&grp[tp[t].o_se], gr * tp[t].w_se);
+                    if (tp[t].o_nw >= 0 && tp[t].w_nw != 0.f) unsafeAtomicAdd(&grp[tp[t].o_nw], gr * tp[t].w_nw);
+                    if (tp[t].o_ne >= 0 && tp[t].w_ne != 0.f) unsafeAtomicAdd(&grp[tp[t].o_ne], gr * tp[t].w_ne);
+                    if (tp[t].o_sw >= 0 && tp[t].w_sw != 0.f) unsafeAtomicAdd(&grp[tp[t].o_sw], gr * tp[t].w_sw);
+                    if (tp[t].o_se >= 0 && tp[t].w_se != 0.f) unsafeAtomicAdd(&grp[tp[t].o_se], gr * tp[t].w_se);
                 }
                 // d(sample)/d(ix) = (b - a) * fs + (d - c) * fn     (ATen's grid_sampler backward: gix)
                 gix[t] += gr * ((bq - a) * tp[t].fs + (d - cq) * tp[t].fn);
             }
             if (g_left) g_left[(b * C + c) * plane + pix] = gl;
         }
-        if (g_pred0) {
-#pragma unroll
-            for (int t = 0; t < 5; ++t)      // ix = ((w - disp)/half_w - 1 + 1) * half_w: d ix / d disp = -1, by ATen's chain -(half_w * gix) / half_w
-                unsafeAtomicAdd(&g_pred0[nbs[t]], -((half_w * gix[t]) / half_w));
-        }
     }
-    // gamma, beta: one atomic pair per block
-    __shared__ float red[2][4];
-    for (int o = 32; o > 0; o >>= 1) { dgamma += __shfl_xor(dgamma, o); dbeta += __shfl_xor(dbeta, o); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dgamma; red[1][threadIdx.x >> 6] = dbeta; }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) gred[wave][t][lane] = gix[t];
     __syncthreads();
-    if (threadIdx.x == 0 && g_gb) {
-        unsafeAtomicAdd(&g_gb[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        unsafeAtomicAdd(&g_gb[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    if (wave == 0) {
+        if (g_pred0 && active) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {    // ix = ((w - disp)/half_w - 1 + 1) * half_w: d ix / d disp = -1, by ATen's chain -(half_w * gix) / half_w
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += gred[w][t][lane];
+                unsafeAtomicAdd(&g_pred0[nbs[t]], -((half_w * s) / half_w));
+            }
+        }
+        // gamma, beta: one atomic pair per workgroup
+        for (int o = 32; o > 0; o >>= 1) { dgamma += __shfl_xor(dgamma, o); dbeta += __shfl_xor(dbeta, o); }
+        if (lane == 0 && g_gb) {
+            unsafeAtomicAdd(&g_gb[0], dgamma);
+            unsafeAtomicAdd(&g_gb[1], dbeta);
+        }
     }
 }
 
@@ -340,7 +365,7 @@ extern "C" int ss_sample_strength_bwd(const float* left, const float* right, con
     if (grad_var && hipMemsetAsync(grad_var, 0, (size_t)total * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
     if (grad_gamma_beta && hipMemsetAsync(grad_gamma_beta, 0, 2 * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
     const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
-    hipLaunchKernelGGL(sample_strength_bwd_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0, st, left, right, pred0, var, gamma,
+    hipLaunchKernelGGL(sample_strength_bwd_kernel, dim3((unsigned)ss::ceil_div_ll(total, 64)), dim3(64 * SSB_NW), 0, st, left, right, pred0, var, gamma,
                        beta, grad_strength, grad_left, grad_right, grad_pred0, grad_var, grad_gamma_beta, C, H, W, half_w, half_h, total);
     return ss::check_launch();
 }

@@ -58,6 +58,9 @@ constexpr int KSTEPS = 14;        // ceil(27 taps / 2): the 3-D kernels (BCfg::K
 #ifndef SS_ROW_PAIR_S2
 #define SS_ROW_PAIR_S2 1
 #endif
+#ifndef SS_S2_DEINT
+#define SS_S2_DEINT 1             // stride 2: the halo rows in LDS de-interleaved by column parity (r06: fragment reads of 64 consecutive slots, see lane_pos)
+#endif
 constexpr int SS_IN_AUX = 0;      // cache policy bits of the activation loads (buffer_load aux: 1 = sc0, 2 = nt)
 #ifndef SS_IN_AUX_GATED
 #define SS_IN_AUX_GATED 0         // ... of the gated launch (concat_stem), whose inputs -- warped half, partial sum -- are dead after it (nt / sc0+nt measured on the whole step: 479.5 / 476 against 489.6 pairs/s on one box: the launch itself 284 -> 334 / 344 us)
@@ -216,10 +219,15 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     const int cow = co0 + (wave % MS) * 32 * MT;                // this wave's first channel
     const int b = blockIdx.z;
     const int dzw = (wrow * NT) / TH, hy0 = (wrow * NT) % TH;
-    // (Stride 2: the 32 lanes of a fragment read are 32 bytes apart, a 2-way bank conflict per ds_read_b128 lane group.  Rows stored
-    // even columns first, then odd -- conflict-free reads, 2-way writes -- measured 88.7 / 89.6 us against 89.0 / 86.4: LDS is not
-    // what the stride-2 layers wait for (wait_inst_lds 1.9 % of wave cycles, profiles/r03_k_pmc_sq_conv_s2.txt); not kept.)
-    const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + l31 * S;     // slot of this lane's first row, tap (0,0,0)
+    // Stride 2: with a row's columns in their natural order the 32 lanes of a fragment read are 32 bytes apart, a 2-way bank conflict
+    // per ds_read_b128 lane group (r05: SQ_LDS_BANK_CONFLICT 5.3 M cycles on the largest layer, the only conv family with any).  DEINT
+    // (r06): a row of the halo tile is stored even columns first (33 slots), then odd (32), and a thread OWNS the position of its slot
+    // (make_poff maps slot -> column), so nothing is permuted on the way in: tap kw of output column l31 is input column 2 l31 + kw =
+    // slot l31 (kw 0), 33 + l31 (kw 1), l31 + 1 (kw 2) -- 64 consecutive slots per fragment read as in the stride-1 forms.  (r03 measured
+    // a de-interleaved build of the MT = 2 form as neutral, 88.7 / 89.6 us against 89.0 / 86.4; this is the MS = 2 form with scalar
+    // addressing.)
+    constexpr bool DEINT = (S == 2) && SS_S2_DEINT;
+    const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + (DEINT ? l31 : l31 * S);     // slot of this lane's first row, tap (0,0,0)
     auto tile_origin = [&](int tile, int& ow0, int& oh0, int& od0) {
         int t = tile;
         const int tw = t % tiles_w; t /= tiles_w;
@@ -276,7 +284,8 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
 #pragma unroll
         for (int i = 0; i < C::NPOS; ++i) {
             const int p = tid + 256 * i;
-            const int wx = p % C::IW;
+            const int sx = p % C::IW;
+            const int wx = DEINT ? (sx < (C::IW + 1) / 2 ? 2 * sx : 2 * (sx - (C::IW + 1) / 2) + 1) : sx;      // (DEINT: slot -> column)
             int r = p / C::IW;
             const int hy = r % C::IH;
             const int dz = r / C::IH;
@@ -522,8 +531,9 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         uint4 bcur[RP][NC], bnxt[RP][NC];
         auto read_b = [&](uint4 (&dst)[NC], int s, int i) {
             const int ta = 2 * s, tb = 2 * s + 1;
-            const int offa = ((ta / 9) * C::IH + (ta / 3) % 3) * C::IW + ta % 3;
-            const int offb = (tb < C::KT) ? ((tb / 9) * C::IH + (tb / 3) % 3) * C::IW + tb % 3 : 0;
+            constexpr int kwo[3] = {0, DEINT ? (C::IW + 1) / 2 : 1, DEINT ? 1 : 2};            // slot offset of tap column kw
+            const int offa = ((ta / 9) * C::IH + (ta / 3) % 3) * C::IW + kwo[ta % 3];
+            const int offb = (tb < C::KT) ? ((tb / 9) * C::IH + (tb / 3) % 3) * C::IW + kwo[tb % 3] : 0;
             const int slot = lane_pos + i * S * C::IW + (half ? offb : offa);
 #pragma unroll
             for (int c = 0; c < NC; ++c) dst[c] = lds[(tb >= C::KT && half) ? ZSLOT : c * C::CS + slot];

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
                                                               int nsplit, int ci_tiles) {
     using C = WG<S>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a SCALAR: everything derived from it -- the unit, its chunk walk, the row offsets of the buffer loads -- is then
+    // scalar arithmetic; as a per-lane value every buffer load's scalar offset needed a waterfall loop: 164 of them in the first build)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int unit = blockIdx.x * 4 + wave;
     const int kd = (unit % 9) / 3, kh = unit % 3, split = unit / 9;      // a wave = (kernel-depth plane, kernel row, chunk range)
@@ -168,13 +170,26 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
         return false;
     };
     float av[2][8];                                         // A of the chunk loaded last: 2 K-steps x 8 positions of channel l31
+    // (lane = channel: a load instruction touches 32 cache lines whatever its width -- 16 bytes per lane where the rows are 16-byte
+    // aligned, i.e. Wo % 4 == 0, every layer of the model: 4 instructions per chunk instead of 16)
+    const bool a_wide = (Wo & 3) == 0;
     auto issue_a = [&]() {
         const unsigned a_row = (unsigned)((((long long)nod * Ho + noh) * Wo + nw0) * 4);
+        if (a_wide) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                av[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gres, (int)(a_lane + (unsigned)((16 * s + e) * 4)), (int)a_row, 0));
+                for (int e = 0; e < 8; e += 4) {
+                    const float4 v4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gres, (int)(a_lane + (unsigned)((16 * s + e) * 4)), (int)a_row, 0));
+                    av[s][e] = v4.x; av[s][e + 1] = v4.y; av[s][e + 2] = v4.z; av[s][e + 3] = v4.w;
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    av[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gres, (int)(a_lane + (unsigned)((16 * s + e) * 4)), (int)a_row, 0));
+        }
     };
     bool have = advance();
     if (have) { issue_a(); issue_in(nod * S + kd - 1, noh * S + kh - 1, nw0); }

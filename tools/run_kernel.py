@@ -160,6 +160,16 @@ elif name in ("conv_s2", "conv_s1", "deconv"):
         sc, sh = torch.rand(cout, device=dev) + 0.5, R(cout) * 0.1
         fn = lambda: M.conv3d_bf16s_hip(x, ws, cout, sc, sh, True, 19, stride=stride)       # noqa: E731
         nbytes = 4.0 * B * (32 * 24 * 256 * 256 + cout * (24 // stride) * (256 // stride) ** 2)
+elif name.startswith("wgrad"):   # weight gradients of the training step (1024^2 / md64): wgrad = classif.0 (32 -> 32 at [24,256,256]), wgrad_stem = concat_stem (64 -> 32),
+    # wgrad_mid = hourglass2.conv2 (64 -> 64 at [12,128,128]), wgrad_low = conv4 (128 -> 128 at [6,64,64]), wgrad_s2 = conv1 (32 -> 64, stride 2), wgrad_head (32 -> 1)
+    from semstereo_amd import train_layers as TL
+    cin, cout, d, hw, stride = {"wgrad": (32, 32, 24, 256, 1), "wgrad_stem": (64, 32, 24, 256, 1), "wgrad_mid": (64, 64, 12, 128, 1), "wgrad_low": (128, 128, 6, 64, 1),
+                                "wgrad_s2": (32, 64, 24, 256, 2), "wgrad_s2_low": (64, 128, 12, 128, 2), "wgrad_head": (32, 1, 24, 256, 1)}[name]
+    x = R(B, cin, d, hw, hw)
+    g = R(B, cout, d // stride, hw // stride, hw // stride)
+    fn = lambda: TL.conv3d_wgrad_hip(g, x, cout, cin, stride)                  # noqa: E731
+    nbytes = 4.0 * (x.numel() + g.numel())
+    print(f"{name}: {2.0 * 27 * cin * cout * g[0, 0].numel() * B / 1e9:.1f} GFLOP fp32-equivalent (x 6 bf16 products)")
 else:
     sys.exit(__doc__)
 
