@@ -59,7 +59,7 @@ constexpr int KSTEPS = 14;        // ceil(27 taps / 2): the 3-D kernels (BCfg::K
 #define SS_ROW_PAIR_S2 1
 #endif
 #ifndef SS_S2_DEINT
-#define SS_S2_DEINT 1             // stride 2: the halo rows in LDS de-interleaved by column parity (r06: fragment reads of 64 consecutive slots, see lane_pos)
+#define SS_S2_DEINT 0             // stride 2: the halo rows in LDS de-interleaved by column parity (r06; 1: a thread owns its SLOT's column, 2: a thread owns a column and writes the permuted slot; see lane_pos -- both measured slower than the natural order, 0)
 #endif
 constexpr int SS_IN_AUX = 0;      // cache policy bits of the activation loads (buffer_load aux: 1 = sc0, 2 = nt)
 #ifndef SS_IN_AUX_GATED
@@ -225,8 +225,13 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
     // (make_poff maps slot -> column), so nothing is permuted on the way in: tap kw of output column l31 is input column 2 l31 + kw =
     // slot l31 (kw 0), 33 + l31 (kw 1), l31 + 1 (kw 2) -- 64 consecutive slots per fragment read as in the stride-1 forms.  (r03 measured
     // a de-interleaved build of the MT = 2 form as neutral, 88.7 / 89.6 us against 89.0 / 86.4; this is the MS = 2 form with scalar
-    // addressing.)
-    constexpr bool DEINT = (S == 2) && SS_S2_DEINT;
+    // addressing.)  Measured r06, same box, interleaved (profiles/r06_e_ab_conv_s2_deint.txt): SQ_LDS_BANK_CONFLICT 5.3 M -> 0, but the
+    // largest layer 88.0 -> 94.8 us and the [16,64,64] one 26.4 -> 32.1: the lanes of a staging load are then 8 bytes apart (two
+    // instructions per cache line instead of one) and that costs more than the conflicts did (wait_inst_lds was 1.4 % of wave cycles).
+    // DEINT_W (SS_S2_DEINT=2): columns stay with their natural owners (coalesced loads) and the permutation is applied to the LDS WRITE
+    // address instead (2-way conflicts on 3 writes per position instead of on every fragment read).
+    constexpr bool DEINT_W = (S == 2) && SS_S2_DEINT == 2;
+    constexpr bool DEINT = (S == 2) && SS_S2_DEINT != 0;
     const int lane_pos = (dzw * S * C::IH + hy0 * S) * C::IW + (DEINT ? l31 : l31 * S);     // slot of this lane's first row, tap (0,0,0)
     auto tile_origin = [&](int tile, int& ow0, int& oh0, int& od0) {
         int t = tile;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
         for (int i = 0; i < C::NPOS; ++i) {
             const int p = tid + 256 * i;
             const int sx = p % C::IW;
-            const int wx = DEINT ? (sx < (C::IW + 1) / 2 ? 2 * sx : 2 * (sx - (C::IW + 1) / 2) + 1) : sx;      // (DEINT: slot -> column)
+            const int wx = (DEINT && !DEINT_W) ? (sx < (C::IW + 1) / 2 ? 2 * sx : 2 * (sx - (C::IW + 1) / 2) + 1) : sx;      // (DEINT: slot -> column)
             int r = p / C::IW;
             const int hy = r % C::IH;
             const int dz = r / C::IH;
@@ -483,9 +488,14 @@ __global__ __launch_bounds__(256, (NTERMS == F16X3) ? SS_F16_WGS : 2) void conv3
                     if (F16) split2_pk_f16(x0 * in_scale, x1 * in_scale, hh[c], mm[c]);
                     else split3_pk(x0, x1, hh[c], mm[c], ll[c]);
                 }
-                lds[0 * C::CS + p] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-                lds[1 * C::CS + p] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
-                if (NC == 3) lds[2 * C::CS + p] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                int ps = p;
+                if constexpr (DEINT_W) {                       // column wx of its row -> slot (wx >> 1) + (wx & 1) * 33
+                    const int row = p / C::IW, wx = p - row * C::IW;
+                    ps = row * C::IW + (wx >> 1) + (wx & 1) * ((C::IW + 1) / 2);
+                }
+                lds[0 * C::CS + ps] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                lds[1 * C::CS + ps] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+                if (NC == 3) lds[2 * C::CS + ps] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
             }
         };
 #ifdef SS_EXP_CONV_NOSTAGE        // (timing experiment, wrong results: the split / transpose / LDS writes done once per workgroup)

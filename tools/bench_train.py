@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--maxdisp", type=int, default=64)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam's default (foreach) implementation instead of fused=True")
     ap.add_argument("--no-checks", action="store_true", help="skip the determinism / eval-comparison passes (profiling runs)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_train.json"))
     ap.add_argument("--kernel-stats", default=None)
@@ -120,7 +121,12 @@ def main():
         rec = {}
         try:
             seg.train()
-            opt = torch.optim.Adam(seg.parameters(), lr=1e-3, betas=(0.9, 0.999))
+            # (the reference: optim.Adam(model.parameters(), lr=args.lr, betas=(0.9, 0.999)), main_us3d.py; `fused`: PyTorch's one-launch
+            # implementation of the same update instead of ~6 element-wise launches per parameter tensor)
+            try:
+                opt = torch.optim.Adam(seg.parameters(), lr=1e-3, betas=(0.9, 0.999), fused=not args.no_fused_adam)
+            except (TypeError, RuntimeError):
+                opt = torch.optim.Adam(seg.parameters(), lr=1e-3, betas=(0.9, 0.999))
             fl8, fr8 = bench.synth_features(B, 256, H // 8, W // 8, 6, 5100, dev)
             fl4, fr4 = bench.synth_features(B, 128, H // 4, W // 4, 12, 5200, dev)
             feats = [t.requires_grad_(True) for t in (fl4, fr4, fl8, fr8)]
