@@ -62,7 +62,7 @@ struct WG {
 };
 
 template <int S>
-__global__ __launch_bounds__(256, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const float* __restrict__ gout, const float* __restrict__ in,
+__global__ __launch_bounds__(192, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const float* __restrict__ gout, const float* __restrict__ in,
                                                               float* __restrict__ ws, int Cin, int Cout, int D, int H, int W, int Do,
                                                               int Ho, int Wo, int chunks_per_row, int total_chunks, int chunks_per_unit,
                                                               int nsplit, int ci_tiles) {
@@ -72,8 +72,13 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
     // scalar arithmetic; as a per-lane value every buffer load's scalar offset needed a waterfall loop: 164 of them in the first build)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int unit = blockIdx.x * 4 + wave;
-    const int kd = (unit % 9) / 3, kh = unit % 3, split = unit / 9;      // a wave = (kernel-depth plane, kernel row, chunk range)
+    // a workgroup = (chunk range `split`, kernel-depth plane kd), its three waves the kernel rows kh.  The nine waves of a chunk range
+    // read the same gout chunks and overlapping input rows: the three workgroups of a range get block indices 8 apart, i.e. the SAME
+    // XCD (workgroups go round-robin over the 8 XCDs), a few dispatches from each other, so that what one fetches the others find in
+    // that XCD's L2.  (First build: consecutive waves = consecutive kernel rows, spread over 2-3 XCDs -- every XCD fetched its own copy
+    // over the fabric, 1.9 GB for a 0.4 GB layer, and a chunk took ~20 000 cycles of a wave's life.)
+    const int kh = wave;
+    const int kd = (blockIdx.x / 8) % 3, split = (blockIdx.x / 24) * 8 + (blockIdx.x % 8);
     if (split >= nsplit) return;                           // (no barrier anywhere: a wave may leave)
     const int c_begin = split * chunks_per_unit, c_end = min(c_begin + chunks_per_unit, total_chunks);
     const int co0 = (blockIdx.y / ci_tiles) * 32, ci0 = (blockIdx.y % ci_tiles) * 32;
@@ -118,15 +123,16 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
                                               ires, (int)(hok ? (unsigned)((ci0 + l31) * ichan * 4) + (unsigned)(hw * 4) : 0x80000000u), (int)row_b, 0));
     };
     // ---- split the loaded row and write it to this wave's LDS tile ----
-    auto store_in = [&](int w0) {
+    auto store_in = [&](int w0, auto whole_tag) {           // WHOLE: every column this chunk reads lies inside the row (wave-uniform): no masks
+        constexpr bool WHOLE = decltype(whole_tag)::value;
         const int iw0 = (w0 + 2 * q) * S;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float v[C::NLD];
 #pragma unroll
-            for (int e = 0; e < C::NLD; ++e) v[e] = (iw0 + e < W) ? rin[i * C::NLD + e] : 0.f;      // (beyond the row: the next row's data)
+            for (int e = 0; e < C::NLD; ++e) v[e] = (WHOLE || iw0 + e < W) ? rin[i * C::NLD + e] : 0.f;      // (beyond the row: the next row's data)
             const int c = 4 * i + csub;
-            if (S == 1) {
+            if constexpr (S == 1) {
                 unsigned h, m, l;
                 split3_pk_w(v[0], v[1], h, m, l);
                 unsigned char* p = tile + c * C::RS + 16 + 4 * q;
@@ -193,27 +199,43 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
     };
     bool have = advance();
     if (have) { issue_a(); issue_in(nod * S + kd - 1, noh * S + kh - 1, nw0); }
+    bool first_chunk = true;
     while (have) {
         const int w0 = nw0;
         // ---- A fragments of this chunk: 2 K-steps x 8 positions of channel l31, split in registers (loaded a chunk ago) ----
         uint4 af[2][3];                                     // [K-step][term]
+        // (a chunk that lies inside its rows -- all but the last of a row, and that one too when the widths are multiples of 32 -- takes
+        // the copies without the per-element "inside the row" selects: a quarter of the staging's vector instructions)
+        const bool whole = w0 + CW <= Wo && (w0 + CW) * S + 1 <= W;
+        auto split_a = [&](auto whole_tag) {
+            constexpr bool WHOLE = decltype(whole_tag)::value;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            unsigned h[4], m[4], l[4];
+            for (int s = 0; s < 2; ++s) {
+                unsigned h[4], m[4], l[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int w = w0 + 16 * s + 8 * half + 2 * e;
-                split3_pk_w(w < Wo ? av[s][2 * e] : 0.f, w + 1 < Wo ? av[s][2 * e + 1] : 0.f, h[e], m[e], l[e]);
+                for (int e = 0; e < 4; ++e) {
+                    const int w = w0 + 16 * s + 8 * half + 2 * e;
+                    split3_pk_w((WHOLE || w < Wo) ? av[s][2 * e] : 0.f, (WHOLE || w + 1 < Wo) ? av[s][2 * e + 1] : 0.f, h[e], m[e], l[e]);
+                }
+                af[s][0] = make_uint4(h[0], h[1], h[2], h[3]);
+                af[s][1] = make_uint4(m[0], m[1], m[2], m[3]);
+                af[s][2] = make_uint4(l[0], l[1], l[2], l[3]);
             }
-            af[s][0] = make_uint4(h[0], h[1], h[2], h[3]);
-            af[s][1] = make_uint4(m[0], m[1], m[2], m[3]);
-            af[s][2] = make_uint4(l[0], l[1], l[2], l[3]);
+        };
+#ifdef SS_EXP_WG_NOSTAGE          // (timing experiment, wrong results: split + LDS staging only for a wave's first chunk)
+        if (first_chunk)
+#endif
+        {
+        if (whole) { split_a(std::true_type{}); store_in(w0, std::true_type{}); }
+        else { split_a(std::false_type{}); store_in(w0, std::false_type{}); }
         }
-        store_in(w0);
+        first_chunk = false;
         __builtin_amdgcn_wave_barrier();
         // the next chunk's loads fly under this chunk's MFMAs
         have = advance();
+#ifndef SS_EXP_WG_NOLOAD          // (timing experiment, wrong results: no global loads after a wave's first chunk)
         if (have) { issue_a(); issue_in(nod * S + kd - 1, noh * S + kh - 1, nw0); }
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             uint4 bfr[3][3];                                // [kw][term]
@@ -244,8 +266,13 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
             }
             // six cross products per tap, smallest first: (m,m) (h,l) (l,h) (h,m) (m,h) (h,h)
             constexpr int pa[6] = {1, 0, 2, 0, 1, 0}, pb[6] = {1, 2, 0, 1, 0, 0};
+#ifdef SS_EXP_WG_NOMFMA           // (timing experiment, wrong results: one MFMA per tap and K-step instead of six)
+#pragma unroll
+            for (int p = 5; p < 6; ++p)
+#else
 #pragma unroll
             for (int p = 0; p < 6; ++p)
+#endif
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
                     acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][pa[p]]), __builtin_bit_cast(bf16x8, bfr[kw][pb[p]]),
@@ -292,18 +319,18 @@ extern "C" int ss_conv3d_wgrad_bf16s_fwd(const float* grad_out, const float* in,
     if (total_ll > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
     const int total = (int)total_ll;
     // ~8 waves per CU on 256 CUs; a unit (= wave) is (kernel-depth plane, tile pair, batch element, chunk range)
-    int nsplit = std::max(1, 3072 / (9 * tiles * B));
+    int nsplit = std::max(1, 3072 / (9 * tiles * B));             // ~12 waves per CU on 256 CUs
     int per_unit = std::max(chunks_per_row >= 4 ? 4 : 1, ss::ceil_div(total, nsplit));
     nsplit = ss::ceil_div(total, per_unit);
-    const dim3 grid(ss::ceil_div(9 * nsplit, 4), tiles, B);
+    const dim3 grid(ss::ceil_div(nsplit, 8) * 24, tiles, B);          // (split, kd) -> block index ((split / 8) * 3 + kd) * 8 + split % 8
     if (stride == 1) {
         auto kern = conv3d_wgrad_bf16s<1>;
-        hipLaunchKernelGGL(kern, grid, dim3(256), 4 * WG<1>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
+        hipLaunchKernelGGL(kern, grid, dim3(192), 3 * WG<1>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
                            total, per_unit, nsplit, ci_tiles);
     } else {
         auto kern = conv3d_wgrad_bf16s<2>;
-        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 4 * WG<2>::TILE) != SS_OK) return SS_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(256), 4 * WG<2>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 3 * WG<2>::TILE) != SS_OK) return SS_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(192), 3 * WG<2>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
                            total, per_unit, nsplit, ci_tiles);
     }
     if (ss::check_launch() != SS_OK) return SS_ERR_LAUNCH;

@@ -629,6 +629,8 @@ def stem_volume_half_presplit(stem, xs, xexp, partial, gate=None):
 #: feature map (ss_conv3d_gather_fwd) -- no warp launch, no 201 MB volume.  For INTEGER candidates only (what the reference's
 #: top-24 selection produces, models/SemStereo.py:299-305): callers pass `integer_candidates=True` when they know the provenance.
 STEM_GATHER = os.environ.get("SS_STEM_GATHER", "1") != "0"
+#: SS_STEM_INPLACE (r06): the gathered conv writes its result over the partial sum it continues (callers hand it a partial sum nobody else holds)
+STEM_INPLACE = os.environ.get("SS_STEM_INPLACE", "1") != "0"
 
 
 def stem_gather_applies(stem, right, samples):
@@ -654,7 +656,10 @@ def stem_gather_half(stem, right, samples, att, partial, gate=None):
     Cout = stem.conv.out_channels
     g = None if gate is None else gate.contiguous()
     dev = _lib.require_device(right, samples, att, partial, scale, shift, g)
-    out = torch.empty((B, Cout, nd, H, W), dtype=torch.float32, device=right.device)
+    # r06: the result may be written IN PLACE over the partial sum (every element is read once, by the lane that then writes it): the pair
+    # of launches then touches one 201 MB tensor instead of two, which is what the 256 MB Infinity Cache can still hold between them
+    inplace = STEM_INPLACE and partial is not None and partial.is_contiguous() and tuple(partial.shape) == (B, Cout, nd, H, W) and not partial.requires_grad
+    out = partial if inplace else torch.empty((B, Cout, nd, H, W), dtype=torch.float32, device=right.device)
     if partial is not None:
         assert partial.shape == out.shape and partial.is_contiguous()
     if g is not None:
@@ -677,4 +682,4 @@ ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launc
 
 #: the names tests / tools may SET on this module; `modules.X` forwards reads of them here
 SWITCHES = ("CONV_ENGINE", "DECONV_F16", "DECONV_MIN_WORKGROUPS", "DECONV_BF16S", "CLASSIFIER_CL", "CLASSIFIER_FUSED", "TRAIN_HIP", "ATTENTION_FORM",
-            "STEM_LEFT_FUSED", "STEM_PRESPLIT", "STEM_GATHER", "HEAD_F16", "CONV2D_HIP")
+            "STEM_LEFT_FUSED", "STEM_PRESPLIT", "STEM_GATHER", "STEM_INPLACE", "HEAD_F16", "CONV2D_HIP")
