@@ -29,6 +29,7 @@ ss::Tuning read_tuning() {
     t.deconv_groups = env_int("SS_DECONV_GROUPS");
     if (t.deconv_groups > 2) t.deconv_groups = -1;
     t.deconv_stream = env_int("SS_DECONV_STREAM");
+    t.wgrad_coop = env_int("SS_WGRAD_COOP");
     return t;
 }
 

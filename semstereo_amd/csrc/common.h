@@ -36,6 +36,7 @@ struct Tuning {
     int deconv_split;     // SS_DECONV_SPLIT 0/1: even/odd-plane split of the exact-fp32 transposed conv
     int deconv_groups;    // SS_DECONV_GROUPS (fp16 transposed convs): 0 = all 8 parity classes per workgroup, 1 = two class groups, 2 = + chunk-blocked accumulation; unset: by layer size
     int deconv_stream;    // SS_DECONV_STREAM 0/1: plain / nontemporal stores of the fp16 transposed convs' output; unset: by output size
+    int wgrad_coop;       // SS_WGRAD_COOP=0: the per-wave form of the stride-1 bf16 weight gradient instead of the cooperative one (r06)
 };
 const Tuning& tuning();
 

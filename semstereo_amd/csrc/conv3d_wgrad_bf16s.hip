@@ -199,7 +199,9 @@ __global__ __launch_bounds__(192, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
     };
     bool have = advance();
     if (have) { issue_a(); issue_in(nod * S + kd - 1, noh * S + kh - 1, nw0); }
+#ifdef SS_EXP_WG_NOSTAGE
     bool first_chunk = true;
+#endif
     while (have) {
         const int w0 = nw0;
         // ---- A fragments of this chunk: 2 K-steps x 8 positions of channel l31, split in registers (loaded a chunk ago) ----
@@ -229,7 +231,9 @@ __global__ __launch_bounds__(192, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
         if (whole) { split_a(std::true_type{}); store_in(w0, std::true_type{}); }
         else { split_a(std::false_type{}); store_in(w0, std::false_type{}); }
         }
+#ifdef SS_EXP_WG_NOSTAGE
         first_chunk = false;
+#endif
         __builtin_amdgcn_wave_barrier();
         // the next chunk's loads fly under this chunk's MFMAs
         have = advance();
@@ -288,6 +292,167 @@ __global__ __launch_bounds__(192, S == 1 ? 3 : 2) void conv3d_wgrad_bf16s(const 
         for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
 }
 
+// ---- the cooperative form (stride 1): the nine waves of a workgroup are the nine kernel rows (kd, kh) and WALK DOWN a column of
+// chunks: fixed (od, w0), oh = oh0 ... oh1.  The phase ablation of the per-wave kernel above (profiles/r06_h_wgrad_ablation.txt: 751
+// us as is, 386 without its global loads, 709 with a sixth of its MFMAs) says what it is bound by: every wave fetching its own 4 KB
+// of gout and 4.3 KB of input per 36 MFMAs, 3.6 GB through L2 for a 0.4 GB layer.  Walking down a column, step oh needs the input
+// rows oh - 1, oh, oh + 1 of each depth plane: ONE new row per plane and step, staged once -- a third of it by each of the plane's
+// three waves -- into a ring of four LDS tiles that all three read their fragments from; the gout chunk is staged once per step
+// by the nine waves together (double-buffered) instead of nine times: 17 KB per 324 MFMAs instead of 75, and a fifth of the
+// conversion work.  One barrier per step: at step t the workgroup writes row t + 1 into ring slot (t + 1) & 3 and gout chunk t into
+// buffer t & 1 (loaded a step ago), meets, issues the loads of step t + 1 and multiplies -- a wave still multiplying step t - 1
+// reads slots t - 2, t - 1, t and buffer (t - 1) & 1, none of which is being written.
+constexpr int CO_RING = 4;
+constexpr int CO_RSA = 80;                                // gout tile: [32 positions] bf16 per (term, co), 64 bytes, stride 80
+constexpr int CO_TILE = WG<1>::TILE;                      // one input-row tile: 3 terms x 32 ci x 112 bytes
+constexpr int CO_ATILE = 3 * 32 * CO_RSA;
+constexpr int CO_LDS = 3 * CO_RING * CO_TILE + 2 * CO_ATILE;      // 144 384 bytes: one workgroup of nine waves per CU
+
+__global__ __launch_bounds__(576, 1) void conv3d_wgrad_bf16s_coop(const float* __restrict__ gout, const float* __restrict__ in,
+                                                                   float* __restrict__ ws, int Cin, int Cout, int D, int H, int W,
+                                                                   int chunks_per_row, int seg_len, int nseg, int ci_tiles) {
+    using C = WG<1>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int kd = wave / 3, kh = wave - 3 * kd;
+    const int col = blockIdx.x / nseg, seg = blockIdx.x - col * nseg;
+    const int od = col / chunks_per_row, w0 = (col - od * chunks_per_row) * CW;
+    const int oh0 = seg * seg_len, oh1 = min(oh0 + seg_len, H);           // output rows [oh0, oh1) (stride 1: Ho = H, Wo = W)
+    const int co0 = (blockIdx.y / ci_tiles) * 32, ci0 = (blockIdx.y % ci_tiles) * 32;
+    const int b = blockIdx.z;
+    const int id = od + kd - 1;
+    const bool plane_ok = (unsigned)id < (unsigned)D;                      // (wave-uniform) this wave's depth plane exists
+    unsigned char* ring = lds_raw + kd * (CO_RING * CO_TILE);
+    unsigned char* abuf = lds_raw + 3 * CO_RING * CO_TILE;
+
+    const long long chan = (long long)D * H * W;
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(gout + (long long)b * Cout * chan), 0, (int)min((long long)Cout * chan * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in + (long long)b * Cin * chan), 0, (int)min((long long)Cin * chan * 4, 0x7fffffffLL), 0x00020000);
+    const int q = lane & 15, csub = lane >> 4;             // staging: lane = (position pair q, channel 4 i + csub)
+    const bool whole = w0 + CW + 1 <= W;                    // every column this column of chunks reads lies inside the rows: no masks
+    // this wave's share of the staging: iterations [i0, i1) of the new input row of its plane (+ the halo: kh == 2), iteration `wave`
+    // of the gout chunk (wave 8: none)
+    const int i0 = 3 * kh, i1 = min(3 * kh + 3, 8);
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float rin[6], rhalo = 0.f, ra[2] = {0.f, 0.f};
+    auto issue = [&](int t) {                               // the loads of step t: input row t + 1 (this wave's share), gout row t
+        const int ih = t + 1;
+        const bool row_ok = plane_ok && (unsigned)ih < (unsigned)H && ih <= oh1;
+        const unsigned row_b = (unsigned)((((long long)id * H + ih) * W) * 4);
+        const unsigned dead = row_ok ? 0u : 0x80000000u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = i0 + k;
+            const int c = ci0 + 4 * i + csub;
+            const unsigned ch = ((c < Cin && i < i1) ? (unsigned)(c * chan * 4) : 0x80000000u) | dead;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                rin[k * 2 + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(ch + (unsigned)((w0 + 2 * q + e) * 4)), (int)row_b, 0));
+        }
+        const int hw = half ? w0 + CW : w0 - 1;
+        const bool hok = row_ok && kh == 2 && (ci0 + l31 < Cin) && hw >= 0 && hw < W;
+        rhalo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              ires, (int)(hok ? (unsigned)((ci0 + l31) * chan * 4) + (unsigned)(hw * 4) : 0x80000000u), (int)row_b, 0));
+        const bool a_ok = wave < 8 && t >= oh0 && t < oh1;
+        const int ca = co0 + 4 * wave + csub;
+        const unsigned cha = (a_ok && ca < Cout) ? (unsigned)(ca * chan * 4) : 0x80000000u;
+        const unsigned arow_b = (unsigned)((((long long)od * H + max(t, 0)) * W) * 4);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            ra[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gres, (int)(cha + (unsigned)((w0 + 2 * q + e) * 4)), (int)arow_b, 0));
+    };
+    auto stage = [&](int t, auto whole_tag) {               // write what `issue(t)` loaded: input row t + 1 -> ring, gout row t -> buffer t & 1
+        constexpr bool WHOLE = decltype(whole_tag)::value;
+        const int ih = t + 1;
+        if (plane_ok && (unsigned)ih < (unsigned)H && ih <= oh1) {
+            unsigned char* tile = ring + ((ih + 4) & 3) * CO_TILE;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = i0 + k;
+                if (i < i1) {                                // (wave-uniform)
+                    const float v0 = (WHOLE || w0 + 2 * q < W) ? rin[k * 2] : 0.f, v1 = (WHOLE || w0 + 2 * q + 1 < W) ? rin[k * 2 + 1] : 0.f;
+                    unsigned h, m, l;
+                    split3_pk_w(v0, v1, h, m, l);
+                    unsigned char* p = tile + (4 * i + csub) * C::RS + 16 + 4 * q;
+                    *reinterpret_cast<unsigned*>(p) = h;
+                    *reinterpret_cast<unsigned*>(p + C::PLANE) = m;
+                    *reinterpret_cast<unsigned*>(p + 2 * C::PLANE) = l;
+                }
+            }
+            if (kh == 2) {                                   // the halo elements of channel l31: element 7 (left) / 40 (right) of the row
+                unsigned h, m, l;
+                split3_pk_w(rhalo, 0.f, h, m, l);
+                unsigned char* p = tile + l31 * C::RS + (half ? 80 : 14);
+                *reinterpret_cast<unsigned short*>(p) = (unsigned short)h;
+                *reinterpret_cast<unsigned short*>(p + C::PLANE) = (unsigned short)m;
+                *reinterpret_cast<unsigned short*>(p + 2 * C::PLANE) = (unsigned short)l;
+            }
+        }
+        if (wave < 8 && t >= oh0 && t < oh1) {
+            const float v0 = (WHOLE || w0 + 2 * q < W) ? ra[0] : 0.f, v1 = (WHOLE || w0 + 2 * q + 1 < W) ? ra[1] : 0.f;
+            unsigned h, m, l;
+            split3_pk_w(v0, v1, h, m, l);
+            unsigned char* p = abuf + (t & 1) * CO_ATILE + (4 * wave + csub) * CO_RSA + 4 * q;
+            *reinterpret_cast<unsigned*>(p) = h;
+            *reinterpret_cast<unsigned*>(p + 32 * CO_RSA) = m;
+            *reinterpret_cast<unsigned*>(p + 64 * CO_RSA) = l;
+        }
+    };
+
+    // pseudo-steps t = oh0 - 2, oh0 - 1 only stage (rows oh0 - 1, oh0); steps oh0 ... oh1 - 1 stage row t + 1 and multiply
+    issue(oh0 - 2);
+    for (int t = oh0 - 2; t < oh1; ++t) {
+        if (whole) stage(t, std::true_type{});
+        else stage(t, std::false_type{});
+        __syncthreads();
+        if (t + 1 < oh1) issue(t + 1);
+        const int ih = t + kh - 1;
+        if (t >= oh0 && plane_ok && (unsigned)ih < (unsigned)H) {          // (wave-uniform)
+            const unsigned char* tile = ring + ((ih + 4) & 3) * CO_TILE;
+            const unsigned char* at = abuf + (t & 1) * CO_ATILE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 af[3], bfr[3][3];
+                const int offa = l31 * CO_RSA + 16 * (2 * s + half), off = l31 * C::RS + 16 * (1 + 2 * s + half);
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) {
+                    af[tm] = *reinterpret_cast<const uint4*>(at + tm * 32 * CO_RSA + offa);
+                    const uint4 x = *reinterpret_cast<const uint4*>(tile + tm * C::PLANE + off);
+                    const unsigned pl = *reinterpret_cast<const unsigned*>(tile + tm * C::PLANE + off - 4);
+                    const unsigned nf = *reinterpret_cast<const unsigned*>(tile + tm * C::PLANE + off + 16);
+                    const unsigned a0 = __builtin_amdgcn_alignbit(x.x, pl, 16), a1 = __builtin_amdgcn_alignbit(x.y, x.x, 16);
+                    const unsigned a2 = __builtin_amdgcn_alignbit(x.z, x.y, 16), a3 = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+                    const unsigned a4 = __builtin_amdgcn_alignbit(nf, x.w, 16);
+                    bfr[0][tm] = make_uint4(a0, a1, a2, a3);
+                    bfr[1][tm] = x;
+                    bfr[2][tm] = make_uint4(a1, a2, a3, a4);
+                }
+                constexpr int pa[6] = {1, 0, 2, 0, 1, 0}, pb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[pa[p]]), __builtin_bit_cast(bf16x8, bfr[kw][pb[p]]),
+                                                                          acc[kw], 0, 0, 0);
+            }
+        }
+    }
+    float* wt = ws + ((long long)blockIdx.y * 27 + kd * 9 + kh * 3) * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
+}
+
 // workspace [tile][tap][register][lane] -> dW [Cout][Cin][27]: register r of lane (l31, half) = row (r & 3) + 8 (r >> 2) + 4 half
 // (output channel), column l31 (input channel)
 __global__ void wgrad_reorder_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int ci_tiles, long long total) {
@@ -323,7 +488,19 @@ extern "C" int ss_conv3d_wgrad_bf16s_fwd(const float* grad_out, const float* in,
     int per_unit = std::max(chunks_per_row >= 4 ? 4 : 1, ss::ceil_div(total, nsplit));
     nsplit = ss::ceil_div(total, per_unit);
     const dim3 grid(ss::ceil_div(nsplit, 8) * 24, tiles, B);          // (split, kd) -> block index ((split / 8) * 3 + kd) * 8 + split % 8
-    if (stride == 1) {
+    if (stride == 1 && ss::tuning().wgrad_coop != 0) {
+        // the cooperative form: a workgroup walks down a column (od, w0) of chunks, the columns cut into segments so that ~3 workgroups
+        // per CU exist
+        auto kern = conv3d_wgrad_bf16s_coop;
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), CO_LDS) != SS_OK) return SS_ERR_LAUNCH;
+        const long long cols = (long long)Do * chunks_per_row;
+        int nseg_c = (int)std::min<long long>(std::max<long long>(1, 768 / std::max<long long>(1, cols * tiles * B)), std::max(1, Ho / 8));
+        const int seg_len = ss::ceil_div(Ho, nseg_c);
+        nseg_c = ss::ceil_div(Ho, seg_len);
+        if (cols * nseg_c > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cols * nseg_c), tiles, B), dim3(576), CO_LDS, st, grad_out, in, workspace, Cin, Cout, D, H, W,
+                           chunks_per_row, seg_len, nseg_c, ci_tiles);
+    } else if (stride == 1) {
         auto kern = conv3d_wgrad_bf16s<1>;
         hipLaunchKernelGGL(kern, grid, dim3(192), 3 * WG<1>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
                            total, per_unit, nsplit, ci_tiles);
