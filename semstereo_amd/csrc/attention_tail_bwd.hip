@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void upsoft_bwd_coarse_kernel(const float* __r
 struct Taps4 {
     int o_nw, o_ne, o_sw, o_se;
     float w_nw, w_ne, w_sw, w_se, fw, fs, fn;
+    int ix, iy;                       // column of the west taps, row of the north taps
 };
 
 // the forward's arithmetic (attention_tail.hip::bilinear_taps / warp.hip::make_taps), plus the fractions the x-derivative needs
@@ -111,6 +112,7 @@ __device__ __forceinline__ Taps4 bilinear_taps(float disp, int h, int w, int H, 
     t.w_nw = ss::mul_rn(fs, fe); t.w_ne = ss::mul_rn(fs, fw);
     t.w_sw = ss::mul_rn(fn, fe); t.w_se = ss::mul_rn(fn, fw);
     t.fw = fw; t.fs = fs; t.fn = fn;
+    t.ix = ixw; t.iy = iyn;
     t.o_nw = (mn && mw) ? iyn * W + ixw : -1;
     t.o_ne = (mn && me) ? iyn * W + ixw + 1 : -1;
     t.o_sw = (ms && mw) ? (iyn + 1) * W + ixw : -1;
@@ -126,6 +128,12 @@ __device__ __forceinline__ Taps4 bilinear_taps(float disp, int h, int w, int H, 
 // atomic pair per workgroup.  (Rounds 4-5: ONE thread per pixel walked all C channels twice -- 1 024 waves on the whole chip, 168 M
 // unconditional atomics: 3.6 ms of the 1024^2 training step, measured r06.)
 constexpr int SSB_NW = 8;
+// ... and (r06, second step) the scatter into g_right goes through LDS: a workgroup's 64 pixels lie in one row y (W % 64 == 0) and the
+// five candidates' taps land in that same row within +-SSB_M columns of them (|disparity| <= maxdisp / 4), so each wave sums its
+// channel's contributions in a private row buffer (ds_add_f32) and adds the touched part to memory once: ~1 global atomic per
+// (pixel, channel) instead of ~12.  Taps in another row (the south taps where the row coordinate is not exact) or beyond the
+// margin go to memory directly, as before.
+constexpr int SSB_M = 64, SSB_RB = 64 + 2 * SSB_M + 2;
 __global__ __launch_bounds__(64 * SSB_NW) void sample_strength_bwd_kernel(const float* __restrict__ left, const float* __restrict__ right,
                                                                    const float* __restrict__ pred0, const float* __restrict__ var,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(64 * SSB_NW) void sample_strength_bwd_kernel(const 
                                                                    float* __restrict__ g_var, float* __restrict__ g_gb, int C, int H, int W,
                                                                    float half_w, float half_h, long long total) {
     constexpr int NW = SSB_NW;
-    __shared__ float red[NW][5][64], gred[NW][5][64];
+    __shared__ float red[NW][5][64], gred[NW][5][64], rowbuf[NW][SSB_RB + 62];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + lane;
     const bool active = i < total;
@@ -203,12 +211,27 @@ __global__ __launch_bounds__(64 * SSB_NW) void sample_strength_bwd_kernel(const 
         }
     }
     float gix[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    // (a workgroup whose 64 pixels share a row: every lane active, same y -- wave-uniform)
+    const bool rowblock = (W % 64 == 0) && g_right != nullptr;
+    const int xb = (int)((((long long)blockIdx.x * 64) % W)) - SSB_M;      // column of rowbuf[.][0]
+    float* rb = rowbuf[wave];
     if (active) {
         for (int c = wave; c < C; c += NW) {
             const float l = left[(b * C + c) * plane + pix];
             const float* rp = right + (b * C + c) * plane;
             float* grp = g_right ? g_right + (b * C + c) * plane : nullptr;
             float gl = 0.f;
+            if (rowblock) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rb[lane + 64 * k] = 0.f;
+                __builtin_amdgcn_wave_barrier();
+            }
+            auto scatter = [&](int o, int row, int col, float v) {
+                if (o < 0 || v == 0.f) return;
+                const unsigned k = (unsigned)(col - xb);
+                if (rowblock && row == y && k < (unsigned)SSB_RB) ss::lds_add(&rowbuf[wave][k], v);
+                else unsafeAtomicAdd(&grp[o], v);
+            };
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
                 float a, bq, cq, d;
@@ -216,15 +239,25 @@ __global__ __launch_bounds__(64 * SSB_NW) void sample_strength_bwd_kernel(const 
                 gl += dcorr[t] * (a * tp[t].w_nw + bq * tp[t].w_ne + cq * tp[t].w_sw + d * tp[t].w_se);
                 const float gr = dcorr[t] * l;
                 if (grp) {
-                    if (tp[t].o_nw >= 0 && tp[t].w_nw != 0.f) unsafeAtomicAdd(&grp[tp[t].o_nw], gr * tp[t].w_nw);
-                    if (tp[t].o_ne >= 0 && tp[t].w_ne != 0.f) unsafeAtomicAdd(&grp[tp[t].o_ne], gr * tp[t].w_ne);
-                    if (tp[t].o_sw >= 0 && tp[t].w_sw != 0.f) unsafeAtomicAdd(&grp[tp[t].o_sw], gr * tp[t].w_sw);
-                    if (tp[t].o_se >= 0 && tp[t].w_se != 0.f) unsafeAtomicAdd(&grp[tp[t].o_se], gr * tp[t].w_se);
+                    if (tp[t].w_nw != 0.f) scatter(tp[t].o_nw, tp[t].iy, tp[t].ix, gr * tp[t].w_nw);
+                    if (tp[t].w_ne != 0.f) scatter(tp[t].o_ne, tp[t].iy, tp[t].ix + 1, gr * tp[t].w_ne);
+                    if (tp[t].w_sw != 0.f) scatter(tp[t].o_sw, tp[t].iy + 1, tp[t].ix, gr * tp[t].w_sw);
+                    if (tp[t].w_se != 0.f) scatter(tp[t].o_se, tp[t].iy + 1, tp[t].ix + 1, gr * tp[t].w_se);
                 }
                 // d(sample)/d(ix) = (b - a) * fs + (d - c) * fn     (ATen's grid_sampler backward: gix)
                 gix[t] += gr * ((bq - a) * tp[t].fs + (d - cq) * tp[t].fn);
             }
             if (g_left) g_left[(b * C + c) * plane + pix] = gl;
+            if (rowblock) {                                  // the touched part of the row -> memory
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = lane + 64 * k;
+                    const float v = rb[idx];
+                    if (idx < SSB_RB && v != 0.f) unsafeAtomicAdd(&grp[(long long)y * W + xb + idx], v);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
 #pragma unroll

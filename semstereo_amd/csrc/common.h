@@ -91,6 +91,14 @@ __device__ __forceinline__ float exp_fast(float x) {
     return __fmaf_rn(p, e * 0.693147180559945f, p);
 }
 
+// fp32 add into LDS as ONE ds_add_f32 (no return value).  `p` must point into LDS: through a generic pointer the atomic is a FLAT
+// instruction, and pointer arithmetic that leaves the LDS aperture on the way (a negative intermediate offset) faults the queue
+// (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, r06).
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    typedef float __attribute__((address_space(3))) * lds_ptr_t;
+    __hip_atomic_fetch_add((lds_ptr_t)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // 16-byte LDS read that stays ONE ds_read_b128.  Through a plain float4 the optimiser splits the load into scalars,
 // drops unused lanes and re-merges the rest as 4- and 8-byte reads (gwc_patch_gate_v4: 56 LDS instructions per channel
 // block instead of 24, and at a 16-byte lane stride those are bank conflicts -- 47 -> 37 us, tools/pmc_sq.sh).

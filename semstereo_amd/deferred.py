@@ -576,7 +576,7 @@ def stem_of(stem_node, gate_module=None, im=None):
             and stem.conv.in_channels == 2 * cl.shape[1] and M._conv_geometry(stem.conv) == (3, 1)):
         partial = M.stem_broadcast_half(stem, cl, att)
         if M.stem_gather_applies(stem, cr, samples) and ops.integer_candidates(samples):
-            return M.stem_gather_half(stem, cr, samples, att, partial, gate)
+            return M.stem_gather_half(stem, cr, samples, att, partial, gate, consume_partial=True)
         if M.stem_presplit_applies(stem, cr):
             xs, xexp = ops.concat_volume_sampled_presplit(cr, samples, att)
             return M.stem_volume_half_presplit(stem, xs, xexp, partial, gate)

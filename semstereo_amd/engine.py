@@ -642,10 +642,11 @@ def stem_gather_applies(stem, right, samples):
             and right.shape[-1] > 1 and right.shape[-2] > 1)
 
 
-def stem_gather_half(stem, right, samples, att, partial, gate=None):
+def stem_gather_half(stem, right, samples, att, partial, gate=None, consume_partial=False):
     """`stem` over its last C input channels when they are att * (the 2-D map `right` [B,C,H,W] warped by the INTEGER candidates
     `samples` [B,nd,H,W]) -- models/SemStereo.py:241-244, 316-320 -- continuing `partial`, then BatchNorm, ReLU and the gate:
-    one launch, the operand gathered while the conv stages its tiles."""
+    one launch, the operand gathered while the conv stages its tiles.  consume_partial=True (callers that made `partial` themselves and
+    hold no other reference, STEM_INPLACE): the result is written over `partial`."""
     assert stem.is_3d and not stem.deconv and CONV_ENGINE == "f16x3" and _inference(stem, right, partial, gate)
     right, samples = right.contiguous(), samples.contiguous()
     att = att.reshape(att.shape[0], att.shape[-3], att.shape[-2], att.shape[-1]).contiguous()
@@ -658,7 +659,7 @@ def stem_gather_half(stem, right, samples, att, partial, gate=None):
     dev = _lib.require_device(right, samples, att, partial, scale, shift, g)
     # r06: the result may be written IN PLACE over the partial sum (every element is read once, by the lane that then writes it): the pair
     # of launches then touches one 201 MB tensor instead of two, which is what the 256 MB Infinity Cache can still hold between them
-    inplace = STEM_INPLACE and partial is not None and partial.is_contiguous() and tuple(partial.shape) == (B, Cout, nd, H, W) and not partial.requires_grad
+    inplace = consume_partial and STEM_INPLACE and partial is not None and partial.is_contiguous() and tuple(partial.shape) == (B, Cout, nd, H, W) and not partial.requires_grad
     out = partial if inplace else torch.empty((B, Cout, nd, H, W), dtype=torch.float32, device=right.device)
     if partial is not None:
         assert partial.shape == out.shape and partial.is_contiguous()

@@ -267,7 +267,7 @@ class HotSegment(nn.Module):
                 if M.stem_gather_applies(self.concat_stem, cr, samples) and ops.integer_candidates(samples):
                     # `samples` are the integer candidates of ops.topk_candidates (:299-305): the warped half is gathered inside
                     # the conv's staging -- no warp launch, no volume (ss_conv3d_gather_fwd)
-                    volume = M.stem_gather_half(self.concat_stem, cr, samples, att_topk, partial, _ready(gate4))   # :316-320
+                    volume = M.stem_gather_half(self.concat_stem, cr, samples, att_topk, partial, _ready(gate4), consume_partial=True)   # :316-320
                 elif M.stem_presplit_applies(self.concat_stem, cr):
                     xs, xexp = ops.concat_volume_sampled_presplit(cr, samples, att_topk)       # :316 + :318, warped half, pre-split
                     volume = M.stem_volume_half_presplit(self.concat_stem, xs, xexp, partial, _ready(gate4))   # :319 + :320
