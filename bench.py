@@ -909,8 +909,7 @@ def main():
         "config": {"workload": f"BASELINE.json {cfg_name}: {H}x{W} tile, maxdisp={maxdisp}, batch={B} per GPU x {world} GPU(s), features "
                                "[B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity [B,1,H/4,W/4]",
                    "pairs_per_gpu_per_step": B, "input_sets_rotated": len(feat_sets) if not graphed else 1,
-                   "execution": (f"consecutive steps (batch {B} each) round-robin on {args.streams} HIP streams (semstereo_amd.PairPipeline); "
-                                 "results bit-identical to one stream") if pipelined
+                   "execution": (f"steps round-robin on {args.streams} HIP streams (PairPipeline); bit-identical to one stream") if pipelined
                                 else "every step on one HIP stream",
                    "conv_engine": engine, "conv_engine_note": engine_note, "hip_graph": graphed},
         # (filled below, kept in the line's tail) the headline again beside the one-stream rate of the same K steps
@@ -944,7 +943,7 @@ def main():
                    f"conv3d_bf16s<1,4,4,4,{code},true,1,3" if k % 4 == 0 else f"conv3d_bf16s<1,4,2,8,{code},true,1,3")
             if not presplit:
                 sym += ",1,false,true>" if gathered else ">"
-            what = (" (warped half GATHERED from the 2-D right map inside the staging: warp + x att + conv) + partial sum" if gathered
+            what = (" (warped half gathered in the staging) + partial sum" if gathered
                     else " (warped half) + partial sum" if halves else "")
             line["roofline"] = {"kernel": f"{sym}: concat_stem {cin_stem}->32 k3 on [B,{cin_stem},24,H/4,W/4]" + what + " + BN + ReLU + gate",
                                 "bound": "mfma", "achieved": ex, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -981,7 +980,7 @@ def main():
             continue
         line["rates"][f"{key}_pairs_per_s"] = rec["pairs_per_s"]
         line["rates"][f"{key}_ms_per_step"] = rec["ms_per_step"]
-        line["rates"][f"{key}_single_stream_pairs_per_s"] = rec["single_stream_pairs_per_s"]
+        line["rates"][f"{key}_one_stream_pairs_per_s"] = rec["single_stream_pairs_per_s"]
     detail["side_configs"] = side_cfg
     line["dist"] = dist_rec
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and parity: rank 0 at N = 1 only
@@ -1035,14 +1034,12 @@ def main():
                     pu = parity_vs_reference(semstereo_amd, fx, "f1024_md128", device)
                     detail["parity_vs_reference_uncalibrated"] = pu
                     rp_u = pu.get("reference_picks_restored") or {}
-                    parity["fixture_uncal"] = {
+                    parity["fixture_uncal"] = {       # (everything else of this record: the detail file)
                         "epe_plain_fullres_px": pu["epe_vs_reference_fullres_px"], "pixels_with_other_candidates": pu["pixels_with_other_candidates"],
-                        "unexplained_candidate_differences": rp_u.get("unexplained_candidate_differences"),
+                        "unexplained": rp_u.get("unexplained_candidate_differences"),
                         "epe_picks_restored_fullres_px": rp_u.get("epe_vs_reference_fullres_px"),
                         "epe_picks_restored_off_ties_fullres_px": (4.0 * rp_u["epe_vs_reference_off_ties_px"]) if rp_u else None,
-                        "max_err_off_ties_px": rp_u.get("max_err_off_ties_px"), "pixels_at_top2_ties": rp_u.get("pixels_at_top2_ties"),
-                        "hip_vs_truth_epe_off_ties_px": rp_u.get("hip_vs_truth_epe_off_ties_px"),
-                        "reference_vs_truth_epe_off_ties_px": rp_u.get("reference_vs_truth_epe_off_ties_px")}
+                        "pixels_at_top2_ties": rp_u.get("pixels_at_top2_ties")}
                 epe_plain = [pvs[n_]["epe_vs_reference_fullres_px"] for n_ in names]
                 epe_rest = [(pvs[n_].get("reference_picks_restored") or {}).get("epe_vs_reference_fullres_px") for n_ in names]
                 parity["fixtures_1024"] = {
@@ -1057,9 +1054,9 @@ def main():
             stats, rows, secs = seeded_pairs_parity(seg, M, engines, args.parity_pairs, H, W, maxdisp, device, nthreads)
             # the line carries the default engine's figures in full and three per other engine; every statistic is in the detail file
             keep_main = ("epe_vs_oracle_px", "pixels_with_other_candidates", "picks_differing_from_float64", "epe_picks_restored_px",
-                         "epe_picks_restored_off_top2_ties_px", "pixels_gt_1e-3_picks_restored_off_ties")
+                         "epe_picks_restored_off_top2_ties_px")
             keep_other = ("epe_vs_oracle_px", "epe_picks_restored_px", "picks_differing_from_float64")
-            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] over pairs vs the fp32 CPU oracle; picks vs float64; picks_restored: the oracle's top-24 picks put back",
+            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] vs the fp32 CPU oracle; picks vs float64; restored: the oracle's top-24 picks put back",
                                       "by_conv_engine": {e: {k_: v for k_, v in st.items() if k_ in (keep_main if e == engine else keep_other)}
                                                          for e, st in stats.items()}}
             detail["seeded_pairs_stats"] = stats
