@@ -132,7 +132,19 @@ class Deferred:
         STATS["replayed"] += 1
         args, kwargs = real(self.args), real(self.kwargs)
         with suspended():                                # the recorded call itself, computing (no handles out of a replay)
-            return self.func(*args, **kwargs)
+            value = self.func(*args, **kwargs)
+        #  `ind_k.squeeze(1).float() - maxdisp // 4` replayed statement by statement is a fresh tensor: its provenance --
+        # integer indices minus an integer -- is known HERE, so it is marked as integer candidates and the gathered stem does not pay
+        # a device reduction and a host sync to find that out (ops.integer_candidates)
+        if self.op in ("sub", "float") and isinstance(value, torch.Tensor):
+            m = _samples_index_node(self)
+            if m is not None and float(m[1]) == int(m[1]):
+                from . import ops
+                try:
+                    ops._mark_integer(value, True)
+                except Exception:       # noqa: BLE001
+                    pass
+        return value
 
     # -- the tensor-like protocol --------------------------------------------------------------------------------------
     @classmethod

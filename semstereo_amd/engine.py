@@ -60,10 +60,18 @@ def drop_retired():
     del _RETIRED[:]
 
 
+#: at most this many replaced entries are kept (a primed but idle PairPipeline while plain calls follow weight updates would
+#: otherwise park the whole model's packed weights once per update, without bound); beyond it the oldest go -- they are older than any
+#: pair a pipeline can still have in flight by the time that many rebuilds (each a full pack launch sequence) have been issued
+RETIRED_CAP = 256
+
+
 def _note_build(old):
     _CACHE_GENERATION[0] += 1
     if old is not None and _RETAIN[0]:
         _RETIRED.append(old)
+        if len(_RETIRED) > RETIRED_CAP:
+            del _RETIRED[:len(_RETIRED) - RETIRED_CAP]
 
 
 class _ParamCache:

@@ -97,6 +97,7 @@ def accelerate(model, fuse_forward=False):
 
 def _realise_outputs(module, inputs, output):
     from . import deferred as dfr
+    M.drop_parked_gates(module)       #  a class gate parked by an odd number of SSR_upsample calls does not outlive the forward
     return dfr.real(output)
 
 

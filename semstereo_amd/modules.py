@@ -685,8 +685,14 @@ class SSR_upsample(nn.Module):
         for it twice with the very same tensors (models/SemStereo.py:311, 324): the first call parks it, the second takes it (one
         entry, consumed on use, so nothing outlives the forward; BatchNorm in train() then also sees the batch once per stage --
         its running statistics are updated once where the reference updates them twice with identical numbers)."""
-        key = (id(weights), id(pred_label), weights._version, pred_label._version, torch.is_grad_enabled(), self.training)
-        hit = self.__dict__.pop("_gate_parked", None)
+        # (ADVICE r5: the key also carries the versions of the gate's own parameters -- an optimizer step between the two calls must not
+        # hand back a gate computed with the old weights on an already-freed graph -- and the entry is parked OUTSIDE the module's
+        # __dict__, in a weak map, so that copy.deepcopy / state handling of the model never meet the non-leaf tensors; an entry left
+        # by an odd number of calls (att_weights_only, a direct call of the head) is replaced by the next call or dropped by
+        # drop_parked_gates(), which accelerate()'s forward hook calls when the model's forward returns)
+        key = (id(weights), id(pred_label), weights._version, pred_label._version, torch.is_grad_enabled(), self.training,
+               tuple(p_._version for p_ in self.parameters()))
+        hit = _GATE_PARKED.pop(self, None)
         if hit is not None and hit[0] == key and hit[1] is weights and hit[2] is pred_label:
             PATH_COUNTS["ssr_gate_reused"] = PATH_COUNTS.get("ssr_gate_reused", 0) + 1
             # the reference's second evaluation would have moved the running statistics once more with the same batch statistics s:
@@ -709,8 +715,22 @@ class SSR_upsample(nn.Module):
         prob = torch.sigmoid(self.conv1(F.softmax(pred_label, dim=1) * weights))
         prob = torch.sigmoid(self.conv2(prob * weights))
         if before is not None and torch.is_grad_enabled():
-            self.__dict__["_gate_parked"] = (key, weights, pred_label, prob, before)
+            _GATE_PARKED[self] = (key, weights, pred_label, prob, before)
         return prob
+
+
+_GATE_PARKED = __import__("weakref").WeakKeyDictionary()
+
+
+def drop_parked_gates(model=None):
+    """Forget the class gates parked by SSR_upsample._class_gate (all of them, or those of `model`'s heads): nothing parked outlives
+    the forward that made it."""
+    if model is None:
+        _GATE_PARKED.clear()
+        return
+    for m_ in model.modules():
+        if isinstance(m_, SSR_upsample):
+            _GATE_PARKED.pop(m_, None)
 
 
 def __getattr__(name):

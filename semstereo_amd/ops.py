@@ -538,6 +538,8 @@ def integer_candidates(samples):
     mark = getattr(samples, "_ss_integer", None)
     if mark is not None and mark[1] == samples._version:
         return mark[0]
+    if samples.is_cuda and torch.cuda.is_current_stream_capturing():
+        return False            #  no host sync inside a HIP-graph capture: an unmarked tensor takes the warp launch
     verdict = bool(torch.equal(samples, torch.trunc(samples)))
     try:
         _mark_integer(samples, verdict)

@@ -408,10 +408,13 @@ class PairPipeline:
         self.segment, self.nlanes = segment, int(lanes)
         self.lanes, self.turn, self.last_event, self._primed = None, 0, None, False
         self.rebuilds = 0                       # calls during which a per-module cache entry was (re)built (see __call__)
+        self.warmed_lanes = 0                   # lanes whose allocator pools were filled at first use (all of them unless memory is short)
 
     def _prime(self, inputs, dev):
         # weight packing and every other per-module cache are filled by a call ON THE CALLING STREAM, and drained, before several
         # streams read them
+        torch.cuda.reset_peak_memory_stats(dev)
+        self._alloc_before = torch.cuda.memory_allocated(dev)
         with torch.no_grad():
             self.segment(*inputs)
         torch.cuda.synchronize(dev)
@@ -422,7 +425,16 @@ class PairPipeline:
         M.E.drop_retired()
         if self.nlanes > 1:             # every lane's allocator pool filled by throw-away calls (see LANE_WARM_CALLS)
             cur = torch.cuda.current_stream(dev)
-            for _ in range(self.LANE_WARM_CALLS):
+            #  each lane's pool ends up holding one call's working set: `lanes` times the memory of a plain call.  The
+            # priming call above measured that working set; lanes whose pools would not fit in what is free now are not warmed (their
+            # first calls then allocate -- or fail -- inside the caller's own steps, where the caller sees it)
+            try:
+                free_b, _total = torch.cuda.mem_get_info(dev)
+                per_lane = max(torch.cuda.max_memory_allocated(dev) - self._alloc_before, 1)
+                self.warmed_lanes = int(min(self.nlanes, free_b * 0.8 // per_lane))
+            except Exception:       # noqa: BLE001
+                self.warmed_lanes = self.nlanes
+            for _ in range(self.LANE_WARM_CALLS if self.warmed_lanes == self.nlanes else 0):
                 for lane in self.lanes:
                     lane.wait_stream(cur)
                     with torch.cuda.stream(lane), torch.no_grad(), overlap_override(False):

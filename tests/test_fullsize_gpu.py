@@ -298,6 +298,30 @@ def test_hot_segment_full_size_vs_reference_checksums(sa, golden, name):
     assert float(err[clean].mean()) <= ((4e-5 if gathered else 3e-5) if default_engine else 1e-4) and float(err.median()) <= 1e-4
 
 
+def test_hot_segment_full_size_strict_without_the_gathered_stem(sa, golden, monkeypatch):
+    """the three-launch stem (SS_STEM_GATHER=0: warp kernel -> volume -> conv, the reference's own coordinate arithmetic
+    restated operation by operation) keeps ROUND 4's bounds against the reference -- every pixel off its cost ties within 5e-4 px,
+    HIP vs truth <= 1.25x / 1.3x the reference's own distance -- so that path cannot regress unnoticed behind the gathered default,
+    whose distance to the reference is the reference's own error."""
+    if sa.modules.CONV_ENGINE != "f16x3":
+        pytest.skip("bounds of the default engine")
+    import strict
+    name = "f1024_md128_cal"
+    if "segment_full" not in golden or strict.fixture_view(golden["segment_full"], name) is None:
+        pytest.skip(f"{name}: no round-3 fixture")
+    monkeypatch.setattr(sa.engine, "STEM_GATHER", False)
+    g = golden["segment_full"]
+    seg = sa.HotSegment(cases.segment_shape(name)[3])
+    seg.load_state_dict(cases.segment_params(name, g), strict=False)
+    seg = seg.cuda().eval()
+    rep, v, pred, differs, unexplained = strict.run_strict(seg, g, name)
+    ref_self, ref_mean = rep["reference_vs_truth_max_off_ties_px"], rep["reference_vs_truth_epe_off_ties_px"]
+    assert not bool(unexplained.any())
+    assert rep["max_err_off_ties_px"] <= 5e-4, rep
+    assert rep["hip_vs_truth_max_off_ties_px"] <= 1.25 * ref_self and rep["hip_vs_truth_epe_off_ties_px"] <= 1.3 * ref_mean, rep
+    assert rep["epe_vs_reference_off_ties_px"] <= 3e-5 and rep["epe_vs_reference_fullres_px"] <= 1e-3, rep
+
+
 @pytest.mark.parametrize("name", sorted(cases.SEGMENT_FULL))
 def test_hot_segment_full_size_strict_on_the_reference_picks(sa, golden, name):
     """Round 3: the full sizes held to the bound on EVERY pixel, with no receptive-field excuse.  The HIP

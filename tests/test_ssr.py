@@ -123,7 +123,27 @@ def test_training_computes_the_class_gate_once_and_keeps_the_reference_semantics
     w1, l1 = w.clone().requires_grad_(True), l.clone().requires_grad_(True)
     before = sa.modules.PATH_COUNTS.get("ssr_gate_reused", 0)
     ya = a(d1, w1, l1) + a(d2, w1, l1)                          # same tensors twice: the second call takes the parked gate
-    assert sa.modules.PATH_COUNTS.get("ssr_gate_reused", 0) == before + 1 and "_gate_parked" not in a.__dict__
+    assert sa.modules.PATH_COUNTS.get("ssr_gate_reused", 0) == before + 1 and a not in sa.modules._GATE_PARKED
+    ya.sum().backward()
+    #  an ODD number of calls leaves an entry behind: it lives outside the module (deepcopy still works), is dropped on
+    # request (accelerate()'s forward hook does so when the model's forward returns), and a parameter update between two calls
+    # invalidates it (the key carries the parameters' versions)
+    a(d1, w1, l1)
+    assert a in sa.modules._GATE_PARKED
+    copy.deepcopy(a)
+    with torch.no_grad():
+        next(a.parameters()).add_(0.0)                         # what optimizer.step() does to the version counter
+    reused = sa.modules.PATH_COUNTS.get("ssr_gate_reused", 0)
+    a(d2, w1, l1)
+    assert sa.modules.PATH_COUNTS.get("ssr_gate_reused", 0) == reused, "a gate computed with the old weights was handed back"
+    sa.modules.drop_parked_gates(a)
+    assert a not in sa.modules._GATE_PARKED
+    for p_ in a.parameters():
+        p_.grad = None
+    a.load_state_dict(b.state_dict())
+    a.zero_grad(); b.zero_grad()
+    w1, l1 = w.clone().requires_grad_(True), l.clone().requires_grad_(True)
+    ya = a(d1, w1, l1) + a(d2, w1, l1)
     ya.sum().backward()
     w2, l2 = w.clone().requires_grad_(True), l.clone().requires_grad_(True)
     yb = b(d1, w2, l2) + b(d2, w2.clone(), l2.clone())          # other tensor objects: two full evaluations (the reference's form)
