@@ -453,6 +453,105 @@ __global__ __launch_bounds__(576, 1) void conv3d_wgrad_bf16s_coop(const float* _
         for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
 }
 
+// ---- a single output channel (the classifiers' 32 -> 1 heads, models/SemStereo.py:228-234): dW[ci, tap] = sum_p' x[ci, p'] * g[p' - tap + 1].
+// With Cout = 1 the tile forms above spend 27 accumulator tiles on one live matrix row each (the head's weight gradient cost what a
+// 32 -> 32 layer's costs, 0.48 ms at [24,256,256]).  Here the 27 TAPS are the MFMA's N columns: A = x (lane = input channel, 8
+// consecutive input positions, read exactly once), B[k = position][n = tap] = the gradient row the tap points at, shifted by kw --
+// every lane reads its own (row, shift) from a small LDS tile of the 9 neighbouring gradient rows.  One accumulator tile per wave.
+__global__ __launch_bounds__(256) void conv3d_wgrad_head_bf16s(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw,
+                                                                int Cin, int D, int H, int W, int chunks_per_row, int total_chunks,
+                                                                int chunks_per_wave) {
+    __shared__ float gt_all[4][9][40];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int unit = blockIdx.x * 4 + wave;
+    const int c_begin = unit * chunks_per_wave, c_end = min(c_begin + chunks_per_wave, total_chunks);
+    const int ci0 = blockIdx.y * 32;
+    const int b = blockIdx.z;
+    float (*gt)[40] = gt_all[wave];
+    const long long chan = (long long)D * H * W;
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g + (long long)b * chan), 0, (int)min(chan * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + (long long)b * Cin * chan), 0, (int)min((long long)Cin * chan * 4, 0x7fffffffLL), 0x00020000);
+    const unsigned a_lane = (ci0 + l31 < Cin) ? (unsigned)((ci0 + l31) * chan * 4) + 32u * half : 0x80000000u;
+    const bool tap_ok = l31 < 27;
+    const int trow = tap_ok ? l31 / 3 : 0, kw = tap_ok ? l31 % 3 : 0;       // row kd * 3 + kh of the gradient tile, column shift
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float av[2][8], gv[9];
+    auto issue = [&](int c) {                               // the loads of chunk c: its 9 gradient rows (lanes < 34) and this lane's 2 x 8 inputs
+        const int row = c / chunks_per_row, w0 = (c - row * chunks_per_row) * CW;
+        const int id = row / H, ih = row - id * H;
+        const int col = w0 - 1 + lane;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int od = id - r / 3 + 1, oh = ih - r % 3 + 1;
+            const bool ok = lane < 34 && (unsigned)od < (unsigned)D && (unsigned)oh < (unsigned)H && (unsigned)col < (unsigned)W;
+            gv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  gres, (int)(ok ? (unsigned)((((long long)od * H + oh) * W + col) * 4) : 0x80000000u), 0, 0));
+        }
+        const unsigned x_row = (unsigned)((((long long)id * H + ih) * W + w0) * 4);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                av[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, (int)(a_lane + (unsigned)((16 * s + e) * 4)), (int)x_row, 0));
+    };
+    if (c_begin < c_end) issue(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int row = c / chunks_per_row, w0 = (c - row * chunks_per_row) * CW;
+        // this chunk's operands out of the prefetch registers: the gradient rows -> LDS, the inputs -> three bf16 terms
+        if (lane < 34) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) gt[r][lane] = gv[r];
+        }
+        uint4 af[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int w = w0 + 16 * s + 8 * half + 2 * e;
+                split3_pk_w(w < W ? av[s][2 * e] : 0.f, w + 1 < W ? av[s][2 * e + 1] : 0.f, h[e], m[e], l[e]);
+            }
+            af[s][0] = make_uint4(h[0], h[1], h[2], h[3]); af[s][1] = make_uint4(m[0], m[1], m[2], m[3]); af[s][2] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (c + 1 < c_end) issue(c + 1);                    // the next chunk's loads fly under this chunk's arithmetic
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 bf[3];
+            unsigned h[4], m[4], l[4];
+            const float* gp = &gt[trow][16 * s + 8 * half + 2 - kw];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3_pk_w(tap_ok ? gp[2 * e] : 0.f, tap_ok ? gp[2 * e + 1] : 0.f, h[e], m[e], l[e]);
+            bf[0] = make_uint4(h[0], h[1], h[2], h[3]); bf[1] = make_uint4(m[0], m[1], m[2], m[3]); bf[2] = make_uint4(l[0], l[1], l[2], l[3]);
+            constexpr int pa[6] = {1, 0, 2, 0, 1, 0}, pb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][pa[p]]), __builtin_bit_cast(bf16x8, bf[pb[p]]), acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the four waves' tiles are summed through LDS (fixed order), then ONE wave adds the workgroup's tile to grad_w: every workgroup hits
+    // the same Cin x 27 addresses, and 8 192 waves doing so one by one took 0.4 ms of a 0.03 ms kernel
+    __shared__ float red[4][16][64];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // D layout: register r of lane (l31, half) = row (r & 3) + 8 (r >> 2) + 4 half (input channel), column l31 (tap)
+    if (wave == 0 && tap_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+            if (ci < Cin) unsafeAtomicAdd(dw + (long long)ci * 27 + l31, v);
+        }
+    }
+}
+
 // workspace [tile][tap][register][lane] -> dW [Cout][Cin][27]: register r of lane (l31, half) = row (r & 3) + 8 (r >> 2) + 4 half
 // (output channel), column l31 (input channel)
 __global__ void wgrad_reorder_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int ci_tiles, long long total) {
@@ -478,6 +577,20 @@ extern "C" int ss_conv3d_wgrad_bf16s_fwd(const float* grad_out, const float* in,
     hipStream_t st = ss::as_stream(stream);
     const int ci_tiles = ss::ceil_div(Cin, 32), tiles = ci_tiles * ss::ceil_div(Cout, 32);
     if (tiles > 65535) return SS_ERR_UNSUPPORTED;
+    if (Cout == 1 && stride == 1 && ss::tuning().wgrad_coop != 0) {
+        // a single output channel: the taps as the matrix columns (conv3d_wgrad_head_bf16s), straight into grad_w
+        if (hipMemsetAsync(grad_w, 0, (size_t)Cin * 27 * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+        const int cpr = ss::ceil_div(W, CW);
+        const long long total_ll = (long long)D * H * cpr;
+        if (total_ll > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+        const int total = (int)total_ll;
+        const int waves = std::max(4, 2048 / (ci_tiles * B));
+        const int per_wave = std::max(1, ss::ceil_div(total, waves));
+        const int nwaves = ss::ceil_div(total, per_wave);
+        hipLaunchKernelGGL(conv3d_wgrad_head_bf16s, dim3(ss::ceil_div(nwaves, 4), ci_tiles, B), dim3(256), 0, st, grad_out, in, grad_w, Cin, D, H, W,
+                           cpr, total, per_wave);
+        return ss::check_launch();
+    }
     if (hipMemsetAsync(workspace, 0, (size_t)tiles * 27 * 1024 * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
     const int chunks_per_row = ss::ceil_div(Wo, CW);
     const long long total_ll = (long long)Do * Ho * chunks_per_row;
