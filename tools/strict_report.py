@@ -46,7 +46,7 @@ for name in names:
     del seg
     torch.cuda.empty_cache()
 if len(ALL) > 1:
-    same = [o for o in ALL if o["fixture"].startswith("f1024")]
+    same = [o for o in ALL if o["fixture"].startswith("f1024") and "_cal" in o["fixture"]]      # (the calibrated records; the uncalibrated one has its own line)
     if len(same) > 1:
         print(json.dumps({"mean_over": [o["fixture"] for o in same],
                           "plain_run_epe_vs_reference_fullres_px": sum(o["plain_run_epe_vs_reference_fullres_px"] for o in same) / len(same),
