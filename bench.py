@@ -906,8 +906,8 @@ def main():
         # pair, and not the one-call-at-a-time rate of rounds 1-3 (that one is rates.single_stream_pairs_per_s, same K steps)
         "value_kind": (f"throughput, {args.streams} pairs in flight" if pipelined else "throughput, one call at a time"),
         "lanes_in_flight": args.streams if pipelined else 1,
-        "config": {"workload": f"BASELINE.json {cfg_name}: {H}x{W} tile, maxdisp={maxdisp}, batch={B} per GPU x {world} GPU(s), features "
-                               "[B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity [B,1,H/4,W/4]",
+        "config": {"workload": f"BASELINE.json {cfg_name}: {H}x{W}, maxdisp={maxdisp}, batch={B}/GPU x {world} GPU(s); features "
+                               "[B,128,H/4,W/4]+[B,256,H/8,W/8] -> disparity",
                    "pairs_per_gpu_per_step": B, "input_sets_rotated": len(feat_sets) if not graphed else 1,
                    "execution": (f"steps round-robin on {args.streams} HIP streams (PairPipeline); bit-identical to one stream") if pipelined
                                 else "every step on one HIP stream",
@@ -1025,7 +1025,7 @@ def main():
                 rp = pv.get("reference_picks_restored")
                 if rp:
                     parity["reference_picks_restored"] = {k_: rp[k_] for k_ in (
-                        "epe_vs_reference_fullres_px", "max_err_off_ties_px", "pixels_beyond_1e-3", "hip_vs_truth_epe_off_ties_px",
+                        "epe_vs_reference_fullres_px", "max_err_off_ties_px", "hip_vs_truth_epe_off_ties_px",
                         "reference_vs_truth_epe_off_ties_px", "hip_vs_truth_max_off_ties_px", "reference_vs_truth_max_off_ties_px")}
                 # r06: the record with DEFAULT (uncalibrated) BatchNorm statistics -- the state of the random-init weights
                 # the timed step and the seeded pairs run on: 13 % of its pixels sit within 1e-4 (relative) of a top-24 tie and 7 % within
@@ -1056,7 +1056,7 @@ def main():
             keep_main = ("epe_vs_oracle_px", "pixels_with_other_candidates", "picks_differing_from_float64", "epe_picks_restored_px",
                          "epe_picks_restored_off_top2_ties_px")
             keep_other = ("epe_vs_oracle_px", "epe_picks_restored_px", "picks_differing_from_float64")
-            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] vs the fp32 CPU oracle; picks vs float64; restored: the oracle's top-24 picks put back",
+            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] vs fp32 CPU oracle; picks vs float64; restored = oracle's top-24 picks put back",
                                       "by_conv_engine": {e: {k_: v for k_, v in st.items() if k_ in (keep_main if e == engine else keep_other)}
                                                          for e, st in stats.items()}}
             detail["seeded_pairs_stats"] = stats
