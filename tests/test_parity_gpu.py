@@ -1832,6 +1832,29 @@ def test_conv3d_training_forward_dgrad_wgrad_in_hip(sa, case):
     assert e_y <= 2e-6 and e_x <= 2e-6 and e_w <= 5e-6, (e_y, e_x, e_w)
 
 
+@pytest.mark.parametrize("form", ["f32", "per_wave"])
+def test_conv3d_weight_gradient_other_forms(sa, form, tuning_env, monkeypatch):
+    """The weight-gradient kernels that are not the default: the exact-fp32 MFMA kernel of rounds 2-5 (SS_WGRAD_ENGINE=f32) and the
+    per-wave form of the stride-1 bf16 kernel (SS_WGRAD_COOP=0) -- same bound as the default forms, on shapes with ragged chunks,
+    a single output channel and channel counts that are not multiples of 32."""
+    import torch.nn.functional as F
+    from oracle import detdata as dd
+    if form == "f32":
+        monkeypatch.setattr(sa.train_layers, "WGRAD_ENGINE", "f32")
+    else:
+        tuning_env("SS_WGRAD_COOP", "0")
+    for (B, Cin, Cout, D, H, W, stride) in [(1, 32, 32, 5, 21, 150, 1), (1, 40, 48, 2, 6, 20, 1), (1, 8, 1, 3, 9, 70, 1), (2, 32, 64, 6, 22, 138, 2)]:
+        x = dd.t_normalish((B, Cin, D, H, W), 850)
+        w64 = (dd.t_uniform((Cout, Cin, 3, 3, 3), 851, -1, 1) * (3.0 / (Cin * 27)) ** 0.5).double().requires_grad_(True)
+        y64 = F.conv3d(x.double(), w64, None, stride, 1)
+        seed = dd.t_normalish(tuple(y64.shape), 852)
+        y64.backward(seed.double())
+        gw = sa.train_layers.conv3d_wgrad_hip(dev(seed), dev(x), Cout, Cin, stride)
+        e_w = float((gw.double().cpu() - w64.grad).abs().max()) / float(w64.grad.abs().max())
+        REPORT[f"conv3d_wgrad/{form}/{(B, Cin, Cout, D, H, W, stride)}"] = e_w
+        assert e_w <= 5e-6, (form, e_w)
+
+
 @pytest.mark.parametrize("case", [(1, 64, 32, 3, 6, 18), (2, 128, 64, 2, 4, 8), (1, 48, 40, 2, 5, 33)])
 def test_deconv3d_training_forward_dgrad_wgrad_in_hip(sa, case):
     """ConvTranspose3d(k3,s2,p1,op1) of the hourglasses (models/SemStereo.py:124-130) through the HIP autograd function."""
