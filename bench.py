@@ -384,6 +384,55 @@ def side_config_leg(seg, B2, H2, W2, md2, streams, steps, device):
     return rec
 
 
+def training_leg(seg, steps, device):
+    """the TRAINING step of the hot segment in the same run (N = 1 only): forward + backward + fused-Adam step of
+    HotSegment.train() at the shape the reference trains at (1024 x 1024 tiles, maxdisp 64: main_us3d.py:54, 74, 186-222), batch 1 and the
+    reference's batch 4, HIP events around `steps` steps after 2; tools/bench_train.py is the stand-alone form (memory, determinism, the
+    rocprofv3 breakdown)."""
+    import torch.nn.functional as F
+    H = W = 1024
+    md = 64
+    tr = semstereo_amd.HotSegment(md).to(device)
+    tr.load_state_dict(seg.state_dict())
+    tr.train()
+    rec = {"workload": f"{H}x{W} maxdisp={md}, HotSegment.train(): forward + backward + Adam step (main_us3d.py:186-222)", "steps": steps, "by_batch": {}}
+    before = dict(semstereo_amd.modules.PATH_COUNTS)
+    for B2 in (1, 4):
+        try:
+            opt = torch.optim.Adam(tr.parameters(), lr=1e-3, betas=(0.9, 0.999), fused=True)
+        except (TypeError, RuntimeError):
+            opt = torch.optim.Adam(tr.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        fl8, fr8 = synth_features(B2, 256, H // 8, W // 8, 6, 8100, device)
+        fl4, fr4 = synth_features(B2, 128, H // 4, W // 4, 12, 8200, device)
+        feats = [t.requires_grad_(True) for t in (fl4, fr4, fl8, fr8)]
+        gt = (torch.rand(B2, H // 4, W // 4, device=device) * 2 - 1) * (md // 4 - 1)
+
+        def one():
+            opt.zero_grad(set_to_none=True)
+            for t in feats:
+                t.grad = None
+            r = tr(*feats)
+            (F.smooth_l1_loss(r["pred"].squeeze(1), gt) + F.smooth_l1_loss(r["pred_att"], gt)).backward()
+            opt.step()
+        torch.cuda.reset_peak_memory_stats(device)
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            one()
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / steps
+        rec["by_batch"][str(B2)] = {"ms_per_step": ms, "pairs_per_s": 1e3 * B2 / ms, "peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30}
+        del opt, feats
+    rec["pytorch_layers_run"] = semstereo_amd.modules.PATH_COUNTS["torch"] - before["torch"]
+    del tr
+    torch.cuda.empty_cache()
+    return rec
+
+
 def power_under_load(run_steps):
     """Socket power and shader clock (rocm-smi, ~3 samples a second from a side thread) while `run_steps()` keeps the step loop
     busy.  The step sits at the package power cap with the shader clock throttled (profiles/r04_w_power_trace.txt: 1335 W of
@@ -659,6 +708,8 @@ def main():
     ap.add_argument("--power-seconds", type=float, default=2.5, help="seconds of the step loop sampled with rocm-smi (socket power, shader clock; N = 1 only; 0: skip)")
     ap.add_argument("--side-config-steps", type=int, default=12, help="timed steps of each side leg (configs[2]: batch 8; configs[4] per GPU: "
                     "2048^2 / 192 batch 1) run at N = 1 beside the configs[1] headline; 0: skip")
+    ap.add_argument("--train-steps", type=int, default=4, help="timed steps of the training leg (HotSegment.train() at 1024^2 / maxdisp 64, batch 1 and 4; "
+                    "N = 1 only; 0: skip)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), help="where the forensics go")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (one launch per step instead "
                     "of ~45 from Python); the per-kernel HIP-event timers are off in this mode")
@@ -822,6 +873,14 @@ def main():
                 side_cfg[key] = {"error": repr(e)[:200]}
         assert M.PATH_COUNTS["torch"] == 0, "a PyTorch fallback ran inside a side leg"
 
+    training = None
+    if world == 1 and not dry and not graphed and args.train_steps > 0 and (H, W, maxdisp, B) == (1024, 1024, 128, 1) and engine == "f16x3":
+        try:
+            training = training_leg(seg, args.train_steps, device)
+        except Exception as e:       # noqa: BLE001  (never lose the headline to a side leg)
+            training = {"error": repr(e)[:200]}
+        assert M.PATH_COUNTS["torch"] == 0, "a PyTorch layer ran inside the training leg's 3-D stack"
+
     # what a SCALE run must show to be self-verifying -- the group's size as torch.distributed sees it, every rank's
     # own rate, and the bytes of the one collective that follows the forward (the padded all_gather of the [b,1,H/4,W/4] disparities)
     dist_rec = {"world_size": dist.get_world_size() if grouped else 1, "backend": dist.get_backend() if grouped else None}
@@ -980,8 +1039,11 @@ def main():
             continue
         line["rates"][f"{key}_pairs_per_s"] = rec["pairs_per_s"]
         line["rates"][f"{key}_ms_per_step"] = rec["ms_per_step"]
-        line["rates"][f"{key}_one_stream_pairs_per_s"] = rec["single_stream_pairs_per_s"]
     detail["side_configs"] = side_cfg
+    detail["training"] = training
+    if training and "by_batch" in training:       # (the full record: detail file; tools/bench_train.py: memory, determinism, rocprofv3 breakdown)
+        line["rates"]["train_ms_per_step_b1"] = training["by_batch"]["1"]["ms_per_step"]
+        line["rates"]["train_pairs_per_s_b4"] = training["by_batch"]["4"]["pairs_per_s"]
     line["dist"] = dist_rec
     if not args.no_cpu_baseline and world == 1:        # CPU baseline and parity: rank 0 at N = 1 only
         # The oracle (this repo's CPU restatement of the reference algorithm) on ONE pair of the same workload: about 10 s of CPU
@@ -1020,7 +1082,7 @@ def main():
                 pvs = {n_: parity_vs_reference(semstereo_amd, fx, n_, device) for n_ in names}
                 detail["parity_vs_reference"] = pvs
                 pv = pvs[names[0]]
-                for k_ in ("epe_vs_reference_px", "epe_vs_reference_fullres_px", "pixels_with_other_candidates", "pixels_beyond_1e-3", "max_abs_err_px"):
+                for k_ in ("epe_vs_reference_fullres_px", "pixels_with_other_candidates", "pixels_beyond_1e-3", "max_abs_err_px"):
                     parity[k_] = pv[k_]
                 rp = pv.get("reference_picks_restored")
                 if rp:
@@ -1056,7 +1118,7 @@ def main():
             keep_main = ("epe_vs_oracle_px", "pixels_with_other_candidates", "picks_differing_from_float64", "epe_picks_restored_px",
                          "epe_picks_restored_off_top2_ties_px")
             keep_other = ("epe_vs_oracle_px", "epe_picks_restored_px", "picks_differing_from_float64")
-            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] vs fp32 CPU oracle; picks vs float64; restored = oracle's top-24 picks put back",
+            parity["seeded_pairs"] = {"n": args.parity_pairs, "stat": "[mean, std] vs fp32 CPU oracle; restored = oracle's top-24 picks put back",
                                       "by_conv_engine": {e: {k_: v for k_, v in st.items() if k_ in (keep_main if e == engine else keep_other)}
                                                          for e, st in stats.items()}}
             detail["seeded_pairs_stats"] = stats

@@ -8,7 +8,7 @@ out=$root/gpurun_out
 mkdir -p $out/prof_$tag
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $out/prof_$tag -o run -- python3 $root/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-engines --steady-seconds 0 --power-seconds 0 --no-side-rooflines --side-config-steps 0 --streams 1 "$@" > $out/${tag}_bench.json 2> $out/${tag}_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $out/prof_$tag -o run -- python3 $root/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-engines --steady-seconds 0 --power-seconds 0 --no-side-rooflines --side-config-steps 0 --train-steps 0 --streams 1 "$@" > $out/${tag}_bench.json 2> $out/${tag}_prof.err
 cd $root
 db=$(find $out/prof_$tag -name "*.db" | head -1)
 stats=$(find $out/prof_$tag -name "*kernel_stats.csv" | head -1)

@@ -22,8 +22,8 @@ timeout 400 python tools/bench_train.py --batches 1,2,4 --out $o/${tag}_bench_tr
 timeout 300 bash tools/profile_train.sh ${tag} 1 > /dev/null 2>&1
 timeout 600 python bench.py --steps 20 --warmup 5 --detail $o/${tag}_bench_detail_k20.json > $o/${tag}_bench_k20.json 2> /dev/null     # the driver's form
 timeout 900 python bench.py --detail $o/${tag}_bench_detail_b1.json > $o/${tag}_bench_b1.json 2> $o/${tag}_bench_b1.err
-timeout 300 python bench.py --batch 4 --side-config-steps 0 --no-cpu-baseline --no-other-engines --no-side-rooflines --detail /tmp/d4.json > $o/${tag}_bench_b4.json 2>/dev/null
-timeout 300 python bench.py --batch 8 --side-config-steps 0 --no-cpu-baseline --no-other-engines --no-side-rooflines --detail /tmp/d8.json > $o/${tag}_bench_b8.json 2>/dev/null
+timeout 300 python bench.py --batch 4 --side-config-steps 0 --train-steps 0 --no-cpu-baseline --no-other-engines --no-side-rooflines --detail /tmp/d4.json > $o/${tag}_bench_b4.json 2>/dev/null
+timeout 300 python bench.py --batch 8 --side-config-steps 0 --train-steps 0 --no-cpu-baseline --no-other-engines --no-side-rooflines --detail /tmp/d8.json > $o/${tag}_bench_b8.json 2>/dev/null
 timeout 300 python bench.py --height 2048 --width 2048 --maxdisp 192 --no-cpu-baseline --no-other-engines --no-side-rooflines --detail /tmp/d2k.json > $o/${tag}_bench_2048_b1.json 2>/dev/null
 timeout 300 bash tools/profile_step.sh ${tag} > /dev/null 2>&1
 timeout 600 python tools/strict_report.py f1024_md128_cal f1024_md128_cal_b f1024_md128_cal_c f2048_md192_cal f1024_md128 > $o/${tag}_strict_report.txt 2>/dev/null
