@@ -57,6 +57,9 @@ constexpr int KST = 27;           // K-steps per 16-channel chunk
 // hourglass2.conv6 (201 MB written, alone): 128 -> 108 us; sc0 + nt the same; nontemporal loads of the skip tensor 119, both 124
 // (profiles/r05_f_deconv_forms.txt).  The launcher streams outputs of >= 192 MB per launch (the rule of the gwc volume kernel:
 // smaller outputs are handed to the next kernel by the 256 MB Infinity Cache); SS_DECONV_STREAM=0/1 forces it.
+#ifndef SS_DECONV_XCD
+#define SS_DECONV_XCD 0           // 1: every XCD walks a contiguous eighth of the units (see the kernel's last lines)
+#endif
 #ifndef SS_DECONV_SKIP_AUX
 #define SS_DECONV_SKIP_AUX 0      // ... of the skip tensor's loads
 #endif
@@ -550,7 +553,18 @@ __global__ __launch_bounds__(256, (SPLIT && !ACCB) ? 3 : 2) void deconv3d_bf16s(
     // unit's stores drain under the next one's loads -- was built and measured in r05: the loop costs 65 spilled registers at the
     // 256 of two workgroups per CU, 129 -> 177 us on hourglass2.conv6, and with the spills equalised persistence itself bought
     // 4 %: profiles/r05_e_deconv_persist.txt.)
+#if SS_DECONV_XCD
+    // XCD-aware unit order (r06): workgroups are dispatched round-robin over the 8 XCDs, so with unit = blockIdx.x a tile and its
+    // neighbours in h (4 indices away) and d never share an L2 and every halo row / plane is fetched from the fabric again (PMC r05:
+    // 537 MB for 453 algorithmic on hourglass2.conv6, the layer that runs at the copy rate of the bytes it moves).  Here XCD k walks
+    // the contiguous k-th eighth of the units: a bijection of [0, nunits) (XCD x gets nunits / 8 units, the first nunits % 8 XCDs one more).
+    const int unit = [&]() {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, q = nunits >> 3, r = nunits & 7;
+        return x * q + min(x, r) + j;
+    }();
+#else
     const int unit = blockIdx.x;
+#endif
     unit_origin(unit, iw0, ih0, id0);
     if constexpr (!SPLIT) {
         body(std::integral_constant<int, -1>{}, unit);
