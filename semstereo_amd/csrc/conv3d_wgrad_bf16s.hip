@@ -12,7 +12,11 @@
 // lo bf16 terms, six cross products, fp32 accumulation (error below the exact-fp32 MFMA's; bf16 has fp32's exponent range, so
 // gradients of any magnitude need no scaling).
 //
-// One WAVE is one unit of work, nothing is shared between waves (no barrier in the kernel): a (32 co x 32 ci) tile pair, ONE
+// Three kernels share that arithmetic (ss_conv3d_wgrad_bf16s_fwd picks): `conv3d_wgrad_bf16s_coop` for stride 1 (nine waves walk down a
+// column of chunks and share what they stage: the form every big layer runs, further down), `conv3d_wgrad_bf16s<S>` below for stride 2 and
+// the transposed convs' weights (and for stride 1 under SS_WGRAD_COOP=0), `conv3d_wgrad_head_bf16s` for a single output channel.
+//
+// conv3d_wgrad_bf16s<S>: one WAVE is one unit of work, nothing is shared between waves (no barrier in the kernel): a (32 co x 32 ci) tile pair, ONE
 // kernel row (kd, kh) (3 taps = 3 accumulator tiles: 48 registers, so three waves share a SIMD and one's staging hides under the
 // others' MFMAs -- all 9 taps of a depth plane in one wave need 144 and spilled) and a contiguous range of 32-position chunks of
 // output rows.  Per chunk:
