@@ -457,163 +457,6 @@ __global__ __launch_bounds__(576, 1) void conv3d_wgrad_bf16s_coop(const float* _
         for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
 }
 
-// ---- the cooperative form for stride 2 (and the transposed convs' weights).  Step oh needs the input rows 2 oh - 1, 2 oh, 2 oh + 1
-// of each depth plane, so TWO new rows per plane and step and a ring of FIVE tiles (a wave still multiplying step t - 1 reads rows
-// 2t - 3 ... 2t - 1 while rows 2t, 2t + 1 are written: five consecutive rows, distinct modulo 5).  To fit 15 tiles + the gout buffers
-// in 160 KB a chunk is 16 output positions (one K-step): even / odd input columns [16] / [8 pad | 16] bf16 per (term, ci), row stride 48
-// bytes.  (At batch 4 the per-wave stride-2 kernel was 9 % of the training step: 0.70 ms per call.)
-constexpr int C2_CW = 16, C2_RS = 48, C2_RING = 5;
-constexpr int C2_PLANE = 32 * C2_RS;                      // bytes per (row kind, term)
-constexpr int C2_TILE = 6 * C2_PLANE;                     // E x 3 terms, O x 3 terms
-constexpr int C2_ATILE = 3 * 32 * C2_RS;
-constexpr int C2_LDS = 3 * C2_RING * C2_TILE + 2 * C2_ATILE;      // 147 456 bytes
-
-__global__ __launch_bounds__(576, 1) void conv3d_wgrad_bf16s_coop2(const float* __restrict__ gout, const float* __restrict__ in,
-                                                                    float* __restrict__ ws, int Cin, int Cout, int D, int H, int W, int Do,
-                                                                    int Ho, int Wo, int chunks_per_row, int seg_len, int nseg, int ci_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int kd = wave / 3, kh = wave - 3 * kd;
-    const int col = blockIdx.x / nseg, seg = blockIdx.x - col * nseg;
-    const int od = col / chunks_per_row, w0 = (col - od * chunks_per_row) * C2_CW;
-    const int oh0 = seg * seg_len, oh1 = min(oh0 + seg_len, Ho);
-    const int co0 = (blockIdx.y / ci_tiles) * 32, ci0 = (blockIdx.y % ci_tiles) * 32;
-    const int b = blockIdx.z;
-    const int id = 2 * od + kd - 1;
-    const bool plane_ok = (unsigned)id < (unsigned)D;
-    unsigned char* ring = lds_raw + kd * (C2_RING * C2_TILE);
-    unsigned char* abuf = lds_raw + 3 * C2_RING * C2_TILE;
-
-    const long long ochan = (long long)Do * Ho * Wo, ichan = (long long)D * H * W;
-    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(gout + (long long)b * Cout * ochan), 0, (int)min((long long)Cout * ochan * 4, 0x7fffffffLL), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(in + (long long)b * Cin * ichan), 0, (int)min((long long)Cin * ichan * 4, 0x7fffffffLL), 0x00020000);
-    const int q = lane & 7, csub = lane >> 3;              // staging: lane = (position pair q, channel 8 i + csub)
-    // this wave's share of the staging: items [it0, it1) of its plane's two new rows (item = row select * 4 + channel iteration; the halo
-    // column of both rows: kh == 2), iteration `wave` of the gout chunk (waves 0-3)
-    const int it0 = 3 * kh, it1 = min(3 * kh + 3, 8);
-    const int iw0 = 2 * (w0 + 2 * q);                       // first of this lane's four input columns
-
-    f32x16 acc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    float rin[12], rhalo = 0.f, ra[2] = {0.f, 0.f};
-    auto row_needed = [&](int ih) { return plane_ok && (unsigned)ih < (unsigned)H && ih <= 2 * (oh1 - 1) + 1; };
-    auto issue = [&](int t) {                               // the loads of step t: input rows 2t, 2t + 1 (this wave's share), gout row t
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int item = it0 + k, ih = 2 * t + (item >> 2), i = item & 3;
-            const bool ok = item < it1 && row_needed(ih);
-            const int c = ci0 + 8 * i + csub;
-            const unsigned ch = (ok && c < Cin) ? (unsigned)(c * ichan * 4) : 0x80000000u;
-            const unsigned row_b = (unsigned)((((long long)id * H + ih) * W) * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                rin[k * 4 + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(ch + (unsigned)((iw0 + e) * 4)), (int)row_b, 0));
-        }
-        {   // halo: column 2 w0 - 1 of channel l31, row 2t (lanes 0-31) / 2t + 1 (lanes 32-63)
-            const int ih = 2 * t + half, hw = 2 * w0 - 1;
-            const bool hok = kh == 2 && row_needed(ih) && (ci0 + l31 < Cin) && hw >= 0;
-            const unsigned row_b = (unsigned)((((long long)id * H + ih) * W) * 4);
-            rhalo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                  ires, (int)(hok ? (unsigned)((ci0 + l31) * ichan * 4) + (unsigned)(hw * 4) : 0x80000000u), (int)row_b, 0));
-        }
-        const bool a_ok = wave < 4 && t >= oh0 && t < oh1;
-        const int ca = co0 + 8 * wave + csub;
-        const unsigned cha = (a_ok && ca < Cout) ? (unsigned)(ca * ochan * 4) : 0x80000000u;
-        const unsigned arow_b = (unsigned)((((long long)od * Ho + max(t, 0)) * Wo) * 4);
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            ra[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gres, (int)(cha + (unsigned)((w0 + 2 * q + e) * 4)), (int)arow_b, 0));
-    };
-    auto stage = [&](int t) {                               // write what `issue(t)` loaded
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int item = it0 + k, ih = 2 * t + (item >> 2), i = item & 3;
-            if (item < it1 && row_needed(ih)) {              // (wave-uniform)
-                unsigned char* tile = ring + ((ih + 10) % C2_RING) * C2_TILE;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (iw0 + e < W) ? rin[k * 4 + e] : 0.f;
-                unsigned h, m, l;
-                unsigned char* p = tile + (8 * i + csub) * C2_RS + 4 * q;
-                split3_pk_w(v[0], v[2], h, m, l);          // even columns E[j], E[j + 1]
-                *reinterpret_cast<unsigned*>(p) = h;
-                *reinterpret_cast<unsigned*>(p + C2_PLANE) = m;
-                *reinterpret_cast<unsigned*>(p + 2 * C2_PLANE) = l;
-                split3_pk_w(v[1], v[3], h, m, l);          // odd columns O[j], O[j + 1]
-                p += 3 * C2_PLANE + 16;
-                *reinterpret_cast<unsigned*>(p) = h;
-                *reinterpret_cast<unsigned*>(p + C2_PLANE) = m;
-                *reinterpret_cast<unsigned*>(p + 2 * C2_PLANE) = l;
-            }
-        }
-        if (kh == 2) {
-            const int ih = 2 * t + half;                     // (per lane half: both rows' halo elements in one pass)
-            if (row_needed(ih)) {
-                unsigned h, m, l;
-                split3_pk_w(rhalo, 0.f, h, m, l);
-                unsigned char* p = ring + ((ih + 10) % C2_RING) * C2_TILE + 3 * C2_PLANE + l31 * C2_RS + 14;      // element 7 of the odd row
-                *reinterpret_cast<unsigned short*>(p) = (unsigned short)h;
-                *reinterpret_cast<unsigned short*>(p + C2_PLANE) = (unsigned short)m;
-                *reinterpret_cast<unsigned short*>(p + 2 * C2_PLANE) = (unsigned short)l;
-            }
-        }
-        if (wave < 4 && t >= oh0 && t < oh1) {
-            const float v0 = (w0 + 2 * q < Wo) ? ra[0] : 0.f, v1 = (w0 + 2 * q + 1 < Wo) ? ra[1] : 0.f;
-            unsigned h, m, l;
-            split3_pk_w(v0, v1, h, m, l);
-            unsigned char* p = abuf + (t & 1) * C2_ATILE + (8 * wave + csub) * C2_RS + 4 * q;
-            *reinterpret_cast<unsigned*>(p) = h;
-            *reinterpret_cast<unsigned*>(p + 32 * C2_RS) = m;
-            *reinterpret_cast<unsigned*>(p + 64 * C2_RS) = l;
-        }
-    };
-
-    // pseudo-step oh0 - 1 only stages (row 2 oh0 - 1); steps oh0 ... oh1 - 1 stage rows 2t, 2t + 1 and multiply
-    issue(oh0 - 1);
-    for (int t = oh0 - 1; t < oh1; ++t) {
-        stage(t);
-        __syncthreads();
-        if (t + 1 < oh1) issue(t + 1);
-        const int ih = 2 * t + kh - 1;
-        if (t >= oh0 && plane_ok && (unsigned)ih < (unsigned)H) {          // (wave-uniform)
-            const unsigned char* tile = ring + ((ih + 10) % C2_RING) * C2_TILE;
-            const unsigned char* at = abuf + (t & 1) * C2_ATILE;
-            uint4 af[3], bfr[3][3];
-            const int offa = l31 * C2_RS + 16 * half, offe = l31 * C2_RS + 16 * half, offo = 3 * C2_PLANE + l31 * C2_RS + 16 * (1 + half);
-#pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
-                af[tm] = *reinterpret_cast<const uint4*>(at + tm * 32 * C2_RS + offa);
-                const uint4 xe = *reinterpret_cast<const uint4*>(tile + tm * C2_PLANE + offe);
-                const uint4 xo = *reinterpret_cast<const uint4*>(tile + tm * C2_PLANE + offo);
-                const unsigned pl = *reinterpret_cast<const unsigned*>(tile + tm * C2_PLANE + offo - 4);
-                bfr[0][tm] = make_uint4(__builtin_amdgcn_alignbit(xo.x, pl, 16), __builtin_amdgcn_alignbit(xo.y, xo.x, 16),
-                                        __builtin_amdgcn_alignbit(xo.z, xo.y, 16), __builtin_amdgcn_alignbit(xo.w, xo.z, 16));
-                bfr[1][tm] = xe;
-                bfr[2][tm] = xo;
-            }
-            constexpr int pa[6] = {1, 0, 2, 0, 1, 0}, pb[6] = {1, 2, 0, 1, 0, 0};
-#pragma unroll
-            for (int p = 0; p < 6; ++p)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[pa[p]]), __builtin_bit_cast(bf16x8, bfr[kw][pb[p]]),
-                                                                      acc[kw], 0, 0, 0);
-        }
-    }
-    float* wt = ws + ((long long)blockIdx.y * 27 + kd * 9 + kh * 3) * 1024 + lane;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
-}
-
 // ---- a single output channel (the classifiers' 32 -> 1 heads, models/SemStereo.py:228-234): dW[ci, tap] = sum_p' x[ci, p'] * g[p' - tap + 1].
 // With Cout = 1 the tile forms above spend 27 accumulator tiles on one live matrix row each (the head's weight gradient cost what a
 // 32 -> 32 layer's costs, 0.48 ms at [24,256,256]).  Here the 27 TAPS are the MFMA's N columns: A = x (lane = input channel, 8
@@ -774,17 +617,6 @@ extern "C" int ss_conv3d_wgrad_bf16s_fwd(const float* grad_out, const float* in,
         if (cols * nseg_c > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(kern, dim3((unsigned)(cols * nseg_c), tiles, B), dim3(576), CO_LDS, st, grad_out, in, workspace, Cin, Cout, D, H, W,
                            chunks_per_row, seg_len, nseg_c, ci_tiles);
-    } else if (stride == 2 && ss::tuning().wgrad_coop != 0) {
-        auto kern = conv3d_wgrad_bf16s_coop2;
-        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), C2_LDS) != SS_OK) return SS_ERR_LAUNCH;
-        const int cpr = ss::ceil_div(Wo, C2_CW);
-        const long long cols = (long long)Do * cpr;
-        int nseg_c = (int)std::min<long long>(std::max<long long>(1, 768 / std::max<long long>(1, cols * tiles * B)), std::max(1, Ho / 8));
-        const int seg_len = ss::ceil_div(Ho, nseg_c);
-        nseg_c = ss::ceil_div(Ho, seg_len);
-        if (cols * nseg_c > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(cols * nseg_c), tiles, B), dim3(576), C2_LDS, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo,
-                           cpr, seg_len, nseg_c, ci_tiles);
     } else if (stride == 1) {
         auto kern = conv3d_wgrad_bf16s<1>;
         hipLaunchKernelGGL(kern, grid, dim3(192), 3 * WG<1>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
