@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--maxdisp", type=int, default=64)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam's default (foreach) implementation instead of fused=True")
     ap.add_argument("--no-checks", action="store_true", help="skip the determinism / eval-comparison passes (profiling runs)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_train.json"))
