@@ -1796,6 +1796,9 @@ CONV_TRAIN_CASES = [
     (1, 32, 32, 5, 21, 150, 1),         # r06: rows of several 32-position chunks, ragged last chunk (the bf16 weight-gradient kernel's K loop)
     (2, 32, 64, 6, 22, 138, 2),         # ... stride 2 (even / odd column rows), batch 2
     (1, 8, 1, 3, 9, 70, 1),             # ... a single output channel (the classifiers' heads run this kernel too)
+    (1, 32, 32, 4, 64, 256, 1),         # the rows of the 1024^2 pair (W/4 = 256: eight chunks per row, columns cut into segments)
+    (1, 64, 32, 3, 32, 512, 1),         # ... of the 2048^2 pair, two input-channel tiles
+    (1, 32, 64, 4, 64, 256, 2),         # ... stride 2 on 256-wide rows
 ]
 
 
