@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (13 since round 6; 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (14 since round 6 (13 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -330,6 +330,12 @@ int ss_pack_classifier_head_weights(const float* w2, void* out, ss_stream_t stre
 int ss_conv3d_classifier_fused_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                                    const void* head_w, float* patches, float* out, int B, int Cin, int D, int H, int W,
                                    int nterms, ss_stream_t stream);
+/* regression_topk(cost.squeeze(1), samples, 2) (models/SemStereo.py:322-323, models/submodule.py:434-442) reading the patches of
+ * ss_conv3d_classifier_fused_fwd directly (call that with out = NULL: no patch-sum launch, no [B,1,nd,H,W] cost tensor): patches
+ * [B][tiles][1224], samples [B,nd,H,W] -> out [B,1,H,W], bit-identical to the two-launch form.  nd = 24 and k = 2 (the model's);
+ * anything else returns SS_ERR_UNSUPPORTED. */
+int ss_regression_topk_patched_fwd(const float* patches, const float* samples, float* out, int B, int nd, int H, int W, int k,
+                                   ss_stream_t stream);
 /* 1x1x1 Conv3d / per-position Linear (+ per-channel affine: bias; ReLU) on the split-bf16 engine:
  * qkv_3d and final1x1 of attention_block (models/submodule_other.py:804, 835).
  *   out [B,Cout,npos] = relu?(scale * (W in) + shift), in [B,Cin,npos], npos = D*H*W, W [Cout,Cin];

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -59,6 +59,7 @@ _SIGNATURES = {
     "ss_conv3d_bf16s_cl_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_pack_classifier_head_weights": [_P, _P, _P],
     "ss_conv3d_classifier_fused_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ss_regression_topk_patched_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_pack_conv3d_head_weights_bf16s": [_P, _P, _I, _P],
     "ss_pack_conv3d_head_weights_f16s": [_P, _P, _I, _P],
     "ss_conv3d_pointwise_bf16s_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_longlong, _I, _I, _P],

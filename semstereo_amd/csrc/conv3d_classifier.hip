@@ -62,6 +62,57 @@ __global__ __launch_bounds__(256) void classifier_patch_sum_kernel(const float* 
     out[(((size_t)b * D + d) * H + h) * W + w] = v;
 }
 
+// ---- the patch sum folded into the head's CONSUMER (r06): regression_topk(cost.squeeze(1), samples, 2) of models/SemStereo.py:322-323
+// (models/submodule.py:434-442) reading the tiles' patches directly -- the ND costs of a pixel are summed from their <= 8 patches each in
+// the order of classifier_patch_sum_kernel (same bits), kept in registers, and the top-2 soft-argmax of topk_regress_kernel<2>
+// (regression.hip: value descending, index ascending; the same separately rounded products) follows: one launch and the [B,1,D,H,W]
+// cost tensor fewer.  grid (ceil(W / 256), H, B): plane and row candidates are scalar arithmetic, a lane owns one column.
+template <int ND>
+__global__ __launch_bounds__(256) void topk2_regress_patched_kernel(const float* __restrict__ patches, const float* __restrict__ samples,
+                                                                     float* __restrict__ out, int H, int W, int tiles_w, int tiles_h) {
+    constexpr int tiles_d = ND / 4;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (w >= W) return;
+    const float* pb = patches + (size_t)b * tiles_w * tiles_h * tiles_d * HEAD_PATCH;
+    int th[2], ph[2], tw[2], pw[2];
+    const int nh = patch_candidates(h, 4, tiles_h, th, ph), nw = patch_candidates(w, 32, tiles_w, tw, pw);
+    float cost[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        int td[2], pd[2];
+        const int nd = patch_candidates(d, 4, tiles_d, td, pd);
+        float v = 0.f;
+        for (int a = 0; a < nd; ++a)
+            for (int c = 0; c < nh; ++c) {
+                const float* row = pb + (size_t)((td[a] * tiles_h + th[c]) * tiles_w) * HEAD_PATCH + (pd[a] * 6 + ph[c]) * 34;
+                for (int e = 0; e < nw; ++e) v = ss::add_rn(v, row[tw[e] * HEAD_PATCH + pw[e]]);
+            }
+        cost[d] = v;
+    }
+    // the two largest costs in the order (value descending, index ascending)
+    float v0 = cost[0]; int i0 = 0;
+#pragma unroll
+    for (int d = 1; d < ND; ++d)
+        if (cost[d] > v0) { v0 = cost[d]; i0 = d; }
+    float v1 = -INFINITY; int i1 = INT_MAX;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const float v = cost[d];
+        const bool after = (v < v0) || (v == v0 && d > i0);
+        const bool beats = (v > v1) || (v == v1 && d < i1);
+        if (after && beats) { v1 = v; i1 = d; }
+    }
+    if (i1 == INT_MAX) i1 = 0;
+    const size_t plane = (size_t)H * W, pix = (size_t)h * W + w;
+    const float* sp = samples + (size_t)b * ND * plane + pix;
+    const float e0 = expf(v0 - v0), e1 = expf(v1 - v0);
+    const float sum = ss::add_rn(ss::add_rn(0.f, e0), e1);
+    float acc = ss::add_rn(0.f, ss::mul_rn(sp[(size_t)i0 * plane], e0 / sum));
+    acc = ss::add_rn(acc, ss::mul_rn(sp[(size_t)i1 * plane], e1 / sum));
+    out[(size_t)b * plane + pix] = acc;
+}
+
 }  // namespace
 
 extern "C" int ss_pack_classifier_head_weights(const float* w2, void* out, ss_stream_t stream) {
@@ -74,7 +125,7 @@ extern "C" int ss_pack_classifier_head_weights(const float* w2, void* out, ss_st
 extern "C" int ss_conv3d_classifier_fused_fwd(const float* in, const void* wsplit, const float* scale, const float* shift,
                                               const void* head_w, float* patches, float* out, int B, int Cin, int D, int H, int W,
                                               int nterms, ss_stream_t stream) {
-    SS_REQUIRE(in && wsplit && head_w && patches && out);
+    SS_REQUIRE(in && wsplit && head_w && patches);          // out == NULL: the patches only (ss_regression_topk_patched_fwd reads them)
     SS_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0);
     SS_REQUIRE((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0 && (reinterpret_cast<uintptr_t>(head_w) & 15) == 0);
     if (nterms != F16X3 || D % 4 != 0) return SS_ERR_UNSUPPORTED;
@@ -87,9 +138,22 @@ extern "C" int ss_conv3d_classifier_fused_fwd(const float* in, const void* wspli
     hipStream_t st = ss::as_stream(stream);
     const int rc = launch_bgm<1, 4, 4, 4, F16X3, false, 1, 3, 1, false, false, true>(
         in, wsplit, scale, shift, nullptr, nullptr, patches, B, Cin, D, H, W, 32, 1, st, reinterpret_cast<const float*>(head_w));
-    if (rc != SS_OK) return rc;
+    if (rc != SS_OK || out == nullptr) return rc;
     const int tiles_w = ss::ceil_div(W, 32), tiles_h = ss::ceil_div(H, 4), tiles_d = D / 4;
     hipLaunchKernelGGL(classifier_patch_sum_kernel, dim3(ss::ceil_div(W, 256), H, B * D), dim3(256), 0, st, patches, out, D, H, W, tiles_w,
                        tiles_h, tiles_d);
+    return ss::check_launch();
+}
+
+// regression_topk(cost, samples, 2) (models/submodule.py:434-442) on the PATCHES of ss_conv3d_classifier_fused_fwd(out = NULL): patches
+// [B][tiles][6*6*34] of a [B,1,nd,H,W] cost, samples [B,nd,H,W] -> out [B,1,H,W]; bit-identical to the patch sum followed by
+// ss_regression_topk_fwd.  Built for the model's nd = 24 candidates and k = 2 (anything else: SS_ERR_UNSUPPORTED, take the two launches).
+extern "C" int ss_regression_topk_patched_fwd(const float* patches, const float* samples, float* out, int B, int nd, int H, int W, int k,
+                                              ss_stream_t stream) {
+    SS_REQUIRE(patches && samples && out);
+    SS_REQUIRE(B > 0 && nd > 0 && H > 0 && W > 0);
+    if (nd != 24 || k != 2 || H > 65535 || B > 65535) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(topk2_regress_patched_kernel<24>, dim3(ss::ceil_div(W, 256), H, B), dim3(256), 0, ss::as_stream(stream), patches, samples,
+                       out, H, W, ss::ceil_div(W, 32), ss::ceil_div(H, 4));
     return ss::check_launch();
 }

@@ -341,7 +341,21 @@ def pack_classifier_head_weight(w2):
     return out
 
 
-def classifier_fused_hip(x, ws0, scale0, shift0, nterms0, head_w):
+class PatchedCost:
+    """What a one-pass classifier leaves when its patch sum is folded into the consumer (r06): the tiles' patches of a [B,1,D,H,W] cost."""
+
+    def __init__(self, patches, shape):
+        self.patches, self.shape = patches, tuple(shape)        # shape = (B, D, H, W)
+
+
+#: SS_CLASSIFIER_FOLD=1 (r06, VERDICT r5 #3): `classif` hands its patches straight to the top-2 soft-argmax that follows it
+#: (models/SemStereo.py:322-323: ss_regression_topk_patched_fwd) -- no patch-sum launch, no cost tensor.  Bit-identical, one launch fewer, and
+#: SLOWER: the folded kernel gathers 2.4 patch values per cost in a latency-bound launch -- 571.6 / 571.5 / 570.6 -> 566.9 / 566.2 / 567.0
+#: pairs/s on one stream, 613.5 / 615.1 / 614.7 -> 613.5 / 613.3 / 614.0 pipelined (profiles/r06_z_ab_classifier_fold.txt).  Off.
+CLASSIFIER_FOLD = os.environ.get("SS_CLASSIFIER_FOLD", "0") != "0"
+
+
+def classifier_fused_hip(x, ws0, scale0, shift0, nterms0, head_w, sum_patches=True):
     """nn.Sequential(convbn_3d(C,32,3,1,1), ReLU, Conv3d(32,1,3,p1)) (models/SemStereo.py:228-234) in one pass over the volume: the
     32-channel intermediate stays in the accumulators, each tile writes a 6 x 6 x 34 patch of head outputs, a second small launch
     adds the patches (conv3d_classifier.hip)."""
@@ -350,11 +364,11 @@ def classifier_fused_hip(x, ws0, scale0, shift0, nterms0, head_w):
     B, C, D, H, W = x.shape
     ntiles = ((W + 31) // 32) * ((H + 3) // 4) * (D // 4)
     patches = torch.empty((B, ntiles, 6 * 6 * 34), dtype=x.dtype, device=x.device)
-    out = torch.empty((B, 1, D, H, W), dtype=x.dtype, device=x.device)
+    out = torch.empty((B, 1, D, H, W), dtype=x.dtype, device=x.device) if sum_patches else None
     with torch.cuda.device(dev):
         call("ss_conv3d_classifier_fused_fwd", ptr(x), ptr(ws0), ptr(scale0), ptr(shift0), ptr(head_w), ptr(patches), ptr(out),
              B, C, D, H, W, int(nterms0))
-    return out
+    return out if sum_patches else PatchedCost(patches, (B, D, H, W))
 
 
 def pack_conv2d_weight_bf16s(w, nterms=6):
@@ -690,5 +704,5 @@ def stem_of_broadcast_and_volume(stem, left, att, right_vol, gate=None):
 ATTENTION_FORM = os.environ.get("SS_ATTENTION", "split")      # "split" (3 launches) | "fused" (one kernel per window)
 
 #: the names tests / tools may SET on this module; `modules.X` forwards reads of them here
-SWITCHES = ("CONV_ENGINE", "DECONV_F16", "DECONV_MIN_WORKGROUPS", "DECONV_BF16S", "CLASSIFIER_CL", "CLASSIFIER_FUSED", "TRAIN_HIP", "ATTENTION_FORM",
+SWITCHES = ("CONV_ENGINE", "DECONV_F16", "DECONV_MIN_WORKGROUPS", "DECONV_BF16S", "CLASSIFIER_CL", "CLASSIFIER_FUSED", "CLASSIFIER_FOLD", "TRAIN_HIP", "ATTENTION_FORM",
             "STEM_LEFT_FUSED", "STEM_PRESPLIT", "STEM_GATHER", "STEM_INPLACE", "HEAD_F16", "CONV2D_HIP")

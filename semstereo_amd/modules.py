@@ -402,6 +402,25 @@ class Classifier(nn.Sequential):
         self.train(ref.training)
         return self
 
+    def patches(self, x):
+        """The one-pass form WITHOUT its patch sum (engine.PatchedCost, for ops.regression_topk_patched), or None where that form does
+        not serve this input / engine / switch setting -- the caller then takes forward()."""
+        x = dfr.real(x)
+        c0, bn0, c2 = self[0][0], self[0][1], self[2]
+        if not (_inference(self, x) and E.CLASSIFIER_FOLD and E.CLASSIFIER_FUSED and E.CLASSIFIER_CL and E.CONV_ENGINE != "f32"
+                and c0.in_channels == c0.out_channels == c2.in_channels == 32 and _conv_geometry(c0) == (3, 1)
+                and _conv_geometry(c2) == (3, 1) and c2.out_channels == 1 and classifier_fused_applies(x, _tiled_nterms())):
+            return None
+        nt0 = _tiled_nterms()
+
+        def build_fused():
+            sc, sh = fold_bn(bn0)
+            return pack_conv_weight_bf16s(c0.weight, nt0), sc, sh, pack_classifier_head_weight(c2.weight)
+        srcs = [c0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, c2.weight]
+        ws0, sc, sh, hw = _cache(self).get("fused/%d" % nt0, srcs, build_fused)
+        PATH_COUNTS["hip"] += 1
+        return classifier_fused_hip(x, ws0, sc, sh, nt0, hw, sum_patches=False)
+
     def forward(self, x):
         x = dfr.real(x)
         if dfr.on(self, x):

@@ -361,6 +361,19 @@ def regression_topk(cost, disparity_samples, k):
     return _RegressionTopk.apply(cost, disparity_samples, k)
 
 
+def regression_topk_patched(pc, disparity_samples, k):
+    """regression_topk(cost.squeeze(1), samples, k) where the cost is still the patches of a one-pass classifier (engine.PatchedCost:
+    ss_regression_topk_patched_fwd, r06) -- bit-identical to summing the patches first.  Inference only; k = 2, 24 candidates."""
+    samples = _c(dfr.real(disparity_samples))
+    B, D, H, W = pc.shape
+    assert samples.shape == (B, D, H, W) and int(k) == 2 and D == 24
+    dev = _lib.require_device(pc.patches, samples)
+    out = torch.empty((B, 1, H, W), dtype=samples.dtype, device=samples.device)
+    with torch.cuda.device(dev):
+        call("ss_regression_topk_patched_fwd", ptr(pc.patches), ptr(samples), ptr(out), B, D, H, W, int(k))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # candidate warping
 # --------------------------------------------------------------------------------------

@@ -286,6 +286,10 @@ class HotSegment(nn.Module):
             volume = self.concat_stem(volume)                                                  # :319
             volume = self.concat_feature_att_4(volume, fl4)                                    # :320
         cost = self.hourglass(volume)                                                          # :321
+        if fast and samples.shape[1] == 24 and isinstance(self.classif, M.Classifier):
+            pc = self.classif.patches(cost)              # :322-323 in two launches instead of three: the one-pass classifier's patches
+            if pc is not None:                           # are summed by the soft-argmax that reads them (r06)
+                return ops.regression_topk_patched(pc, samples, 2)
         cost = self.classif(cost)                                                              # :322
         return ops.regression_topk(cost.squeeze(1), samples, 2)                                # :323
 

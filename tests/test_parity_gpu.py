@@ -832,6 +832,35 @@ def _det_classifier(sa, seed=900):
     return m
 
 
+@pytest.mark.parametrize("shape", [(1, 24, 128, 96), (2, 24, 64, 256)])
+def test_classifier_patch_sum_folded_into_the_soft_argmax_is_bit_identical(sa, shape, monkeypatch):
+    """VERDICT r5 #3 (the part built; off by default, it measured slower): `classif` -> regression_topk (models/SemStereo.py:322-323) with
+    the one-pass classifier's patch sum inside the top-2 soft-argmax (ss_regression_topk_patched_fwd, SS_CLASSIFIER_FOLD=1) against the
+    three-launch form: the same bits."""
+    if sa.modules.CONV_ENGINE != "f16x3":
+        pytest.skip("the one-pass classifier exists for the f16x3 engine")
+    monkeypatch.setattr(sa.engine, "CLASSIFIER_FOLD", True)
+    from oracle import detdata as dd
+    B, D, H, W = shape
+    cl = sa.modules.Classifier(32).cuda().eval()
+    with torch.no_grad():
+        for i, t in enumerate(list(cl.parameters()) + list(cl.buffers())):
+            if t.dtype.is_floating_point:
+                t.copy_(dev(dd.t_uniform(tuple(t.shape), 470 + i, 0.5, 1.5) if t.dim() == 1 else dd.t_uniform(tuple(t.shape), 470 + i, -0.06, 0.06)))
+    x = dev(torch.relu(dd.t_normalish((B, 32, D, H, W), 480)))
+    samples = dev(dd.distinct_sorted_candidates(B, D, H, W, 32, 481))
+    with torch.no_grad():
+        pc = cl.patches(x)
+        assert pc is not None, "the one-pass form does not serve this shape"
+        folded = sa.ops.regression_topk_patched(pc, samples, 2)
+        plain = sa.ops.regression_topk(cl(x).squeeze(1), samples, 2)
+    assert folded.shape == plain.shape == (B, 1, H, W) and torch.equal(folded, plain)
+    # ... and exact ties between costs resolve to the lower candidate index in both forms (a zero input: every cost is the same number)
+    with torch.no_grad():
+        z = torch.zeros_like(x)
+        assert torch.equal(sa.ops.regression_topk_patched(cl.patches(z), samples, 2), sa.ops.regression_topk(cl(z).squeeze(1), samples, 2))
+
+
 @pytest.mark.parametrize("shape", [(1, 12, 134, 200), (2, 8, 140, 250), (1, 4, 300, 260), (1, 32, 128, 128)])
 def test_classifier_one_pass_form_against_the_two_launch_form_and_float64(sa, shape, monkeypatch):
     """`classif` / `classif_att_` (models/SemStereo.py:228-234) in ONE pass over the volume (ss_conv3d_classifier_fused_fwd: the
