@@ -134,7 +134,10 @@ constexpr int SSB_NW = 8;
 // (pixel, channel) instead of ~12.  Taps in another row (the south taps where the row coordinate is not exact) or beyond the
 // margin go to memory directly, as before.
 constexpr int SSB_M = 64, SSB_RB = 64 + 2 * SSB_M + 2;
-__global__ __launch_bounds__(64 * SSB_NW) void sample_strength_bwd_kernel(const float* __restrict__ left, const float* __restrict__ right,
+// (four waves per SIMD -- 128 registers, 212 bytes of scratch per lane -- instead of the 176 registers the compiler takes when left alone:
+// the kernel waits for memory and LDS 80 % of its life (SQ counters, r06), and two waves per SIMD did not cover that: 664 -> 586 us alone;
+// unrolling the channel loops to put more gathers in flight spilled further and lost: 828 us)
+__global__ __launch_bounds__(64 * SSB_NW, 4) void sample_strength_bwd_kernel(const float* __restrict__ left, const float* __restrict__ right,
                                                                    const float* __restrict__ pred0, const float* __restrict__ var,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    const float* __restrict__ g_strength, float* __restrict__ g_left,

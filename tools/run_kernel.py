@@ -160,6 +160,25 @@ elif name in ("conv_s2", "conv_s1", "deconv"):
         sc, sh = torch.rand(cout, device=dev) + 0.5, R(cout) * 0.1
         fn = lambda: M.conv3d_bf16s_hip(x, ws, cout, sc, sh, True, 19, stride=stride)       # noqa: E731
         nbytes = 4.0 * B * (32 * 24 * 256 * 256 + cout * (24 // stride) * (256 // stride) ** 2)
+elif name in ("strength_bwd", "warp_bwd"):     # the two scatter kernels of the training step at 1024^2 (quarter resolution 256 x 256)
+    lib = sa._lib
+    if name == "strength_bwd":          # backward of the 5-candidate probe (models/SemStereo.py:286-293): 128-channel features
+        fl, fr = R(B, 128, 256, 256), R(B, 128, 256, 256)
+        yy, xx = torch.meshgrid(torch.arange(256, device=dev), torch.arange(256, device=dev), indexing="ij")
+        p0 = (10.0 * torch.sin(xx / 40.0) * torch.cos(yy / 55.0)).reshape(1, 256, 256).expand(B, 256, 256).contiguous()
+        var, g = torch.rand(B, 1, 256, 256, device=dev), R(B, 5, 256, 256)
+        gm, bt = torch.full((1,), 0.25, device=dev), torch.full((1,), 2.0, device=dev)
+        gl, gr, gp, gv, ggb = torch.empty_like(fl), torch.empty_like(fr), torch.empty_like(p0), torch.empty_like(var), torch.empty(2, device=dev)
+        fn = lambda: lib.call("ss_sample_strength_bwd", lib.ptr(fl), lib.ptr(fr), lib.ptr(p0), lib.ptr(var), lib.ptr(gm), lib.ptr(bt), lib.ptr(g),   # noqa: E731
+                              lib.ptr(gl), lib.ptr(gr), lib.ptr(gp), lib.ptr(gv), lib.ptr(ggb), B, 128, 256, 256)
+        nbytes = 4.0 * B * (4 * 128 + 8) * 256 * 256
+    else:                               # backward of SpatialTransformer_grid at :316 (32 channels, 24 integer candidates)
+        y = R(B, 32, 256, 256)
+        smp = torch.rand(B, 64, 256, 256, device=dev).argsort(dim=1)[:, :24].sort(dim=1).values.float() - 32.0
+        g = R(B, 32, 24, 256, 256)
+        gy = torch.empty_like(y)
+        fn = lambda: lib.call("ss_warp_sampled_bwd", lib.ptr(g), None, lib.ptr(y), lib.ptr(smp), None, lib.ptr(gy), None, B, 32, 256, 256, 24)   # noqa: E731
+        nbytes = 4.0 * B * (32 * 24 + 24 + 32) * 256 * 256
 elif name.startswith("wgrad"):   # weight gradients of the training step (1024^2 / md64): wgrad = classif.0 (32 -> 32 at [24,256,256]), wgrad_stem = concat_stem (64 -> 32),
     # wgrad_mid = hourglass2.conv2 (64 -> 64 at [12,128,128]), wgrad_low = conv4 (128 -> 128 at [6,64,64]), wgrad_s2 = conv1 (32 -> 64, stride 2), wgrad_head (32 -> 1)
     from semstereo_amd import train_layers as TL
