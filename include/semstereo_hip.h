@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (14 since round 6 (13 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (15 since round 6 (13, 14 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -479,6 +479,10 @@ int ss_upsample_softmax_regression_bwd(const float* up, const float* grad_up, co
 int ss_sample_strength_bwd(const float* left, const float* right, const float* pred0, const float* var, const float* gamma,
                            const float* beta, const float* grad_strength, float* grad_left, float* grad_right, float* grad_pred0,
                            float* grad_var, float* grad_gamma_beta, int B, int C, int H, int W, ss_stream_t stream);
+/* ... through a scratch `work` of B * 5 * H * W floats: two launches, the channels on the second one's grid (r06: 3x faster at 128 channels) */
+int ss_sample_strength_bwd_ws(const float* left, const float* right, const float* pred0, const float* var, const float* gamma,
+                              const float* beta, const float* grad_strength, float* grad_left, float* grad_right, float* grad_pred0,
+                              float* grad_var, float* grad_gamma_beta, float* work, int B, int C, int H, int W, ss_stream_t stream);
 int ss_topk_candidates_bwd(const float* logits, const float* strength, const float* samples, const float* grad_att_topk,
                            const float* grad_pred_att, float* grad_logits, float* grad_strength, int B, int dmin, int ndisp, int H, int W,
                            int k, ss_stream_t stream);

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -77,6 +77,7 @@ _SIGNATURES = {
     "ss_tool_copy_fwd": [_P, _P, ctypes.c_longlong, _P],
     "ss_upsample_softmax_regression_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_sample_strength_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ss_sample_strength_bwd_ws": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ss_topk_candidates_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ss_batchnorm_train_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, ctypes.c_float, _I, _P],
     "ss_batchnorm_train_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],

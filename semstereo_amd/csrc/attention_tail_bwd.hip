@@ -285,6 +285,167 @@ __global__ __launch_bounds__(64 * SSB_NW, 4) void sample_strength_bwd_kernel(con
     }
 }
 
+// ---- the same backward as TWO launches over a [B,5,H,W] scratch (r06, ss_sample_strength_bwd_ws): (1) the correlation, the soft-max
+// backward and the per-pixel scalars -> dcorr; (2) the feature gradients with the CHANNELS on the grid (one channel per wave, C / 8 times the
+// workgroups of the one-launch kernel above, whose waves walk 16 channels one after the other at two to four waves per SIMD and wait for memory
+// and LDS 80 % of their life: 664 us alone at 1024^2 / 128 channels).
+__global__ __launch_bounds__(64 * SSB_NW) void ssb_dcorr_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                              const float* __restrict__ pred0, const float* __restrict__ var,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ g_strength, float* __restrict__ dcorr_out,
+                                                              float* __restrict__ g_var, float* __restrict__ g_gb, int C, int H, int W,
+                                                              float half_w, float half_h, long long total) {
+    constexpr int NW = SSB_NW;
+    __shared__ float red[NW][5][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    const bool active = i < total;
+    const long long plane = (long long)H * W;
+    const long long ii = active ? i : 0;
+    const int x = (int)(ii % W), y = (int)((ii / W) % H);
+    const long long b = ii / plane, pix = (long long)y * W + x;
+    Taps4 tp[5];
+    long long nbs[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);
+        nbs[t] = b * plane + (long long)yy * W + xx;
+        tp[t] = bilinear_taps(pred0[nbs[t]], y, x, H, W, half_w, half_h);
+    }
+    float corr[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = wave; c < C; c += NW) {
+        const float l = left[(b * C + c) * plane + pix];
+        const float* rp = right + (b * C + c) * plane;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const float a = (tp[t].o_nw >= 0) ? rp[tp[t].o_nw] : 0.f, bq = (tp[t].o_ne >= 0) ? rp[tp[t].o_ne] : 0.f;
+            const float cq = (tp[t].o_sw >= 0) ? rp[tp[t].o_sw] : 0.f, d = (tp[t].o_se >= 0) ? rp[tp[t].o_se] : 0.f;
+            corr[t] += l * (a * tp[t].w_nw + bq * tp[t].w_ne + cq * tp[t].w_sw + d * tp[t].w_se);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) red[wave][t][lane] = corr[t];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w][t][lane];
+        corr[t] = s;
+    }
+    const float g = gamma[0], bt = beta[0];
+    float gate[5], z[5], mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        corr[t] /= (float)C;
+        gate[t] = 1.0f / (1.0f + expf(-(bt + g * var[nbs[t]])));
+        z[t] = corr[t] * gate[t];
+        mx = fmaxf(mx, z[t]);
+    }
+    float sum = 0.f, dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { z[t] = expf(z[t] - mx); sum += z[t]; }
+    float gs[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { z[t] /= sum; gs[t] = g_strength[(b * 5 + t) * plane + pix]; dot += z[t] * gs[t]; }
+    float dgamma = 0.f, dbeta = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const float dz = z[t] * (gs[t] - dot);
+        if (active) {
+            dcorr_out[(b * 5 + t) * plane + pix] = dz * gate[t] / (float)C;
+            const float dv = dz * corr[t] * gate[t] * (1.0f - gate[t]);
+            dbeta += dv;
+            dgamma += dv * var[nbs[t]];
+            if (g_var) unsafeAtomicAdd(&g_var[nbs[t]], dv * g);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { dgamma += __shfl_xor(dgamma, o); dbeta += __shfl_xor(dbeta, o); }
+    if (lane == 0 && g_gb) {
+        unsafeAtomicAdd(&g_gb[0], dgamma);
+        unsafeAtomicAdd(&g_gb[1], dbeta);
+    }
+}
+
+// grid (pixel blocks of 64, ceil(C / 8)): wave w of a workgroup owns channel 8 blockIdx.y + w
+__global__ __launch_bounds__(64 * SSB_NW) void ssb_scatter_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                                const float* __restrict__ pred0, const float* __restrict__ dcorr_in,
+                                                                float* __restrict__ g_left, float* __restrict__ g_right,
+                                                                float* __restrict__ g_pred0, int C, int H, int W, float half_w,
+                                                                float half_h, long long total) {
+    constexpr int NW = SSB_NW;
+    __shared__ float gred[NW][5][64], rowbuf[NW][SSB_RB + 62];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    const bool active = i < total;
+    const long long plane = (long long)H * W;
+    const long long ii = active ? i : 0;
+    const int x = (int)(ii % W), y = (int)((ii / W) % H);
+    const long long b = ii / plane, pix = (long long)y * W + x;
+    const int c = blockIdx.y * NW + wave;
+    const bool cok = c < C;                                  // (wave-uniform)
+    float gix[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool rowblock = (W % 64 == 0) && g_right != nullptr;
+    const int xb = (int)((((long long)blockIdx.x * 64) % W)) - SSB_M;
+    float* rb = rowbuf[wave];
+    if (cok) {
+        if (rowblock) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rb[lane + 64 * k] = 0.f;
+        }
+        const float l = left[(b * C + c) * plane + pix];
+        const float* rp = right + (b * C + c) * plane;
+        float* grp = g_right ? g_right + (b * C + c) * plane : nullptr;
+        float gl = 0.f;
+        auto scatter = [&](int o, int row, int col, float v) {
+            if (o < 0 || v == 0.f || !active) return;
+            const unsigned k = (unsigned)(col - xb);
+            if (rowblock && row == y && k < (unsigned)SSB_RB) ss::lds_add(&rowbuf[wave][k], v);
+            else unsafeAtomicAdd(&grp[o], v);
+        };
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);
+            const Taps4 tp = bilinear_taps(pred0[b * plane + (long long)yy * W + xx], y, x, H, W, half_w, half_h);
+            const float dc = dcorr_in[(b * 5 + t) * plane + pix];
+            const float a = (tp.o_nw >= 0) ? rp[tp.o_nw] : 0.f, bq = (tp.o_ne >= 0) ? rp[tp.o_ne] : 0.f;
+            const float cq = (tp.o_sw >= 0) ? rp[tp.o_sw] : 0.f, d = (tp.o_se >= 0) ? rp[tp.o_se] : 0.f;
+            gl += dc * (a * tp.w_nw + bq * tp.w_ne + cq * tp.w_sw + d * tp.w_se);
+            const float gr = dc * l;
+            if (grp) {
+                if (tp.w_nw != 0.f) scatter(tp.o_nw, tp.iy, tp.ix, gr * tp.w_nw);
+                if (tp.w_ne != 0.f) scatter(tp.o_ne, tp.iy, tp.ix + 1, gr * tp.w_ne);
+                if (tp.w_sw != 0.f) scatter(tp.o_sw, tp.iy + 1, tp.ix, gr * tp.w_sw);
+                if (tp.w_se != 0.f) scatter(tp.o_se, tp.iy + 1, tp.ix + 1, gr * tp.w_se);
+            }
+            gix[t] = gr * ((bq - a) * tp.fs + (d - cq) * tp.fn);
+        }
+        if (g_left && active) g_left[(b * C + c) * plane + pix] = gl;
+        if (rowblock) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k;
+                const float v = rb[idx];
+                if (idx < SSB_RB && v != 0.f) unsafeAtomicAdd(&grp[(long long)y * W + xb + idx], v);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) gred[wave][t][lane] = gix[t];
+    __syncthreads();
+    if (wave == 0 && g_pred0 && active) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += gred[w][t][lane];
+            unsafeAtomicAdd(&g_pred0[b * plane + (long long)yy * W + xx], -((half_w * s) / half_w));
+        }
+    }
+}
+
 // DETERMINISM: the three backward kernels of this file scatter into neighbouring pixels (the 5 replicate-padded taps
 // of Propagation / Propagation_prob, the bilinear taps of the probe) and into per-block partial sums with fp32 hardware atomics
 // (unsafeAtomicAdd), like the backward of SpatialTransformer_grid (warp.hip) and ATen's own grid_sampler / replication_pad
@@ -423,3 +584,27 @@ extern "C" int ss_topk_candidates_bwd(const float* logits, const float* strength
                        grad_att_topk, grad_pred_att, grad_logits, grad_strength, ndisp, H, W, k, dmin, total);
     return ss::check_launch();
 }
+
+// The same backward through a scratch of B * 5 * H * W floats (`work`): two launches with the channels on the second one's grid (r06).
+extern "C" int ss_sample_strength_bwd_ws(const float* left, const float* right, const float* pred0, const float* var, const float* gamma,
+                                         const float* beta, const float* grad_strength, float* grad_left, float* grad_right,
+                                         float* grad_pred0, float* grad_var, float* grad_gamma_beta, float* work, int B, int C, int H, int W,
+                                         ss_stream_t stream) {
+    SS_REQUIRE(left && right && pred0 && var && gamma && beta && grad_strength && work && B > 0 && C > 0 && H > 0 && W > 0);
+    hipStream_t st = ss::as_stream(stream);
+    const long long plane = (long long)H * W, total = (long long)B * plane;
+    if (ss::ceil_div(C, SSB_NW) > 65535) return SS_ERR_UNSUPPORTED;
+    if (grad_right && hipMemsetAsync(grad_right, 0, (size_t)B * C * plane * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    if (grad_pred0 && hipMemsetAsync(grad_pred0, 0, (size_t)total * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    if (grad_var && hipMemsetAsync(grad_var, 0, (size_t)total * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    if (grad_gamma_beta && hipMemsetAsync(grad_gamma_beta, 0, 2 * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
+    const unsigned gx = (unsigned)ss::ceil_div_ll(total, 64);
+    hipLaunchKernelGGL(ssb_dcorr_kernel, dim3(gx), dim3(64 * SSB_NW), 0, st, left, right, pred0, var, gamma, beta, grad_strength, work, grad_var,
+                       grad_gamma_beta, C, H, W, half_w, half_h, total);
+    if (grad_left || grad_right || grad_pred0)
+        hipLaunchKernelGGL(ssb_scatter_kernel, dim3(gx, ss::ceil_div(C, SSB_NW)), dim3(64 * SSB_NW), 0, st, left, right, pred0, work, grad_left,
+                           grad_right, grad_pred0, C, H, W, half_w, half_h, total);
+    return ss::check_launch();
+}
+

@@ -13,6 +13,8 @@ kernels, for what the 3x3x3 conv / transposed-conv functions of modules.py (`_Co
 Each falls back to the stock PyTorch layer (and counts it in modules.PATH_COUNTS["torch"]) for shapes the kernels are not
 built for.  `engine.TRAIN_HIP = False` (SS_TRAIN_HIP=0) sends everything to PyTorch.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -402,6 +404,10 @@ class _UpsampleSoftmaxRegression(torch.autograd.Function):
         return gc, None, None, None
 
 
+#: SS_SSB_TWO_LAUNCHES=0: the one-launch backward of the probe (rounds 4-5) instead of the two-launch form over a scratch (r06)
+SSB_TWO_LAUNCHES = os.environ.get("SS_SSB_TWO_LAUNCHES", "1") != "0"
+
+
 class _SampleStrength(torch.autograd.Function):
     """:286-293: the 5-candidate matching-strength probe."""
 
@@ -425,8 +431,13 @@ class _SampleStrength(torch.autograd.Function):
         ggb = torch.empty(2, dtype=torch.float32, device=left.device) if (need[4] or need[5]) else None
         gm, bt = _c(gamma.detach().reshape(1)), _c(beta.detach().reshape(1))
         with torch.cuda.device(left.device):
-            call("ss_sample_strength_bwd", ptr(left), ptr(right), ptr(pred0), ptr(var), ptr(gm), ptr(bt), ptr(g), ptr(gl), ptr(gr), ptr(gp), ptr(gv),
-                 ptr(ggb), B, C, H, W)
+            if SSB_TWO_LAUNCHES:        # (r06) through a [B,5,H,W] scratch: the channels on the second launch's grid
+                work = torch.empty((B, 5, H, W), dtype=torch.float32, device=left.device)
+                call("ss_sample_strength_bwd_ws", ptr(left), ptr(right), ptr(pred0), ptr(var), ptr(gm), ptr(bt), ptr(g), ptr(gl), ptr(gr), ptr(gp),
+                     ptr(gv), ptr(ggb), ptr(work), B, C, H, W)
+            else:
+                call("ss_sample_strength_bwd", ptr(left), ptr(right), ptr(pred0), ptr(var), ptr(gm), ptr(bt), ptr(g), ptr(gl), ptr(gr), ptr(gp),
+                     ptr(gv), ptr(ggb), B, C, H, W)
         return (gl, gr, gp, gv, ggb[0:1].reshape(gamma.shape) if need[4] else None, ggb[1:2].reshape(beta.shape) if need[5] else None)
 
 
