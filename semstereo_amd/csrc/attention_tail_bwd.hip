@@ -130,7 +130,7 @@ __device__ __forceinline__ Taps4 bilinear_taps(float disp, int h, int w, int H, 
 constexpr int SSB_NW = 8;
 // ... and (r06, second step) the scatter into g_right goes through LDS: a workgroup's 64 pixels lie in one row y (W % 64 == 0) and the
 // five candidates' taps land in that same row within +-SSB_M columns of them (|disparity| <= maxdisp / 4), so each wave sums its
-// channel's contributions in a private row buffer (ds_add_f32) and adds the touched part to memory once: ~1 global atomic per
+// channel's contributions in a private row buffer (tagged read-add-write, ss::lds_owned_add) and adds the touched part to memory once: ~1 global atomic per
 // (pixel, channel) instead of ~12.  Taps in another row (the south taps where the row coordinate is not exact) or beyond the
 // margin go to memory directly, as before.
 constexpr int SSB_M = 64, SSB_RB = 64 + 2 * SSB_M + 2;
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64 * SSB_NW, 4) void sample_strength_bwd_kernel(con
                                                                    float half_w, float half_h, long long total) {
     constexpr int NW = SSB_NW;
     __shared__ float red[NW][5][64], gred[NW][5][64], rowbuf[NW][SSB_RB + 62];
+    __shared__ int rowtag[NW][SSB_RB + 62];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + lane;
     const bool active = i < total;
@@ -226,14 +227,15 @@ __global__ __launch_bounds__(64 * SSB_NW, 4) void sample_strength_bwd_kernel(con
             float gl = 0.f;
             if (rowblock) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) rb[lane + 64 * k] = 0.f;
+                for (int k = 0; k < 4; ++k) ss::lds_put(&rb[lane + 64 * k], 0.f);
                 __builtin_amdgcn_wave_barrier();
             }
             auto scatter = [&](int o, int row, int col, float v) {
                 if (o < 0 || v == 0.f) return;
                 const unsigned k = (unsigned)(col - xb);
-                if (rowblock && row == y && k < (unsigned)SSB_RB) ss::lds_add(&rowbuf[wave][k], v);
-                else unsafeAtomicAdd(&grp[o], v);
+                const bool in_row = rowblock && row == y && k < (unsigned)SSB_RB;
+                if (!in_row) unsafeAtomicAdd(&grp[o], v);
+                ss::lds_owned_add(rowtag[wave], k, in_row, rb, v);                                  // (the wave's own row buffer: common.h)
             };
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(64 * SSB_NW, 4) void sample_strength_bwd_kernel(con
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int idx = lane + 64 * k;
-                    const float v = rb[idx];
+                    const float v = ss::lds_get(&rb[idx]);
                     if (idx < SSB_RB && v != 0.f) unsafeAtomicAdd(&grp[(long long)y * W + xb + idx], v);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(64 * SSB_NW) void ssb_scatter_kernel(const float* _
                                                                 float half_h, long long total) {
     constexpr int NW = SSB_NW;
     __shared__ float gred[NW][5][64], rowbuf[NW][SSB_RB + 62];
+    __shared__ int rowtag[NW][SSB_RB + 62];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + lane;
     const bool active = i < total;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(64 * SSB_NW) void ssb_scatter_kernel(const float* _
     if (cok) {
         if (rowblock) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rb[lane + 64 * k] = 0.f;
+            for (int k = 0; k < 4; ++k) ss::lds_put(&rb[lane + 64 * k], 0.f);
         }
         const float l = left[(b * C + c) * plane + pix];
         const float* rp = right + (b * C + c) * plane;
@@ -401,8 +404,9 @@ __global__ __launch_bounds__(64 * SSB_NW) void ssb_scatter_kernel(const float* _
         auto scatter = [&](int o, int row, int col, float v) {
             if (o < 0 || v == 0.f || !active) return;
             const unsigned k = (unsigned)(col - xb);
-            if (rowblock && row == y && k < (unsigned)SSB_RB) ss::lds_add(&rowbuf[wave][k], v);
-            else unsafeAtomicAdd(&grp[o], v);
+            const bool in_row = rowblock && row == y && k < (unsigned)SSB_RB;
+            if (!in_row) unsafeAtomicAdd(&grp[o], v);
+            ss::lds_owned_add(rowtag[wave], k, in_row, rb, v);                                      // (the wave's own row buffer: common.h)
         };
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(64 * SSB_NW) void ssb_scatter_kernel(const float* _
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k;
-                const float v = rb[idx];
+                const float v = ss::lds_get(&rb[idx]);
                 if (idx < SSB_RB && v != 0.f) unsafeAtomicAdd(&grp[(long long)y * W + xb + idx], v);
             }
         }

@@ -99,6 +99,54 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
     __hip_atomic_fetch_add((lds_ptr_t)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// fp32 sums into an LDS buffer that ONE WAVE alone writes, without ds_add_f32.  On gfx950 that instruction retires 0.38 lanes per CU
+// clock -- 170 clocks per wave instruction, the rate of the GLOBAL fp32 atomic, whatever the addresses (ds_add_u32: 14.8 lanes per
+// clock; a plain read-add-write: 8-10; tools/exp_lds_atomic.hip, profiles/r06_lds_atomic.txt).  Lanes of one call may aim at the same
+// slot, so each first writes its lane number to tag[k] and reads it back (the LDS executes a wave's instructions in order): the lane
+// whose number survived adds, the others go round again.  The loop condition is a
+// BALLOT on purpose: with a per-lane `while (pending)` the optimiser, which reasons per thread, sinks the update below the loop --
+// every lane spins until it has won the tag and then all of them add at once, colliding lanes losing updates (seen in the ISA, r06).
+// Every access to such a buffer goes through the volatile forms below for the same reason (a lane's own earlier store would be forwarded
+// past another lane's add).  Pointers into LDS only.
+typedef volatile float __attribute__((address_space(3))) * lds_vf_t;
+typedef volatile int __attribute__((address_space(3))) * lds_vi_t;
+// (the value is read in the same round trip as the tag: nobody else writes slot k in a round this lane wins)
+__device__ __forceinline__ void lds_owned_add(int* tag, unsigned k, bool take, float* row, float v) {
+    const int me = (int)__lane_id();
+    bool pending = take;
+    while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+        if (pending) {
+            ((lds_vi_t)tag)[k] = me;
+            const int won = ((lds_vi_t)tag)[k];
+            const float a = ((lds_vf_t)row)[k];
+            if (won == me) {
+                ((lds_vf_t)row)[k] = a + v;
+                pending = false;
+            }
+        }
+    }
+}
+// ... into the same slot of two rows (`two` wave-uniform: false leaves row_b alone)
+__device__ __forceinline__ void lds_owned_add2(int* tag, unsigned k, bool take, float* row_a, float va, float* row_b, float vb, bool two) {
+    const int me = (int)__lane_id();
+    bool pending = take;
+    while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+        if (pending) {
+            ((lds_vi_t)tag)[k] = me;
+            const int won = ((lds_vi_t)tag)[k];
+            const float a = ((lds_vf_t)row_a)[k];
+            const float b = two ? ((lds_vf_t)row_b)[k] : 0.f;
+            if (won == me) {
+                ((lds_vf_t)row_a)[k] = a + va;
+                if (two) ((lds_vf_t)row_b)[k] = b + vb;
+                pending = false;
+            }
+        }
+    }
+}
+__device__ __forceinline__ float lds_get(const float* p) { return *(lds_vf_t)p; }
+__device__ __forceinline__ void lds_put(float* p, float v) { *(lds_vf_t)p = v; }
+
 // 16-byte LDS read that stays ONE ds_read_b128.  Through a plain float4 the optimiser splits the load into scalars,
 // drops unused lanes and re-merges the rest as 4- and 8-byte reads (gwc_patch_gate_v4: 56 LDS instructions per channel
 // block instead of 24, and at a 16-byte lane stride those are bank conflicts -- 47 -> 37 us, tools/pmc_sq.sh).

@@ -406,43 +406,70 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
 }
 
 // grad_y alone (no disparity gradient: the candidates of models/SemStereo.py:316 are indices), row by row: a workgroup owns output row h
-// of WB_CC channels and sums every candidate's contributions to ROW h of grad_y in LDS (ds_add_f32), then adds the row to memory once
-// -- C * H * W global atomics instead of up to 4 * C * nd * H * W (r06: 65 M after the zero-weight taps were dropped, 1.33 ms of the
-// 1024^2 training step at the ~50 G atomics/s the part sustains).  The south taps of the rows whose coordinate is not exact land in
-// row h + 1: those few go to memory directly.
-constexpr int WB_CC = 8;
-__global__ __launch_bounds__(256) void warp_bwd_rows_kernel(const float* __restrict__ gyw, const float* __restrict__ disp, float* __restrict__ gy,
-                                                             int C, int H, int W, int nd, float half_w, float half_h) {
-    extern __shared__ float wb_row[];                     // [WB_CC][W]
+// of WB_CC channels and sums every candidate's contributions to ROW h of grad_y in LDS, then adds the row to memory once -- C * H * W
+// global atomics instead of up to 4 * C * nd * H * W (r06: 65 M after the zero-weight taps were dropped, 1.33 ms of the 1024^2 training
+// step at the ~50 G atomics/s the part sustains).  The south taps of the rows whose coordinate is not exact land in row h + 1: those
+// few go to memory directly.  Each of the four waves owns TWO channel rows and walks the whole row of pixels for them, so that its sums
+// need no ds_add_f32 (170 clocks per wave instruction on gfx950; ss::lds_owned_add2, common.h: the 50 M of them were 0.25 of the kernel's
+// 0.43 ms): one claim per tap serves both channels, whose taps are the same.
+constexpr int WB_CC = 8, WB_WAVES = 4;
+__global__ __launch_bounds__(64 * WB_WAVES) void warp_bwd_rows_kernel(const float* __restrict__ gyw, const float* __restrict__ disp,
+                                                                      float* __restrict__ gy, int C, int H, int W, int nd, float half_w,
+                                                                      float half_h) {
+    extern __shared__ float wb_row[];                     // [WB_CC][W] sums, then [WB_WAVES][W] tags
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = blockIdx.x, c0 = blockIdx.y * WB_CC;
     const long long b = blockIdx.z;
     const long long plane = (long long)H * W;
-    const int ncc = min(WB_CC, C - c0);
-    for (int i = threadIdx.x; i < WB_CC * W; i += 256) wb_row[i] = 0.f;
-    __syncthreads();
-    for (int w = threadIdx.x; w < W; w += 256) {
+    const int ca = c0 + wave, cb = ca + WB_WAVES;         // this wave's channels
+    if (ca >= C) return;                                  // (wave-uniform; no workgroup barrier below)
+    const bool two = cb < C;
+    float* ra = wb_row + (size_t)wave * W;
+    float* rbw = wb_row + (size_t)(wave + WB_WAVES) * W;
+    int* tag = reinterpret_cast<int*>(wb_row + (size_t)WB_CC * W) + (size_t)wave * W;
+    for (int i = lane; i < W; i += 64) { ss::lds_put(ra + i, 0.f); ss::lds_put(rbw + i, 0.f); }
+    __builtin_amdgcn_wave_barrier();
+    const float* ga_p = gyw + (b * C + ca) * nd * plane;
+    const float* gb_p = gyw + (b * C + (two ? cb : ca)) * nd * plane;
+    float* gpa = gy + (b * C + ca) * plane;
+    float* gpb = gy + (b * C + (two ? cb : ca)) * plane;
+    const int base = h * W;
+    constexpr int JU = 4;                                 // candidates whose loads are issued together (the wave is alone with its latency)
+    for (int w = lane; w < W; w += 64) {
         const long long pix = (long long)h * W + w;
-        for (int j = 0; j < nd; ++j) {
-            const Taps tp = make_taps(disp[(b * nd + j) * plane + pix], h, w, H, W, half_w, half_h);
-            // (column of a tap inside its row; the north taps lie in row h wherever the row coordinate is exact -- checked, not assumed)
-            const int base = h * W;
-            for (int c = 0; c < ncc; ++c) {
-                const float g = gyw[((b * C + c0 + c) * nd + j) * plane + pix];
-                float* gp = gy + (b * C + c0 + c) * plane;
+        for (int j0 = 0; j0 < nd; j0 += JU) {
+            float dv[JU], gav[JU], gbv[JU];
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                const int j = min(j0 + u, nd - 1);
+                dv[u] = disp[(b * nd + j) * plane + pix];
+                gav[u] = ga_p[j * plane + pix];
+                gbv[u] = two ? gb_p[j * plane + pix] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                if (j0 + u >= nd) break;
+                const Taps tp = make_taps(dv[u], h, w, H, W, half_w, half_h);
+                const float ga = gav[u], gb = gbv[u];
+                // (column of a tap inside its row; the north taps lie in row h wherever the row coordinate is exact -- checked, not assumed)
                 auto add = [&](int o, float wt) {
-                    if (o < 0 || wt == 0.f) return;
-                    if (o >= base && o < base + W) ss::lds_add(&wb_row[c * W + (o - base)], wt * g);
-                    else unsafeAtomicAdd(gp + o, wt * g);
+                    const bool any = o >= 0 && wt != 0.f;
+                    const bool in_row = any && o >= base && o < base + W;
+                    if (any && !in_row) {
+                        unsafeAtomicAdd(gpa + o, wt * ga);
+                        if (two) unsafeAtomicAdd(gpb + o, wt * gb);
+                    }
+                    ss::lds_owned_add2(tag, (unsigned)(o - base), in_row, ra, wt * ga, rbw, wt * gb, two);
                 };
                 add(tp.o_nw, tp.w_nw); add(tp.o_ne, tp.w_ne); add(tp.o_sw, tp.w_sw); add(tp.o_se, tp.w_se);
             }
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ncc * W; i += 256) {
-        const int c = i / W, col = i - c * W;
-        const float v = wb_row[i];
-        if (v != 0.f) unsafeAtomicAdd(gy + (b * C + c0 + c) * plane + (long long)h * W + col, v);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < W; i += 64) {
+        const float va = ss::lds_get(ra + i), vb = ss::lds_get(rbw + i);
+        if (va != 0.f) unsafeAtomicAdd(gpa + (long long)h * W + i, va);
+        if (two && vb != 0.f) unsafeAtomicAdd(gpb + (long long)h * W + i, vb);
     }
 }
 
@@ -513,7 +540,7 @@ extern "C" int ss_warp_sampled_bwd(const float* grad_y_warped, const float* grad
         const long long total = (long long)B * nd * plane, blocks = ss::ceil_div_ll(total, 256);
         if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
         if (grad_disp == nullptr && W <= 1024 && H <= 65535 && B <= 65535 && ss::ceil_div(C, WB_CC) <= 65535)
-            hipLaunchKernelGGL(warp_bwd_rows_kernel, dim3(H, ss::ceil_div(C, WB_CC), B), dim3(256), (size_t)WB_CC * W * sizeof(float), st,
+            hipLaunchKernelGGL(warp_bwd_rows_kernel, dim3(H, ss::ceil_div(C, WB_CC), B), dim3(64 * WB_WAVES), (size_t)(WB_CC + WB_WAVES) * W * sizeof(float), st,
                                grad_y_warped, disp, grad_y, C, H, W, nd, half_w, half_h);
         else
             hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y_warped, y, disp, grad_y, grad_disp, C, H,

@@ -1815,6 +1815,34 @@ def test_backward_warp_and_topk_in_hip(sa):
         check(f"bwd/topk/{name}/samples", gh[1], go[1], 2e-6, 1e-6)
 
 
+@pytest.mark.parametrize("name", sorted(cases.WARP) + ["c12_w70_int", "c20_w200_frac"])
+def test_backward_warp_onto_the_features_alone_row_by_row(sa, name):
+    """The live backward of SpatialTransformer_grid at models/SemStereo.py:316: the candidates are INDICES (no gradient), so only the
+    feature gradient is formed -- `warp_bwd_rows_kernel`: each wave sums two channel rows in LDS with tagged read-add-writes
+    (ss::lds_owned_add2; lanes whose taps land on the same column take turns) and adds the row to memory once.  Against autograd
+    through the oracle's restatement (F.grid_sample), on every warp case -- rows narrower than a wave, ragged widths, integer
+    candidates that differ between neighbouring pixels (colliding lanes), fractional ones (two taps per row, south taps in the next
+    row), and channel counts that leave the second channel of a wave, or whole waves, without work."""
+    from oracle import detdata as dd
+    if name in cases.WARP:
+        x, y, d = cases.warp_inputs(name)
+    else:
+        C, W, kind = {"c12_w70_int": (12, 70, "int"), "c20_w200_frac": (20, 200, "frac")}[name]
+        x, y = dd.t_normalish((2, C, 5, W), 871), dd.t_normalish((2, C, 5, W), 872)
+        d = dd.distinct_sorted_candidates(2, 24, 5, W, 32, 873) if kind == "int" else dd.t_uniform((2, 6, 5, W), 873, -20.0, 20.0)
+    seeds = [dd.t_normalish((x.shape[0], x.shape[1], d.shape[1], x.shape[2], x.shape[3]), 874 + k) for k in range(2)]
+
+    def both(fn, to):
+        xs = [to(x).clone().requires_grad_(True), to(y).clone().requires_grad_(True), to(d).clone()]
+        yw, xw = fn(*xs)
+        (yw * to(seeds[0])).sum().add((xw * to(seeds[1])).sum()).backward()
+        return xs[0].grad, xs[1].grad
+    gh = both(sa.ops.SpatialTransformer_grid, dev)
+    go = both(oops.SpatialTransformer_grid, lambda t: t)
+    check(f"bwd/warp_rows/{name}/x", gh[0], go[0], 1e-5, 1e-6)
+    check(f"bwd/warp_rows/{name}/y", gh[1], go[1], 1e-5, 2e-6)              # sums in another order
+
+
 CONV_TRAIN_CASES = [
     # (B, Cin, Cout, D, H, W, stride)
     (2, 32, 32, 4, 10, 36, 1),
