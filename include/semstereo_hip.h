@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (15 since round 6 (13, 14 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (16 since round 6 (13-15 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -439,6 +439,21 @@ int ss_batchnorm_eval_fwd(const float* x, const float* residual, const float* me
 int ss_batchnorm_eval_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
                           const float* weight, float* grad_x, float* grad_residual, double* work, int B, int C, long long N,
                           int relu, ss_stream_t stream);
+/* (r06) The batch-statistics forward, either form (residual may be NULL), that also does nn.BatchNorm's bookkeeping in its statistics
+ * kernel: running_mean / running_var [C] (NULL = leave alone) become running * (1 - momentum) + momentum * batch value (the variance
+ * unbiased) as F.batch_norm moves them (torch/nn/modules/batchnorm.py: the reference's layers keep the default momentum 0.1), and
+ * num_batches_tracked (int64[1] or NULL) counts the batch.  0 <= momentum <= 1; a module with momentum=None (cumulative average) is not
+ * this entry's case. */
+int ss_batchnorm_train_fwd_rs(const float* x, const float* residual, const float* weight, const float* bias, float* y, float* mean,
+                              float* invstd, float* var_unbiased, double* work, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, double momentum, int B, int C, long long N, float eps, int relu,
+                              ss_stream_t stream);
+/* (r06) Both backward forms with the parameter gradients also as floats, grad_weight / grad_bias [C] (either may be NULL; the doubles
+ * stay in `work`); grad_residual may be NULL; batch_statistics = 1: the backward of ss_batchnorm_train_fwd / _res_fwd / _fwd_rs,
+ * 0: of ss_batchnorm_eval_fwd. */
+int ss_batchnorm_bwd_pg(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                        const float* weight, float* grad_x, float* grad_residual, double* work, float* grad_weight, float* grad_bias,
+                        int batch_statistics, int B, int C, long long N, int relu, ss_stream_t stream);
 /* Weight gradient of the 1x1(x1) convolutions (redir1 / redir2 `models/SemStereo.py:131-132`, attention_block.qkv_3d /
  * final1x1 `models/submodule_other.py:799-800`, channelAtt.im_att `models/SemStereo.py:92-95`):
  * grad_out [B,Cout,npos], in [B,Cin,npos] -> grad_w [Cout,Cin]. */

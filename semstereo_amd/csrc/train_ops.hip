@@ -84,15 +84,22 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __rest
 }
 
 // sums (x, x^2) -> mean, invstd (biased variance, as F.batch_norm normalises with), var_unbiased for the running statistic
+// ... and, when given, the module's running statistics as F.batch_norm moves them -- running = running * (1 - momentum) + momentum *
+// batch value, the variance unbiased -- and its num_batches_tracked (r06: five element-wise PyTorch launches per layer and step)
 __global__ void bn_finish_stats_kernel(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ invstd,
-                                       float* __restrict__ var_unbiased, int C, double count, float eps) {
+                                       float* __restrict__ var_unbiased, int C, double count, float eps, float* __restrict__ run_mean,
+                                       float* __restrict__ run_var, long long* __restrict__ batches_tracked, float mom, float keep) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double m = sums[2 * c] / count;
     const double v = fmax(sums[2 * c + 1] / count - m * m, 0.0);
-    mean[c] = (float)m;
+    const float mf = (float)m, vu = (float)(count > 1.0 ? v * count / (count - 1.0) : v);
+    mean[c] = mf;
     invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
-    var_unbiased[c] = (float)(count > 1.0 ? v * count / (count - 1.0) : v);
+    var_unbiased[c] = vu;
+    if (run_mean) run_mean[c] = fmaf(mom, mf, __fmul_rn(run_mean[c], keep));
+    if (run_var) run_var[c] = fmaf(mom, vu, __fmul_rn(run_var[c], keep));
+    if (c == 0 && batches_tracked) batches_tracked[0] += 1;
 }
 
 // y = (x - mean) * invstd * w + b  [+ res]  [ReLU]      (res: the skip branch of the hourglass, models/SemStereo.py:141-142)
@@ -138,11 +145,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
                                                                const float* __restrict__ y, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, const float* __restrict__ w,
                                                                const double* __restrict__ sums, float* __restrict__ dx,
-                                                               float* __restrict__ dres, int C, long long N, double count, int relu) {
+                                                               float* __restrict__ dres, int C, long long N, double count, int relu,
+                                                               float* __restrict__ gw, float* __restrict__ gb) {
     const int c = blockIdx.y;
     const long long base = ((long long)blockIdx.z * C + c) * N;
     const float mu = mean[c], is = invstd[c], ws = (w ? w[c] : 1.f) * is;
     const float mg = (float)(sums[2 * c] / count), mgx = (float)(sums[2 * c + 1] / count);
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {      // the parameter gradients as floats (r06: two strided copies per layer)
+        if (gb) gb[c] = (float)sums[2 * c];
+        if (gw) gw[c] = (float)sums[2 * c + 1];
+    }
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < N; i += (long long)gridDim.x * 1024) {
         const float4 gq = *reinterpret_cast<const float4*>(g + base + i);
         const float4 xq = *reinterpret_cast<const float4*>(x + base + i);
@@ -172,9 +184,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ invstd, const float* __restrict__ w,
                                                             const double* __restrict__ sums, float* __restrict__ dx,
                                                             float* __restrict__ dres, int C,
-                                                            long long N, long long total, double count, int relu) {
+                                                            long long N, long long total, double count, int relu,
+                                                            float* __restrict__ gw, float* __restrict__ gb) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
+    if (i < C) {                                             // (total = B * C * N >= C)
+        if (gb) gb[i] = (float)sums[2 * i];
+        if (gw) gw[i] = (float)sums[2 * i + 1];
+    }
     const int c = (int)((i / N) % C);
     float gv = g[i];
     if (relu && !(y[i] > 0.f)) gv = 0.f;
@@ -350,15 +367,17 @@ inline int apply_grid(long long N) { return (int)std::min<long long>(std::max<lo
 // the running statistics; work: 2*C doubles of scratch.
 static int batchnorm_train_fwd_impl(const float* x, const float* residual, const float* weight, const float* bias, float* y, float* mean,
                                     float* invstd, float* var_unbiased, double* work, int B, int C, long long N, float eps, int relu,
-                                    ss_stream_t stream) {
+                                    ss_stream_t stream, float* run_mean = nullptr, float* run_var = nullptr,
+                                    long long* batches_tracked = nullptr, double momentum = 0.0) {
     SS_REQUIRE(x && y && mean && invstd && var_unbiased && work && B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535);
     hipStream_t st = ss::as_stream(stream);
     if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
     long long per_block;
     const int gx = reduce_grid(N, per_block);
     hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(gx, C, B), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, work, C, N, per_block, 0);
+    // (the factor of the old value is 1 - momentum formed in double and rounded once, as `running.mul_(1.0 - momentum)` has it)
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ss::ceil_div(C, 64)), dim3(64), 0, st, work, mean, invstd, var_unbiased, C,
-                       (double)B * (double)N, eps);
+                       (double)B * (double)N, eps, run_mean, run_var, batches_tracked, (float)momentum, (float)(1.0 - momentum));
     const long long total = (long long)B * C * N;
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
@@ -384,11 +403,24 @@ extern "C" int ss_batchnorm_train_res_fwd(const float* x, const float* residual,
     return batchnorm_train_fwd_impl(x, residual, weight, bias, y, mean, invstd, var_unbiased, work, B, C, N, eps, relu, stream);
 }
 
+// ... either form (residual may be NULL) that also moves the module's running statistics (running_mean / running_var [C], NULL = leave
+// alone) with a FIXED momentum and counts the batch in num_batches_tracked (int64[1] or NULL): nn.BatchNorm's own bookkeeping in the
+// statistics kernel instead of five element-wise launches per layer
+extern "C" int ss_batchnorm_train_fwd_rs(const float* x, const float* residual, const float* weight, const float* bias, float* y,
+                                         float* mean, float* invstd, float* var_unbiased, double* work, float* running_mean,
+                                         float* running_var, long long* num_batches_tracked, double momentum, int B, int C,
+                                         long long N, float eps, int relu, ss_stream_t stream) {
+    SS_REQUIRE(momentum >= 0.0 && momentum <= 1.0);
+    return batchnorm_train_fwd_impl(x, residual, weight, bias, y, mean, invstd, var_unbiased, work, B, C, N, eps, relu, stream,
+                                    running_mean, running_var, num_batches_tracked, momentum);
+}
+
 // Its backward: grad_y, x, y (needed only with relu), mean, invstd, weight -> grad_x [B,C,N], grad_weight / grad_bias [C] as
 // doubles in work[2c + 1] / work[2c] (sum g' * xhat, sum g').
 static int batchnorm_train_bwd_impl(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
                                     const float* weight, float* grad_x, float* grad_res, double* work, int B, int C, long long N, int relu,
-                                    ss_stream_t stream) {
+                                    ss_stream_t stream, float* grad_weight = nullptr, float* grad_bias = nullptr,
+                                    bool batch_statistics = true) {
     SS_REQUIRE(grad_y && x && mean && invstd && grad_x && work && B > 0 && C > 0 && N > 0 && (y || !relu) && C <= 65535 && B <= 65535);
     hipStream_t st = ss::as_stream(stream);
     if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
@@ -398,12 +430,14 @@ static int batchnorm_train_bwd_impl(const float* grad_y, const float* x, const f
     const long long total = (long long)B * C * N;
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    // (on running statistics the two mean terms of the apply kernel vanish: an infinite element count makes sum / count == 0)
+    const double count = batch_statistics ? (double)B * (double)N : (double)INFINITY;
     if (vec4_ok(N, grad_y, x, y, grad_x, grad_res))
         hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(apply_grid(N), C, B), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x,
-                           grad_res, C, N, (double)B * (double)N, relu);
+                           grad_res, C, N, count, relu, grad_weight, grad_bias);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x,
-                           grad_res, C, N, total, (double)B * (double)N, relu);
+                           grad_res, C, N, total, count, relu, grad_weight, grad_bias);
     return ss::check_launch();
 }
 
@@ -443,26 +477,19 @@ extern "C" int ss_batchnorm_eval_fwd(const float* x, const float* residual, cons
 extern "C" int ss_batchnorm_eval_bwd(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
                                      const float* weight, float* grad_x, float* grad_residual, double* work, int B, int C, long long N,
                                      int relu, ss_stream_t stream) {
-    SS_REQUIRE(grad_y && x && mean && invstd && grad_x && work && B > 0 && C > 0 && N > 0 && (y || !relu) && C <= 65535 && B <= 65535);
-    hipStream_t st = ss::as_stream(stream);
-    if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
-    long long per_block;
-    const int gx = reduce_grid(N, per_block);
-    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(gx, C, B), dim3(256), 0, st, grad_y, x, y, mean, invstd, work, C, N, per_block, relu);
-    const long long total = (long long)B * C * N;
-    const long long blocks = ss::ceil_div_ll(total, 256);
-    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
-    // (an infinite element count zeroes the two mean terms of the apply kernel: sum / count == 0)
-    if (vec4_ok(N, grad_y, x, y, grad_x, grad_residual))
-        hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(apply_grid(N), C, B), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x,
-                           grad_residual, C, N, (double)INFINITY, relu);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x,
-                           grad_residual, C, N, total, (double)INFINITY, relu);
-    return ss::check_launch();
+    return batchnorm_train_bwd_impl(grad_y, x, y, mean, invstd, weight, grad_x, grad_residual, work, B, C, N, relu, stream, nullptr, nullptr,
+                                    false);
 }
 
-// sums[c] (double) = sum over batch and positions of a[b, c, :]  (bias gradients of the 1x1x1 projections)
+// Both backward forms with the parameter gradients ALSO as floats: grad_weight / grad_bias [C] (either may be NULL) beside the doubles in
+// `work`; grad_residual may be NULL; batch_statistics = 1: the backward of ss_batchnorm_train_fwd / _res_fwd, 0: of ss_batchnorm_eval_fwd
+extern "C" int ss_batchnorm_bwd_pg(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
+                                   const float* weight, float* grad_x, float* grad_residual, double* work, float* grad_weight,
+                                   float* grad_bias, int batch_statistics, int B, int C, long long N, int relu, ss_stream_t stream) {
+    return batchnorm_train_bwd_impl(grad_y, x, y, mean, invstd, weight, grad_x, grad_residual, work, B, C, N, relu, stream, grad_weight,
+                                    grad_bias, batch_statistics != 0);
+}
+
 extern "C" int ss_channel_sum_fwd(const float* a, double* sums, int B, int C, long long N, ss_stream_t stream) {
     SS_REQUIRE(a && sums && B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535);
     hipStream_t st = ss::as_stream(stream);

@@ -46,10 +46,11 @@ def _count(kind):
 class _BatchNormTrain(torch.autograd.Function):
     """y = bn(x) [+ residual] [-> ReLU] with batch statistics; `residual` (same shape as x, or None) joins behind the
     normalisation and before the ReLU (hourglass.forward's `F.relu(self.conv5(conv4) + self.redir2(conv2))`,
-    models/SemStereo.py:141-142) in the same pass."""
+    models/SemStereo.py:141-142) in the same pass.  `stats` = (running_mean, running_var, num_batches_tracked, momentum) or None: the
+    module's bookkeeping done by the statistics kernel (ss_batchnorm_train_fwd_rs) -- a tuple, so that autograd does not see the buffers."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu, residual):
+    def forward(ctx, x, weight, bias, eps, relu, residual, stats=None):
         x = _c(x)
         B, C = x.shape[0], x.shape[1]
         N = x[0, 0].numel()
@@ -57,40 +58,39 @@ class _BatchNormTrain(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd, var_u = torch.empty_like(mean), torch.empty_like(mean)
         work = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        if residual is not None:
+            residual = _c(residual)
+            assert residual.shape == x.shape
+        rm, rv, nbt, mom = stats if stats is not None else (None, None, None, 0.0)
         with torch.cuda.device(x.device):
-            if residual is None:
-                call("ss_batchnorm_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd), ptr(var_u), ptr(work),
-                     B, C, N, float(eps), int(relu))
-            else:
-                residual = _c(residual)
-                assert residual.shape == x.shape
-                call("ss_batchnorm_train_res_fwd", ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd), ptr(var_u),
-                     ptr(work), B, C, N, float(eps), int(relu))
+            call("ss_batchnorm_train_fwd_rs", ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd), ptr(var_u), ptr(work),
+                 ptr(rm), ptr(rv), ptr(nbt), float(mom), B, C, N, float(eps), int(relu))
+        for t in (rm, rv, nbt):                              # (written through raw pointers: the packed-weight caches key on versions)
+            if t is not None:
+                torch.autograd.graph.increment_version(t)
         ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
         ctx.relu, ctx.has_bias, ctx.has_res = bool(relu), bias is not None, residual is not None
         ctx.mark_non_differentiable(mean, var_u)
+        ctx.set_materialize_grads(False)                     # (no zero-filled gradients for `mean` / `var_u`: two launches per layer)
         return y, mean, var_u
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
         x, y, mean, invstd, weight = ctx.saved_tensors
+        if g is None:
+            return (None,) * 7
         g = _c(g)
         B, C = x.shape[0], x.shape[1]
         N = x[0, 0].numel()
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if ctx.has_res else None
         work = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        gw = torch.empty(C, dtype=torch.float32, device=x.device) if weight is not None else None
+        gb = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         with torch.cuda.device(x.device):
-            if gres is None:
-                call("ss_batchnorm_train_bwd", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(work), B, C, N,
-                     int(ctx.relu))
-            else:
-                call("ss_batchnorm_train_res_bwd", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(gres), ptr(work),
-                     B, C, N, int(ctx.relu))
-        sums = work.reshape(C, 2)
-        gw = sums[:, 1].float() if weight is not None else None
-        gb = sums[:, 0].float() if ctx.has_bias else None
-        return gx, gw, gb, None, None, gres
+            call("ss_batchnorm_bwd_pg", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(gres), ptr(work), ptr(gw), ptr(gb),
+                 1, B, C, N, int(ctx.relu))
+        return gx, gw, gb, None, None, gres, None
 
 
 class _BatchNormEval(torch.autograd.Function):
@@ -119,12 +119,11 @@ class _BatchNormEval(torch.autograd.Function):
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if ctx.has_res else None
         work = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        gw = torch.empty(C, dtype=torch.float32, device=x.device) if weight is not None else None
+        gb = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         with torch.cuda.device(x.device):
-            call("ss_batchnorm_eval_bwd", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(gres), ptr(work),
-                 B, C, N, int(ctx.relu))
-        sums = work.reshape(C, 2)
-        gw = sums[:, 1].float() if weight is not None else None
-        gb = sums[:, 0].float() if ctx.has_bias else None
+            call("ss_batchnorm_bwd_pg", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(gres), ptr(work), ptr(gw), ptr(gb),
+                 0, B, C, N, int(ctx.relu))
         return gx, gw, gb, None, None, None, gres
 
 
@@ -144,8 +143,15 @@ def batchnorm_train(bn, x, relu=False, residual=None):
             y = y + residual
         return F.relu(y) if relu else y
     _count("hip_train")
-    y, mean, var_u = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, residual)
-    if bn.track_running_stats and bn.running_mean is not None:
+    tracked = bn.track_running_stats and bn.running_mean is not None
+    if (tracked and bn.momentum is not None and bn.running_mean.dtype == torch.float32 and bn.running_var.dtype == torch.float32
+            and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous() and bn.running_mean.device == x.device
+            and (bn.num_batches_tracked is None or (bn.num_batches_tracked.dtype == torch.int64 and bn.num_batches_tracked.device == x.device))):
+        # the running statistics and the batch counter move inside the statistics kernel (five element-wise launches per layer otherwise)
+        return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, residual,
+                                     (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)))[0]
+    y, mean, var_u = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, residual, None)
+    if tracked:
         with torch.no_grad():
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1

@@ -1982,7 +1982,7 @@ def test_training_kernels_vs_float64_autograd(sa):
 
         def hip(x, w, b_):
             bn.weight, bn.bias = nn.Parameter(w.detach()), nn.Parameter(b_.detach())
-            y_ = T._BatchNormTrain.apply(x, w, b_, bn.eps, relu, None)[0]
+            y_ = T._BatchNormTrain.apply(x, w, b_, bn.eps, relu, None, None)[0]
             return y_
 
         def ref(x, w, b_):
@@ -1999,7 +1999,7 @@ def test_training_kernels_vs_float64_autograd(sa):
     # hourglass.forward, models/SemStereo.py:141-142, inside the BatchNorm apply): forward, and gradients of x, weight, bias, residual
     for shape in ((2, 8, 3, 5, 7), (1, 32, 4, 16, 20)):
         C = shape[1]
-        run(lambda x, w, b_, r_: T._BatchNormTrain.apply(x, w, b_, 1e-5, True, r_)[0],
+        run(lambda x, w, b_, r_: T._BatchNormTrain.apply(x, w, b_, 1e-5, True, r_, None)[0],
             lambda x, w, b_, r_: F.relu(F.batch_norm(x, None, None, w, b_, True, 0.0, 1e-5) + r_),
             [dd.t_normalish(shape, 705) * 2 + 0.3, dd.t_uniform((C,), 706, 0.5, 1.5), dd.t_uniform((C,), 707, -0.3, 0.3),
              dd.t_normalish(shape, 708)], 2e-5, f"bn_res{shape}")
