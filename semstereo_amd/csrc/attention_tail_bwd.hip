@@ -370,15 +370,19 @@ __global__ __launch_bounds__(64 * SSB_NW) void ssb_dcorr_kernel(const float* __r
     }
 }
 
-// grid (pixel blocks of 64, ceil(C / 8)): wave w of a workgroup owns channel 8 blockIdx.y + w
+// grid (pixel blocks of 64, ceil(C / 16)): wave w of a workgroup owns the channel PAIR 2 (8 blockIdx.y + w) + {0, 1}.  (A wave spends its
+// life waiting -- 57 % of its cycles on memory, 15 % issuing, SQ counters r06 -- so it carries two channels through the same chain of
+// loads: the taps are formed once, the gathers of both channels are in flight together and one claim of a row-buffer slot serves both.)
+constexpr int SSB_CH = 2;
 __global__ __launch_bounds__(64 * SSB_NW) void ssb_scatter_kernel(const float* __restrict__ left, const float* __restrict__ right,
                                                                 const float* __restrict__ pred0, const float* __restrict__ dcorr_in,
                                                                 float* __restrict__ g_left, float* __restrict__ g_right,
                                                                 float* __restrict__ g_pred0, int C, int H, int W, float half_w,
                                                                 float half_h, long long total) {
     constexpr int NW = SSB_NW;
-    __shared__ float gred[NW][5][64], rowbuf[NW][SSB_RB + 62];
-    __shared__ int rowtag[NW][SSB_RB + 62];
+    constexpr int RS = SSB_RB + 62;
+    __shared__ float gred[NW][5][64], rowbuf[NW][2][SSB_CH][RS];        // [wave][row y / the other row][channel][column - xb]
+    __shared__ int rowtag[NW][2][RS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + lane;
     const bool active = i < total;
@@ -386,52 +390,81 @@ __global__ __launch_bounds__(64 * SSB_NW) void ssb_scatter_kernel(const float* _
     const long long ii = active ? i : 0;
     const int x = (int)(ii % W), y = (int)((ii / W) % H);
     const long long b = ii / plane, pix = (long long)y * W + x;
-    const int c = blockIdx.y * NW + wave;
-    const bool cok = c < C;                                  // (wave-uniform)
+    const int c0 = (blockIdx.y * NW + wave) * SSB_CH;
+    const bool cok = c0 < C, two = c0 + 1 < C;               // (wave-uniform)
     float gix[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     const bool rowblock = (W % 64 == 0) && g_right != nullptr;
     const int xb = (int)((((long long)blockIdx.x * 64) % W)) - SSB_M;
-    float* rb = rowbuf[wave];
+    float* rows = &rowbuf[wave][0][0][0];
+    int* tags = &rowtag[wave][0][0];
+    // the rows of the taps (the same for every candidate and lane: the probe shifts along x only): floor(iy) and the one below; the
+    // coordinate round trip leaves iy = y -+ ~1e-5 on most rows, so the second row is the rule, with weights ~1e-5 (warp.hip, r06)
+    int other = -1;
     if (cok) {
         if (rowblock) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ss::lds_put(&rb[lane + 64 * k], 0.f);
+            for (int n = 0; n < 2 * SSB_CH; ++n)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ss::lds_put(&rows[n * RS + lane + 64 * k], 0.f);
         }
-        const float l = left[(b * C + c) * plane + pix];
-        const float* rp = right + (b * C + c) * plane;
-        float* grp = g_right ? g_right + (b * C + c) * plane : nullptr;
-        float gl = 0.f;
-        auto scatter = [&](int o, int row, int col, float v) {
-            if (o < 0 || v == 0.f || !active) return;
+        const long long ca = (b * C + c0) * plane, cb = (b * C + (two ? c0 + 1 : c0)) * plane;
+        const float la = left[ca + pix], lb = two ? left[cb + pix] : 0.f;
+        const float* rpa = right + ca;
+        const float* rpb = right + cb;
+        float* gra_p = g_right ? g_right + ca : nullptr;
+        float* grb_p = g_right ? g_right + cb : nullptr;
+        float gla = 0.f, glb = 0.f;
+        auto scatter = [&](int o, int row, int col, float va, float vb) {
+            if (o < 0 || !active || (va == 0.f && vb == 0.f)) return;
             const unsigned k = (unsigned)(col - xb);
-            const bool in_row = rowblock && row == y && k < (unsigned)SSB_RB;
-            if (!in_row) unsafeAtomicAdd(&grp[o], v);
-            ss::lds_owned_add(rowtag[wave], k, in_row, rb, v);                                      // (the wave's own row buffer: common.h)
+            const int r = (row == y) ? 0 : 1;
+            const bool in_row = rowblock && (row == y || row == other) && k < (unsigned)SSB_RB;
+            if (!in_row) {
+                unsafeAtomicAdd(&gra_p[o], va);
+                if (two) unsafeAtomicAdd(&grb_p[o], vb);
+            }
+            float* ra = rows + r * (SSB_CH * RS);                            // (the wave's own row buffers: common.h)
+            ss::lds_owned_add2(tags + r * RS, k, in_row, ra, va, ra + RS, vb, two);
         };
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
             const int yy = min(max(y + kTapDy[t], 0), H - 1), xx = min(max(x + kTapDx[t], 0), W - 1);
             const Taps4 tp = bilinear_taps(pred0[b * plane + (long long)yy * W + xx], y, x, H, W, half_w, half_h);
+            if (t == 0) other = (tp.iy == y) ? y + 1 : tp.iy;
             const float dc = dcorr_in[(b * 5 + t) * plane + pix];
-            const float a = (tp.o_nw >= 0) ? rp[tp.o_nw] : 0.f, bq = (tp.o_ne >= 0) ? rp[tp.o_ne] : 0.f;
-            const float cq = (tp.o_sw >= 0) ? rp[tp.o_sw] : 0.f, d = (tp.o_se >= 0) ? rp[tp.o_se] : 0.f;
-            gl += dc * (a * tp.w_nw + bq * tp.w_ne + cq * tp.w_sw + d * tp.w_se);
-            const float gr = dc * l;
-            if (grp) {
-                if (tp.w_nw != 0.f) scatter(tp.o_nw, tp.iy, tp.ix, gr * tp.w_nw);
-                if (tp.w_ne != 0.f) scatter(tp.o_ne, tp.iy, tp.ix + 1, gr * tp.w_ne);
-                if (tp.w_sw != 0.f) scatter(tp.o_sw, tp.iy + 1, tp.ix, gr * tp.w_sw);
-                if (tp.w_se != 0.f) scatter(tp.o_se, tp.iy + 1, tp.ix + 1, gr * tp.w_se);
+            const float a0 = (tp.o_nw >= 0) ? rpa[tp.o_nw] : 0.f, b0 = (tp.o_ne >= 0) ? rpa[tp.o_ne] : 0.f;
+            const float c0v = (tp.o_sw >= 0) ? rpa[tp.o_sw] : 0.f, d0 = (tp.o_se >= 0) ? rpa[tp.o_se] : 0.f;
+            const float a1 = (two && tp.o_nw >= 0) ? rpb[tp.o_nw] : 0.f, b1 = (two && tp.o_ne >= 0) ? rpb[tp.o_ne] : 0.f;
+            const float c1v = (two && tp.o_sw >= 0) ? rpb[tp.o_sw] : 0.f, d1 = (two && tp.o_se >= 0) ? rpb[tp.o_se] : 0.f;
+            gla += dc * (a0 * tp.w_nw + b0 * tp.w_ne + c0v * tp.w_sw + d0 * tp.w_se);
+            glb += dc * (a1 * tp.w_nw + b1 * tp.w_ne + c1v * tp.w_sw + d1 * tp.w_se);
+            const float ga = dc * la, gb = dc * lb;
+            if (g_right) {
+                if (tp.w_nw != 0.f) scatter(tp.o_nw, tp.iy, tp.ix, ga * tp.w_nw, gb * tp.w_nw);
+                if (tp.w_ne != 0.f) scatter(tp.o_ne, tp.iy, tp.ix + 1, ga * tp.w_ne, gb * tp.w_ne);
+                if (tp.w_sw != 0.f) scatter(tp.o_sw, tp.iy + 1, tp.ix, ga * tp.w_sw, gb * tp.w_sw);
+                if (tp.w_se != 0.f) scatter(tp.o_se, tp.iy + 1, tp.ix + 1, ga * tp.w_se, gb * tp.w_se);
             }
-            gix[t] = gr * ((bq - a) * tp.fs + (d - cq) * tp.fn);
+            gix[t] = ga * ((b0 - a0) * tp.fs + (d0 - c0v) * tp.fn) + gb * ((b1 - a1) * tp.fs + (d1 - c1v) * tp.fn);
         }
-        if (g_left && active) g_left[(b * C + c) * plane + pix] = gl;
+        if (g_left && active) {
+            g_left[ca + pix] = gla;
+            if (two) g_left[cb + pix] = glb;
+        }
         if (rowblock) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = lane + 64 * k;
-                const float v = ss::lds_get(&rb[idx]);
-                if (idx < SSB_RB && v != 0.f) unsafeAtomicAdd(&grp[(long long)y * W + xb + idx], v);
+            for (int r = 0; r < 2; ++r) {
+                const int row = r == 0 ? y : other;                          // (both the same in every lane of the wave)
+                if (row < 0 || row >= H) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = lane + 64 * k, col = xb + idx;
+                    const float va = ss::lds_get(&rows[(r * SSB_CH) * RS + idx]), vb = ss::lds_get(&rows[(r * SSB_CH + 1) * RS + idx]);
+                    if (idx < SSB_RB && col >= 0 && col < W) {
+                        if (va != 0.f) unsafeAtomicAdd(&gra_p[(long long)row * W + col], va);
+                        if (two && vb != 0.f) unsafeAtomicAdd(&grb_p[(long long)row * W + col], vb);
+                    }
+                }
             }
         }
     }
@@ -597,7 +630,7 @@ extern "C" int ss_sample_strength_bwd_ws(const float* left, const float* right, 
     SS_REQUIRE(left && right && pred0 && var && gamma && beta && grad_strength && work && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t st = ss::as_stream(stream);
     const long long plane = (long long)H * W, total = (long long)B * plane;
-    if (ss::ceil_div(C, SSB_NW) > 65535) return SS_ERR_UNSUPPORTED;
+    if (ss::ceil_div(C, SSB_NW * SSB_CH) > 65535) return SS_ERR_UNSUPPORTED;
     if (grad_right && hipMemsetAsync(grad_right, 0, (size_t)B * C * plane * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
     if (grad_pred0 && hipMemsetAsync(grad_pred0, 0, (size_t)total * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
     if (grad_var && hipMemsetAsync(grad_var, 0, (size_t)total * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
@@ -607,7 +640,7 @@ extern "C" int ss_sample_strength_bwd_ws(const float* left, const float* right, 
     hipLaunchKernelGGL(ssb_dcorr_kernel, dim3(gx), dim3(64 * SSB_NW), 0, st, left, right, pred0, var, gamma, beta, grad_strength, work, grad_var,
                        grad_gamma_beta, C, H, W, half_w, half_h, total);
     if (grad_left || grad_right || grad_pred0)
-        hipLaunchKernelGGL(ssb_scatter_kernel, dim3(gx, ss::ceil_div(C, SSB_NW)), dim3(64 * SSB_NW), 0, st, left, right, pred0, work, grad_left,
+        hipLaunchKernelGGL(ssb_scatter_kernel, dim3(gx, ss::ceil_div(C, SSB_NW * SSB_CH)), dim3(64 * SSB_NW), 0, st, left, right, pred0, work, grad_left,
                            grad_right, grad_pred0, C, H, W, half_w, half_h, total);
     return ss::check_launch();
 }

@@ -144,6 +144,44 @@ __device__ __forceinline__ void lds_owned_add2(int* tag, unsigned k, bool take, 
         }
     }
 }
+// ... into the same slot of N rows `stride` floats apart (rows 0 .. nlive - 1 written; nlive wave-uniform)
+template <int N>
+__device__ __forceinline__ void lds_owned_addn(int* tag, unsigned k, bool take, float* row0, int stride, const float (&v)[N], int nlive) {
+    const int me = (int)__lane_id();
+    bool pending = take;
+    if (nlive == N) {                                      // (kept apart: every `n < nlive` below is a scalar branch otherwise)
+        while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+            if (pending) {
+                ((lds_vi_t)tag)[k] = me;
+                const int won = ((lds_vi_t)tag)[k];
+                float a[N];
+#pragma unroll
+                for (int n = 0; n < N; ++n) a[n] = ((lds_vf_t)(row0 + n * stride))[k];
+                if (won == me) {
+#pragma unroll
+                    for (int n = 0; n < N; ++n) ((lds_vf_t)(row0 + n * stride))[k] = a[n] + v[n];
+                    pending = false;
+                }
+            }
+        }
+        return;
+    }
+    while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+        if (pending) {
+            ((lds_vi_t)tag)[k] = me;
+            const int won = ((lds_vi_t)tag)[k];
+            float a[N];
+#pragma unroll
+            for (int n = 0; n < N; ++n) a[n] = (n < nlive) ? ((lds_vf_t)(row0 + n * stride))[k] : 0.f;
+            if (won == me) {
+#pragma unroll
+                for (int n = 0; n < N; ++n)
+                    if (n < nlive) ((lds_vf_t)(row0 + n * stride))[k] = a[n] + v[n];
+                pending = false;
+            }
+        }
+    }
+}
 __device__ __forceinline__ float lds_get(const float* p) { return *(lds_vf_t)p; }
 __device__ __forceinline__ void lds_put(float* p, float v) { *(lds_vf_t)p = v; }
 

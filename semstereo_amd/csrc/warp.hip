@@ -473,6 +473,97 @@ __global__ __launch_bounds__(64 * WB_WAVES) void warp_bwd_rows_kernel(const floa
     }
 }
 
+// ... and where a row is whole 64-pixel blocks (W % 64 == 0: every shape of the path), pixel block by pixel block: a wave owns 64
+// pixels of row h and WBC_CH channels, and sums all nd candidates' contributions in TWO private windows -- the 64 columns +- WBC_M
+// (enough for |disparity| <= 64 at quarter resolution) of row h and of the one other row its taps reach -- which it then adds to memory
+// once; a tap beyond them goes to memory directly.  The other row is not an exception: the reference's coordinate round trip
+// iy = ((h / half_h - 1) + 1) * half_h leaves iy = h -+ ~1e-5 on most rows (and ix likewise), so a candidate that is an exact integer
+// still has four live taps, two of them in row h + 1 or h - 1 with weights ~1e-5 -- which the row kernel above sends to memory one
+// atomic at a time (ablation r06, profiles/EXPERIMENTS.md F.16: 40 us of this kernel's 167 were its loads and sums, 125 those atomics).
+#ifndef SS_WBC_CH
+#define SS_WBC_CH 4
+#endif
+#ifndef SS_WBC_NW
+#define SS_WBC_NW 4
+#endif
+constexpr int WBC_NW = SS_WBC_NW, WBC_CH = SS_WBC_CH, WBC_M = 64, WBC_RB = 64 + 2 * WBC_M + 2, WBC_RS = WBC_RB + 62, WBC_JU = 2;
+__global__ __launch_bounds__(64 * WBC_NW) void warp_bwd_blocks_kernel(const float* __restrict__ gyw, const float* __restrict__ disp,
+                                                                      float* __restrict__ gy, int C, int H, int W, int nd, float half_w,
+                                                                      float half_h) {
+    __shared__ float rowbuf[WBC_NW][2][WBC_CH][WBC_RS];        // [wave][row h / the other row][channel][column - xb]
+    __shared__ int rowtag[WBC_NW][2][WBC_RS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long plane = (long long)H * W;
+    const long long i = (long long)blockIdx.x * 64 + lane;    // over B * H * W (whole blocks: W % 64 == 0)
+    const int w = (int)(i % W), h = (int)((i / W) % H);
+    const long long b = i / plane, pix = (long long)h * W + w;
+    const int c0 = (blockIdx.y * WBC_NW + wave) * WBC_CH;
+    if (c0 >= C) return;                                      // (wave-uniform; no workgroup barrier in this kernel)
+    const int nlive = min(WBC_CH, C - c0);                    // (wave-uniform)
+    float* rows = &rowbuf[wave][0][0][0];
+    int* tags = &rowtag[wave][0][0];
+#pragma unroll
+    for (int n = 0; n < 2 * WBC_CH; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ss::lds_put(&rows[n * WBC_RS + lane + 64 * k], 0.f);
+    const float* g_p = gyw + (b * C + c0) * nd * plane;
+    float* gp = gy + (b * C + c0) * plane;
+    const int xb = (int)(((long long)blockIdx.x * 64) % W) - WBC_M;      // column of slot 0 of the windows
+    // the rows of the taps (the same for every candidate and lane of this wave): yn = floor(iy) and yn + 1, one of them h
+    const int yn = (int)floorf(ss::mul_rn(((float)h / half_h - 1.0f) + 1.0f, half_h));
+    const int other = (yn == h) ? h + 1 : yn;
+    for (int j0 = 0; j0 < nd; j0 += WBC_JU) {
+        float dv[WBC_JU], gv[WBC_JU][WBC_CH];
+#pragma unroll
+        for (int u = 0; u < WBC_JU; ++u) {
+            const int j = min(j0 + u, nd - 1);
+            dv[u] = disp[(b * nd + j) * plane + pix];
+#pragma unroll
+            for (int n = 0; n < WBC_CH; ++n) gv[u][n] = (n < nlive) ? g_p[((long long)n * nd + j) * plane + pix] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < WBC_JU; ++u) {
+            if (j0 + u >= nd) break;
+            const Taps tp = make_taps(dv[u], h, w, H, W, half_w, half_h);
+            auto add = [&](int o, int row, float wt) {
+                const bool any = o >= 0 && wt != 0.f;
+                if (__builtin_amdgcn_ballot_w64(any) == 0) return;             // (one scalar branch for a tap nobody has)
+                const int r = (row == h) ? 0 : 1;
+                const unsigned k = (unsigned)(o - row * W - xb);               // the tap's column inside the window
+                const bool in_win = any && (row == h || row == other) && k < (unsigned)WBC_RB;
+                float v[WBC_CH];
+#pragma unroll
+                for (int n = 0; n < WBC_CH; ++n) v[n] = wt * gv[u][n];
+                if (__builtin_amdgcn_ballot_w64(any && !in_win) != 0) {        // (beyond the windows: |disparity| > 64, or a row that is neither)
+                    for (int n = 0; n < nlive; ++n)
+                        if (any && !in_win) unsafeAtomicAdd(gp + n * plane + o, v[n]);
+                }
+                ss::lds_owned_addn<WBC_CH>(tags + r * WBC_RS, k, in_win, rows + r * (WBC_CH * WBC_RS), WBC_RS, v, nlive);
+            };
+            // (the row of a tap from its offset: the north pair lies in row yn_t, the south pair below it -- per candidate, not assumed)
+            const int row_n = (tp.o_nw >= 0 ? tp.o_nw : tp.o_ne) / W, row_s = (tp.o_sw >= 0 ? tp.o_sw : tp.o_se) / W;
+            add(tp.o_nw, row_n, tp.w_nw); add(tp.o_ne, row_n, tp.w_ne); add(tp.o_sw, row_s, tp.w_sw); add(tp.o_se, row_s, tp.w_se);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = r == 0 ? h : other;
+        if (row < 0 || row >= H) continue;                    // (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = lane + 64 * k, col = xb + idx;
+            if (idx < WBC_RB && col >= 0 && col < W) {
+#pragma unroll
+                for (int n = 0; n < WBC_CH; ++n) {
+                    const float v = ss::lds_get(&rows[(r * WBC_CH + n) * WBC_RS + idx]);
+                    if (n < nlive && v != 0.f) unsafeAtomicAdd(gp + n * plane + (long long)row * W + col, v);
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_over_candidates_kernel(const float* __restrict__ gxw, float* __restrict__ gx, int nd,
                                                                    long long plane, long long total) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;     // over B*C*H*W
@@ -539,7 +630,10 @@ extern "C" int ss_warp_sampled_bwd(const float* grad_y_warped, const float* grad
         const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
         const long long total = (long long)B * nd * plane, blocks = ss::ceil_div_ll(total, 256);
         if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
-        if (grad_disp == nullptr && W <= 1024 && H <= 65535 && B <= 65535 && ss::ceil_div(C, WB_CC) <= 65535)
+        if (grad_disp == nullptr && W % 64 == 0 && total / nd / 64 <= 0x7fffffffLL && ss::ceil_div(C, WBC_NW * WBC_CH) <= 65535)
+            hipLaunchKernelGGL(warp_bwd_blocks_kernel, dim3((unsigned)(total / nd / 64), ss::ceil_div(C, WBC_NW * WBC_CH)), dim3(64 * WBC_NW), 0, st,
+                               grad_y_warped, disp, grad_y, C, H, W, nd, half_w, half_h);
+        else if (grad_disp == nullptr && W <= 1024 && H <= 65535 && B <= 65535 && ss::ceil_div(C, WB_CC) <= 65535)
             hipLaunchKernelGGL(warp_bwd_rows_kernel, dim3(H, ss::ceil_div(C, WB_CC), B), dim3(64 * WB_WAVES), (size_t)(WB_CC + WB_WAVES) * W * sizeof(float), st,
                                grad_y_warped, disp, grad_y, C, H, W, nd, half_w, half_h);
         else

@@ -121,7 +121,11 @@ elif name in ("stem_gather", "stem_gather_smooth"):     # r05: the same launch w
     stem = M.BasicConv(64, 32, is_3d=True, kernel_size=3, stride=1, padding=1).to(dev).eval()
     cr = R(B, 32, 256, 256)
     if name == "stem_gather":        # 24 of 64 disparities drawn independently per pixel: the least coherent gather
-        smp = torch.rand(B, 64, 256, 256, device=dev).argsort(dim=1)[:, :24].sort(dim=1).values.float() - 32.0
+        smp = torch.rand(B, 64, 256, 256, device=dev).argsort(dim=1)[:, :24].sort(dim=1).values.float() - 32.0    # (independent per pixel: many colliding lanes)
+        if name == "warp_bwd_smooth":   # a band of 24 consecutive candidates around a smooth disparity map: what the top-24 of a trained attention looks like
+            yy, xx = torch.meshgrid(torch.arange(256, device=dev), torch.arange(256, device=dev), indexing="ij")
+            d0 = torch.round(10.0 * torch.sin(xx / 40.0) * torch.cos(yy / 55.0))
+            smp = (d0[None, None] + torch.arange(-12, 12, device=dev).float()[None, :, None, None]).expand(B, 24, 256, 256).contiguous()
     else:                            # a window of 24 around a smooth disparity field: the most coherent one
         yy, xx = torch.meshgrid(torch.arange(256, device=dev), torch.arange(256, device=dev), indexing="ij")
         centre = (12.0 * torch.sin(xx / 40.0) * torch.cos(yy / 55.0)).round()
@@ -160,9 +164,9 @@ elif name in ("conv_s2", "conv_s1", "deconv"):
         sc, sh = torch.rand(cout, device=dev) + 0.5, R(cout) * 0.1
         fn = lambda: M.conv3d_bf16s_hip(x, ws, cout, sc, sh, True, 19, stride=stride)       # noqa: E731
         nbytes = 4.0 * B * (32 * 24 * 256 * 256 + cout * (24 // stride) * (256 // stride) ** 2)
-elif name in ("strength_bwd", "warp_bwd"):     # the two scatter kernels of the training step at 1024^2 (quarter resolution 256 x 256)
+elif name in ("strength_bwd", "strength_bwd_ws", "warp_bwd", "warp_bwd_smooth"):     # the two scatter kernels of the training step at 1024^2 (quarter resolution 256 x 256)
     lib = sa._lib
-    if name == "strength_bwd":          # backward of the 5-candidate probe (models/SemStereo.py:286-293): 128-channel features
+    if name.startswith("strength_bwd"):          # backward of the 5-candidate probe (models/SemStereo.py:286-293): 128-channel features
         fl, fr = R(B, 128, 256, 256), R(B, 128, 256, 256)
         yy, xx = torch.meshgrid(torch.arange(256, device=dev), torch.arange(256, device=dev), indexing="ij")
         p0 = (10.0 * torch.sin(xx / 40.0) * torch.cos(yy / 55.0)).reshape(1, 256, 256).expand(B, 256, 256).contiguous()
@@ -171,10 +175,18 @@ elif name in ("strength_bwd", "warp_bwd"):     # the two scatter kernels of the 
         gl, gr, gp, gv, ggb = torch.empty_like(fl), torch.empty_like(fr), torch.empty_like(p0), torch.empty_like(var), torch.empty(2, device=dev)
         fn = lambda: lib.call("ss_sample_strength_bwd", lib.ptr(fl), lib.ptr(fr), lib.ptr(p0), lib.ptr(var), lib.ptr(gm), lib.ptr(bt), lib.ptr(g),   # noqa: E731
                               lib.ptr(gl), lib.ptr(gr), lib.ptr(gp), lib.ptr(gv), lib.ptr(ggb), B, 128, 256, 256)
+        if name == "strength_bwd_ws":   # the form the training step runs (SS_SSB_TWO_LAUNCHES=1): two launches over a [B,5,H,W] scratch
+            work = torch.empty(B, 5, 256, 256, device=dev)
+            fn = lambda: lib.call("ss_sample_strength_bwd_ws", lib.ptr(fl), lib.ptr(fr), lib.ptr(p0), lib.ptr(var), lib.ptr(gm), lib.ptr(bt), lib.ptr(g),   # noqa: E731
+                                  lib.ptr(gl), lib.ptr(gr), lib.ptr(gp), lib.ptr(gv), lib.ptr(ggb), lib.ptr(work), B, 128, 256, 256)
         nbytes = 4.0 * B * (4 * 128 + 8) * 256 * 256
     else:                               # backward of SpatialTransformer_grid at :316 (32 channels, 24 integer candidates)
         y = R(B, 32, 256, 256)
-        smp = torch.rand(B, 64, 256, 256, device=dev).argsort(dim=1)[:, :24].sort(dim=1).values.float() - 32.0
+        smp = torch.rand(B, 64, 256, 256, device=dev).argsort(dim=1)[:, :24].sort(dim=1).values.float() - 32.0    # (independent per pixel: many colliding lanes)
+        if name == "warp_bwd_smooth":   # a band of 24 consecutive candidates around a smooth disparity map: what the top-24 of a trained attention looks like
+            yy, xx = torch.meshgrid(torch.arange(256, device=dev), torch.arange(256, device=dev), indexing="ij")
+            d0 = torch.round(10.0 * torch.sin(xx / 40.0) * torch.cos(yy / 55.0))
+            smp = (d0[None, None] + torch.arange(-12, 12, device=dev).float()[None, :, None, None]).expand(B, 24, 256, 256).contiguous()
         g = R(B, 32, 24, 256, 256)
         gy = torch.empty_like(y)
         fn = lambda: lib.call("ss_warp_sampled_bwd", lib.ptr(g), None, lib.ptr(y), lib.ptr(smp), None, lib.ptr(gy), None, B, 32, 256, 256, 24)   # noqa: E731
