@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (16 since round 6 (13-15 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (17 since round 6 (13-16 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -110,6 +110,16 @@ int ss_warp_sampled_bwd(const float* grad_y_warped, const float* grad_x_warped, 
  * concat_stem through ss_stem_left_fwd). */
 int ss_concat_sampled_fwd(const float* left, const float* right, const float* disp, const float* att,
                           float* out, int B, int C, int H, int W, int nd, ss_stream_t stream);
+/* (r06, training) Backward of ss_concat_sampled_fwd with both halves: grad_out [B,2C,nd,H,W] -> grad_left [B,C,H,W] (= sum_j att *
+ * grad of the broadcast half), grad_right [B,C,H,W] (the warp's backward on att * grad of the warped half: bilinear taps of
+ * F.grid_sample, zeros padding, align_corners=True as the forward) and grad_att [B,nd,H,W] (= sum_c grad . the ungated volume); any of
+ * the three may be NULL; att may be NULL when grad_att is.  The candidates `disp` are constants (the indices of
+ * models/SemStereo.py:299-305): no gradient.  `margin`: a bound on |disp| the caller expects (a performance hint: taps further away are
+ * added one atomic at a time instead of through the LDS windows; any value gives the same result).  W % 64 == 0 (every
+ * quarter-resolution width of the path), else SS_ERR_UNSUPPORTED: the caller composes ss_warp_sampled_bwd with its own cat / multiply. */
+int ss_concat_sampled_bwd(const float* grad_out, const float* left, const float* right, const float* disp, const float* att,
+                          float* grad_left, float* grad_right, float* grad_att, int B, int C, int H, int W, int nd, int margin,
+                          ss_stream_t stream);
 /* The right (warped) half of the same volume, att[b,j] * warp(right)[b,:,j] (models/SemStereo.py:241-244, 316-318), written
  * PRE-SPLIT for the matrix core: every value as the two fp16 terms of x * 2^(141 - e), 8 channels per 16-byte slot,
  *   xs [B][C/8][2 terms][nd][H][W][8] fp16 (C % 8 == 0, 4 bytes per value: the footprint of the fp32 volume),

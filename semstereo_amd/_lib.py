@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -27,6 +27,7 @@ _SIGNATURES = {
     "ss_warp_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_warp_sampled_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_concat_sampled_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ss_concat_sampled_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ss_concat_sampled_presplit_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ss_conv3d_presplit_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ss_stem_left_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -655,6 +655,158 @@ extern "C" int ss_concat_sampled_fwd(const float* left, const float* right, cons
     return launch<MODE_CONCAT>(left, right, disp, att, out, nullptr, B, C, H, W, nd, ss::as_stream(stream));
 }
 
+// ---- backward of ss_concat_sampled_fwd (training: models/SemStereo.py:316-318, `att_topk * cat(left broadcast, warp(right))`, as ONE
+// pass over the gradient of the volume instead of the backward of a warp, a cat and a multiply: r06, those were 402 MB x 6 of traffic
+// per pair at 1024^2).  The candidates are INDICES (no gradient).  A wave owns 64 pixels of row h and CSB_CH channels; per candidate j:
+//   grad_left[c]   += att[j] * gL[c,j]                                  (registers, one plain store at the end)
+//   grad_att[j]    += sum_c gL[c,j] * left[c] + gR[c,j] * warp(right)[c,j]   (the workgroup's waves meet in LDS once per pair of candidates)
+//   grad_right[c]  <- att[j] * w_tap * gR[c,j] at the four taps           (the two row windows of warp_bwd_blocks_kernel)
+// with gL / gR the two halves of the volume's gradient.  `margin`: the |disparity| the windows cover (a hint: taps beyond go to
+// memory one atomic at a time, still right).
+constexpr int CSB_NW = 4, CSB_CH = 8, CSB_JU = 2;
+__global__ __launch_bounds__(64 * CSB_NW) void concat_sampled_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__ left,
+                                                                         const float* __restrict__ right, const float* __restrict__ disp,
+                                                                         const float* __restrict__ att, float* __restrict__ g_left,
+                                                                         float* __restrict__ g_right, float* __restrict__ g_att, int C,
+                                                                         int H, int W, int nd, float half_w, float half_h, int margin,
+                                                                         int rs, int att_atomic) {
+    extern __shared__ float csb_lds[];   // [NW][2][CH][rs] windows | [NW][2][rs] tags | [2][NW][JU][64] partial grad_att
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* rows = csb_lds + (size_t)wave * (2 * CSB_CH * rs);
+    int* tags = reinterpret_cast<int*>(csb_lds + (size_t)CSB_NW * (2 * CSB_CH * rs)) + (size_t)wave * (2 * rs);
+    float* red = csb_lds + (size_t)CSB_NW * (2 * CSB_CH * rs) + (size_t)CSB_NW * (2 * rs);
+    const int rb = 64 + 2 * margin + 2;                       // live slots of a window
+    const long long plane = (long long)H * W;
+    const long long i = (long long)blockIdx.x * 64 + lane;    // over B * H * W (whole blocks: W % 64 == 0)
+    const int w = (int)(i % W), h = (int)((i / W) % H);
+    const long long b = i / plane, pix = (long long)h * W + w;
+    const int c0 = (blockIdx.y * CSB_NW + wave) * CSB_CH;
+    const int nlive = max(0, min(CSB_CH, C - c0));            // (wave-uniform; 0: the wave only keeps the barriers)
+    for (int k = lane; k < 2 * CSB_CH * rs; k += 64) ss::lds_put(&rows[k], 0.f);
+    const float* gl_p = gvol + (b * 2 * C + c0) * nd * plane;         // gradient of the broadcast half, channel c0
+    const float* gr_p = gvol + (b * 2 * C + C + c0) * nd * plane;     // ... of the warped half
+    const float* rp = right + (b * C + c0) * plane;
+    float* grp = g_right ? g_right + (b * C + c0) * plane : nullptr;
+    const int xb = (int)(((long long)blockIdx.x * 64) % W) - margin;
+    const int yn = (int)floorf(ss::mul_rn(((float)h / half_h - 1.0f) + 1.0f, half_h));
+    const int other = (yn == h) ? h + 1 : yn;
+    float cl[CSB_CH], gcl[CSB_CH];
+#pragma unroll
+    for (int n = 0; n < CSB_CH; ++n) {
+        cl[n] = (n < nlive) ? left[(b * C + c0 + n) * plane + pix] : 0.f;
+        gcl[n] = 0.f;
+    }
+    int par = 0;
+    for (int j0 = 0; j0 < nd; j0 += CSB_JU, par ^= 1) {
+        float dv[CSB_JU], av[CSB_JU], gL[CSB_JU][CSB_CH], gR[CSB_JU][CSB_CH], part[CSB_JU];
+#pragma unroll
+        for (int u = 0; u < CSB_JU; ++u) {
+            const int j = min(j0 + u, nd - 1);
+            dv[u] = disp[(b * nd + j) * plane + pix];
+            av[u] = att ? att[(b * nd + j) * plane + pix] : 1.f;
+#pragma unroll
+            for (int n = 0; n < CSB_CH; ++n) {
+                gL[u][n] = (n < nlive) ? gl_p[((long long)n * nd + j) * plane + pix] : 0.f;
+                gR[u][n] = (n < nlive) ? gr_p[((long long)n * nd + j) * plane + pix] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CSB_JU; ++u) {
+            part[u] = 0.f;
+            if (j0 + u >= nd) continue;
+            const Taps tp = make_taps(dv[u], h, w, H, W, half_w, half_h);
+            const float a = av[u];
+            float s = 0.f;
+#pragma unroll
+            for (int n = 0; n < CSB_CH; ++n) {
+                gcl[n] = fmaf(a, gL[u][n], gcl[n]);
+                const float val = (n < nlive) ? sample(rp + n * plane, tp) : 0.f;       // the forward's warp(right)[c, j]
+                s = fmaf(gL[u][n], cl[n], s);
+                s = fmaf(gR[u][n], val, s);
+            }
+            part[u] = s;
+            if (grp != nullptr) {
+                auto add = [&](int o, int row, float wt) {
+                    const bool any = o >= 0 && wt != 0.f;
+                    if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+                    const int r = (row == h) ? 0 : 1;
+                    const unsigned k = (unsigned)(o - row * W - xb);
+                    const bool in_win = any && (row == h || row == other) && k < (unsigned)rb;
+                    float v[CSB_CH];
+#pragma unroll
+                    for (int n = 0; n < CSB_CH; ++n) v[n] = (a * wt) * gR[u][n];
+                    if (__builtin_amdgcn_ballot_w64(any && !in_win) != 0) {
+                        for (int n = 0; n < nlive; ++n)
+                            if (any && !in_win) unsafeAtomicAdd(grp + n * plane + o, v[n]);
+                    }
+                    ss::lds_owned_addn<CSB_CH>(tags + r * rs, k, in_win, rows + r * (CSB_CH * rs), rs, v, nlive);
+                };
+                const int row_n = (tp.o_nw >= 0 ? tp.o_nw : tp.o_ne) / W, row_s = (tp.o_sw >= 0 ? tp.o_sw : tp.o_se) / W;
+                add(tp.o_nw, row_n, tp.w_nw); add(tp.o_ne, row_n, tp.w_ne); add(tp.o_sw, row_s, tp.w_sw); add(tp.o_se, row_s, tp.w_se);
+            }
+        }
+        if (g_att != nullptr) {          // (kernel-uniform) the waves' partial sums over their channels -> one value per (candidate, pixel)
+#pragma unroll
+            for (int u = 0; u < CSB_JU; ++u) red[((par * CSB_NW + wave) * CSB_JU + u) * 64 + lane] = part[u];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int u = 0; u < CSB_JU; ++u) {
+                    if (j0 + u >= nd) continue;
+                    float t = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < CSB_NW; ++wv) t += red[((par * CSB_NW + wv) * CSB_JU + u) * 64 + lane];
+                    float* dst = g_att + (b * nd + j0 + u) * plane + pix;
+                    if (att_atomic) unsafeAtomicAdd(dst, t); else *dst = t;
+                }
+            }
+        }
+    }
+    if (g_left != nullptr) {
+#pragma unroll
+        for (int n = 0; n < CSB_CH; ++n)
+            if (n < nlive) g_left[(b * C + c0 + n) * plane + pix] = gcl[n];
+    }
+    if (grp == nullptr) return;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = r == 0 ? h : other;
+        if (row < 0 || row >= H) continue;                    // (wave-uniform)
+        for (int idx = lane; idx < rb; idx += 64) {
+            const int col = xb + idx;
+            if (col < 0 || col >= W) continue;
+#pragma unroll
+            for (int n = 0; n < CSB_CH; ++n) {
+                const float v = ss::lds_get(&rows[(r * CSB_CH + n) * rs + idx]);
+                if (n < nlive && v != 0.f) unsafeAtomicAdd(grp + n * plane + (long long)row * W + col, v);
+            }
+        }
+    }
+}
+
+extern "C" int ss_concat_sampled_bwd(const float* grad_out, const float* left, const float* right, const float* disp, const float* att,
+                                     float* grad_left, float* grad_right, float* grad_att, int B, int C, int H, int W, int nd, int margin,
+                                     ss_stream_t stream) {
+    SS_REQUIRE(grad_out && left && right && disp && B > 0 && C > 0 && H > 0 && W > 0 && nd > 0 && margin >= 0);
+    SS_REQUIRE(grad_att == nullptr || att != nullptr);
+    if (W % 64 != 0 || (long long)B * H * W / 64 > 0x7fffffffLL || ss::ceil_div(C, CSB_NW * CSB_CH) > 65535) return SS_ERR_UNSUPPORTED;
+    hipStream_t st = ss::as_stream(stream);
+    const long long plane = (long long)H * W;
+    margin = std::min(margin, 96);
+    const int rs = 64 + 2 * margin + 2 + 6;                   // (+ 6: the row stride off the 32-bank period)
+    const size_t lds = ((size_t)CSB_NW * 2 * CSB_CH * rs + (size_t)CSB_NW * 2 * rs + (size_t)2 * CSB_NW * CSB_JU * 64) * sizeof(float);
+    if (lds > 160 * 1024) return SS_ERR_UNSUPPORTED;
+    const int gy = ss::ceil_div(C, CSB_NW * CSB_CH);
+    if (grad_right && hipMemsetAsync(grad_right, 0, (size_t)B * C * plane * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    if (grad_att && gy > 1 && hipMemsetAsync(grad_att, 0, (size_t)B * nd * plane * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
+    const float half_w = (float)((W - 1.0) / 2.0), half_h = (float)((H - 1.0) / 2.0);
+    if (lds > 64 * 1024 && ss::ensure_dynamic_lds(reinterpret_cast<const void*>(concat_sampled_bwd_kernel), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
+    hipLaunchKernelGGL(concat_sampled_bwd_kernel, dim3((unsigned)((long long)B * plane / 64), gy), dim3(64 * CSB_NW), lds, st, grad_out, left,
+                       right, disp, att, grad_left, grad_right, grad_att, C, H, W, nd, half_w, half_h, margin, rs, gy > 1 ? 1 : 0);
+    return ss::check_launch();
+}
+
 // The warped half of `att * cat(left broadcast, warp(right))` (models/SemStereo.py:241-244, 316-318) in the pre-split operand
 // form of ss_conv3d_presplit_fwd: xs [B][C/8][nd][H][W][2][8] fp16 (C % 8 == 0), xexp int[3 * B]: [0, B) the block exponents,
 // [B, 3B) scratch of the maxima.  att may be NULL.

@@ -280,9 +280,14 @@ class HotSegment(nn.Module):
         else:
             cl = self.concat_feature(fl4)                                                      # :314
             cr = self.concat_feature(fr4)                                                      # :315
-            right_w, left_b = ops.SpatialTransformer_grid(cl, cr, samples)                     # :241-242 (concat_volume_generator)
-            volume = torch.cat((left_b, right_w), dim=1)                                       # :243
-            volume = att_topk * volume                                                         # :318
+            if (getattr(self, "FUSED", HotSegment.FUSED) and torch.is_grad_enabled() and isinstance(att_topk, torch.Tensor)
+                    and isinstance(samples, torch.Tensor) and isinstance(cl, torch.Tensor) and T.concat_volume_applies(cl, cr, samples, att_topk)):
+                # training (r06): :316-318 as one launch each way instead of a warp, a cat and a multiply and their three backwards
+                volume = T.concat_volume_sampled(cl, cr, samples, att_topk, margin=max(self.maxdisp // 4, 1))
+            else:
+                right_w, left_b = ops.SpatialTransformer_grid(cl, cr, samples)                 # :241-242 (concat_volume_generator)
+                volume = torch.cat((left_b, right_w), dim=1)                                   # :243
+                volume = att_topk * volume                                                     # :318
             volume = self.concat_stem(volume)                                                  # :319
             volume = self.concat_feature_att_4(volume, fl4)                                    # :320
         cost = self.hourglass(volume)                                                          # :321

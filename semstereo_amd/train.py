@@ -497,3 +497,60 @@ def attention_tail(cost_att, left, right, gamma, beta, rng, H, W, k):
     strength = _SampleStrength.apply(left, right, pred0, var, gamma, beta)
     att_topk, samples, pred_att = _TopkCandidates.apply(att_weights, strength, k, tuple(rng))
     return att_topk, samples, pred_att, pred0
+
+
+# ---- the sparse concat volume (models/SemStereo.py:316-318) -------------------------------------------------------------------------
+
+CONCAT_VOLUME_FUSED = os.environ.get("SS_TRAIN_CONCAT_FUSED", "1") != "0"
+
+
+class _ConcatVolumeSampled(torch.autograd.Function):
+    """att_topk * cat(left broadcast over the candidates, warp(right) at the candidates) -- concat_volume_generator + the multiply of
+    models/SemStereo.py:241-244, 316-318 -- as one forward launch (ss_concat_sampled_fwd, the inference kernel) and one backward launch
+    (ss_concat_sampled_bwd): gradients to left, right and att; the candidates are indices (models/SemStereo.py:299-305: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, left, right, samples, att, margin):
+        left, right, samples = _c(left), _c(right), _c(samples)
+        B, C, H, W = right.shape
+        nd = samples.shape[1]
+        att4 = _c(att.reshape(B, nd, H, W))
+        out = torch.empty((B, 2 * C, nd, H, W), dtype=torch.float32, device=right.device)
+        with torch.cuda.device(right.device):
+            call("ss_concat_sampled_fwd", ptr(left), ptr(right), ptr(samples), ptr(att4), ptr(out), B, C, H, W, nd)
+        ctx.save_for_backward(left, right, samples, att4)
+        ctx.att_shape, ctx.margin = tuple(att.shape), int(margin)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        left, right, samples, att4 = ctx.saved_tensors
+        g = _c(g)
+        B, C, H, W = right.shape
+        nd = samples.shape[1]
+        gl = torch.empty_like(left) if ctx.needs_input_grad[0] else None
+        gr = torch.empty_like(right) if ctx.needs_input_grad[1] else None
+        ga = torch.empty_like(att4) if ctx.needs_input_grad[3] else None
+        with torch.cuda.device(right.device):
+            call("ss_concat_sampled_bwd", ptr(g), ptr(left), ptr(right), ptr(samples), ptr(att4), ptr(gl), ptr(gr), ptr(ga), B, C, H, W, nd, ctx.margin)
+        return gl, gr, None, None if ga is None else ga.reshape(ctx.att_shape), None
+
+
+def concat_volume_applies(left, right, samples, att):
+    """The one-launch form under autograd: fp32 HIP maps whose rows are whole 64-pixel blocks (every quarter-resolution width of the
+    path), candidates that need no gradient, one gate per (candidate, pixel)."""
+    if not (CONCAT_VOLUME_FUSED and _on(left) and _on(right) and _on(samples) and _on(att)):
+        return False
+    if samples.requires_grad or left.dim() != 4 or left.shape != right.shape or samples.dim() != 4:
+        return False
+    B, C, H, W = right.shape
+    nd = samples.shape[1]
+    return (W % 64 == 0 and tuple(samples.shape) == (B, nd, H, W) and att.numel() == B * nd * H * W and att.shape[0] == B
+            and tuple(att.shape[-3:]) == (nd, H, W) and (B * H * W) // 64 < 2 ** 31)
+
+
+def concat_volume_sampled(left, right, samples, att, margin=64):
+    """models/SemStereo.py:316-318 under autograd -> [B, 2C, nd, H, W].  `margin`: the |candidate| the backward's LDS windows cover
+    (maxdisp / 4 of the caller: a hint, larger shifts are still summed, one atomic at a time)."""
+    _count("hip_train")
+    return _ConcatVolumeSampled.apply(left, right, samples, att, margin)

@@ -1843,6 +1843,41 @@ def test_backward_warp_onto_the_features_alone_row_by_row(sa, name):
     check(f"bwd/warp_rows/{name}/y", gh[1], go[1], 1e-5, 2e-6)              # sums in another order
 
 
+@pytest.mark.parametrize("case", [
+    # (B, C, H, W, nd, kind, margin)
+    (1, 32, 6, 64, 24, "int", 16),          # the live form: 32 concat channels, 24 integer candidates
+    (2, 12, 5, 128, 6, "int", 16),          # a wave with 4 of its 8 channels, batch 2
+    (1, 40, 4, 64, 5, "frac", 64),          # two channel groups on the grid (grad_att through atomics), fractional candidates: four taps, two rows
+    (1, 8, 7, 192, 24, "int", 2),           # candidates far outside the windows' margin: every tap the long way
+    (1, 16, 1, 64, 3, "frac", 8),           # H == 1
+])
+def test_concat_volume_training_one_launch_each_way(sa, case):
+    """models/SemStereo.py:316-318 under autograd (r06): `att_topk * cat(left broadcast, warp(right))` as ss_concat_sampled_fwd +
+    ss_concat_sampled_bwd -- gradients to the left map (sum over the candidates), to the right map (the warp's bilinear scatter, summed
+    in LDS windows of the two rows the taps reach) and to att (the ungated volume dotted with the gradient) -- against CPU autograd
+    through the oracle's restatement of the reference's three statements."""
+    from oracle import detdata as dd
+    B, C, H, W, nd, kind, margin = case
+    left, right = dd.t_normalish((B, C, H, W), 881), dd.t_normalish((B, C, H, W), 882)
+    d = dd.distinct_sorted_candidates(B, nd, H, W, max(nd, 20), 883) if kind == "int" else dd.t_uniform((B, nd, H, W), 883, -20.0, 20.0)
+    att = dd.t_uniform((B, 1, nd, H, W), 884, 0.0, 1.0)
+    seed = dd.t_normalish((B, 2 * C, nd, H, W), 885)
+    T = sa.train
+    assert T.concat_volume_applies(dev(left), dev(right), dev(d), dev(att))
+    xs = [dev(t).clone().requires_grad_(True) for t in (left, right, att)]
+    vol = T.concat_volume_sampled(xs[0], xs[1], dev(d), xs[2], margin=margin)
+    (vol * dev(seed)).sum().backward()
+    # (fp32 on the CPU, as test_backward_warp_and_topk_in_hip: the coordinate round trip of grid_sample is part of the function --
+    # in fp32 an integer candidate leaves ix = integer -+ ~1e-5 and so four live taps; float64 would not)
+    rs = [t.clone().requires_grad_(True) for t in (left, right, att)]
+    right_w, left_b = oops.SpatialTransformer_grid(rs[0], rs[1], d)
+    ref = rs[2] * torch.cat((left_b, right_w), dim=1)
+    (ref * seed).sum().backward()
+    check(f"train/concat_volume/{case}/fwd", vol, ref, 2e-6, 2e-6)
+    for name, a_, r_ in zip(("left", "right", "att"), xs, rs):
+        check(f"train/concat_volume/{case}/grad_{name}", a_.grad, r_.grad, 1e-5, 3e-6)
+
+
 CONV_TRAIN_CASES = [
     # (B, Cin, Cout, D, H, W, stride)
     (2, 32, 32, 4, 10, 36, 1),
