@@ -256,25 +256,29 @@ __global__ __launch_bounds__(256) void gate_bwd_logits_kernel(const float* __res
 // ---- windowed attention core, backward (models/submodule_other.py:805-834) ------------------------------------------------------
 // qkv [B,3C,D,H,W] (C = heads * 8), gy [B,C,D,H,W] = gradient of y = softmax(q k^T * scale [+ pad mask]) v per (window, head),
 // un-partitioned.  -> gqkv [B,3C,D,H,W].  One workgroup per (window, head): q, k, v, gy tiles [T][8] and the probabilities
-// [T][T] in LDS.
+// [T][T] (then, in place, the logits' gradient) in LDS.
 // Volumes whose H, W are not window multiples (r04): the reference zero-pads the volume BEFORE the qkv Linear
 // (models/submodule_other.py:808-813), so a pad token's q / k / v are the Linear's bias -- `bqkv` [3C] here, the qkv tensor
 // holds real positions only -- its output is cropped (gradient 0), and a logit between a pad and a real token gets -1000 when
 // BOTH H and W were padded (`mask_on`; the reference's `-0:` slices mark every token when only one was, :822-823: no mask).
 // What reaches a pad token's q / k / v is the bias's gradient: accumulated into gbias [3C] (fp32 atomics).
+// (r06: one [T][T] array instead of two -- 51 KB of LDS, three workgroups per CU instead of one -- and the soft-max rows spread over the
+// lanes: a half-wave owns a row, its lanes the columns j = l, l + 32, ...; the row's probabilities, dP = go v^T and their dot stay in
+// registers between the passes.  The first form walked each row with ONE thread, 96 of 256 threads, four serial passes: 509 us at the
+// 1024^2 / md64 training shape against 46 for the forward.)
 template <int T>
 __global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bqkv,
                                                                          const float* __restrict__ gy, float* __restrict__ gqkv,
                                                                          float* __restrict__ gbias, int C, int D, int H, int W,
                                                                          int heads, int bd, int bh, int bw, float scale, int mask_on) {
-    constexpr int HD = 8;
-    extern __shared__ __attribute__((aligned(16))) float sm_att[];          // 4 x [T][9] + 2 x [T][T + 1] floats (88 KB at T = 96)
+    constexpr int HD = 8, NJ = T / 32, ROWS = T / 8;          // columns per lane of a row; rows per half-wave (8 half-waves)
+    static_assert(T % 32 == 0, "a row is whole 32-lane passes");
+    extern __shared__ __attribute__((aligned(16))) float sm_att[];          // 4 x [T][9] + [T][T + 1] floats (51 KB at T = 96)
     float (*q)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(sm_att);
     float (*k)[HD + 1] = q + T;
     float (*v)[HD + 1] = k + T;
     float (*go)[HD + 1] = v + T;
-    float (*P)[T + 1] = reinterpret_cast<float (*)[T + 1]>(sm_att + 4 * T * (HD + 1));
-    float (*dS)[T + 1] = P + T;
+    float (*A)[T + 1] = reinterpret_cast<float (*)[T + 1]>(sm_att + 4 * T * (HD + 1));     // P, then dS in place
     __shared__ unsigned char is_pad[T];
     const int head = blockIdx.y, b = blockIdx.z;
     const int nw = (W + bw - 1) / bw, nh = (H + bh - 1) / bh;
@@ -290,8 +294,9 @@ __global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const fl
         return (long long)(wd * bd + td) * plane + (long long)gh * W + gw;
     };
     const float* qb = qkv + (long long)b * 3 * C * vol;
+    // (token-major over the lanes: consecutive lanes read consecutive tokens of one channel plane)
     for (int e = threadIdx.x; e < T * HD; e += 256) {
-        const int t = e / HD, j = e % HD;
+        const int t = e % T, j = e / T;
         bool in;
         const long long p = pos(t, in);
         const int ch = head * HD + j;
@@ -302,34 +307,73 @@ __global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const fl
         if (j == 0) is_pad[t] = in ? 0 : 1;
     }
     __syncthreads();
-    // P = softmax(q k^T * scale + mask) row-wise; dP = go v^T
-    for (int e = threadIdx.x; e < T * T; e += 256) {
-        const int i = e / T, j = e % T;
-        float s = 0.f, dp = 0.f;
+    // pass A, row by row: P = softmax(q k^T * scale + mask), dP = go v^T, dot = sum_j P dP
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    float pr[ROWS][NJ], dpr[ROWS][NJ], dot[ROWS];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) { s += q[i][c] * k[j][c]; dp += go[i][c] * v[j][c]; }
-        P[i][j] = s * scale + ((mask_on && is_pad[i] != is_pad[j]) ? -1000.0f : 0.f);
-        dS[i][j] = dp;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < T; i += 256) {
-        float mx = -INFINITY;
-        for (int j = 0; j < T; ++j) mx = fmaxf(mx, P[i][j]);
+    for (int it = 0; it < ROWS; ++it) {
+        const int i = hw + 8 * it;
+        float qi[HD], gi[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { qi[c] = q[i][c]; gi[c] = go[i][c]; }
+        float sv[NJ], mx = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = l + 32 * jj;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) { s += qi[c] * k[j][c]; dp += gi[c] * v[j][c]; }
+            sv[jj] = s * scale + ((mask_on && is_pad[i] != is_pad[j]) ? -1000.0f : 0.f);
+            dpr[it][jj] = dp;
+            mx = fmaxf(mx, sv[jj]);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float sum = 0.f;
-        for (int j = 0; j < T; ++j) { const float e_ = expf(P[i][j] - mx); P[i][j] = e_; sum += e_; }
-        float dot = 0.f;
-        for (int j = 0; j < T; ++j) { P[i][j] /= sum; dot += P[i][j] * dS[i][j]; }
-        for (int j = 0; j < T; ++j) dS[i][j] = P[i][j] * (dS[i][j] - dot) * scale;       // d(logits before scale)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) { sv[jj] = expf(sv[jj] - mx); sum += sv[jj]; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        float dt = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const float pv = sv[jj] / sum;
+            pr[it][jj] = pv;
+            A[i][l + 32 * jj] = pv;
+            dt += pv * dpr[it][jj];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dt += __shfl_xor(dt, o);
+        dot[it] = dt;
     }
     __syncthreads();
+    // dv = P^T go (P column-wise)
     float* gb = gqkv + (long long)b * 3 * C * vol;
     for (int e = threadIdx.x; e < T * HD; e += 256) {
-        const int t = e / HD, c = e % HD;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
+        const int t = e % T, c = e / T;
+        float dv = 0.f;
+        for (int j = 0; j < T; ++j) dv += A[j][t] * go[j][c];
+        bool in;
+        const long long p = pos(t, in);
+        const int ch = head * HD + c;
+        if (in) gb[(long long)(2 * C + ch) * vol + p] = dv;
+        else if (gbias != nullptr) unsafeAtomicAdd(&gbias[2 * C + ch], dv);
+    }
+    __syncthreads();
+    // pass B, in place: dS = P (dP - dot) * scale        (the gradient of the logits before the scale)
+#pragma unroll
+    for (int it = 0; it < ROWS; ++it) {
+        const int i = hw + 8 * it;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) A[i][l + 32 * jj] = pr[it][jj] * (dpr[it][jj] - dot[it]) * scale;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * HD; e += 256) {
+        const int t = e % T, c = e / T;
+        float dq = 0.f, dk = 0.f;
         for (int j = 0; j < T; ++j) {
-            dq += dS[t][j] * k[j][c];
-            dk += dS[j][t] * q[j][c];
-            dv += P[j][t] * go[j][c];
+            dq += A[t][j] * k[j][c];
+            dk += A[j][t] * q[j][c];
         }
         bool in;
         const long long p = pos(t, in);
@@ -337,11 +381,9 @@ __global__ __launch_bounds__(256) void window_attention_core_bwd_kernel(const fl
         if (in) {
             gb[(long long)ch * vol + p] = dq;
             gb[(long long)(C + ch) * vol + p] = dk;
-            gb[(long long)(2 * C + ch) * vol + p] = dv;
         } else if (gbias != nullptr) {
             unsafeAtomicAdd(&gbias[ch], dq);
             unsafeAtomicAdd(&gbias[C + ch], dk);
-            unsafeAtomicAdd(&gbias[2 * C + ch], dv);
         }
     }
 }
@@ -541,7 +583,7 @@ static int window_attention_core_bwd_impl(const float* qkv, const float* bqkv, c
     if (grad_bias != nullptr && hipMemsetAsync(grad_bias, 0, (size_t)3 * C * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;
     const int mask_on = ((H % bh) != 0 && (W % bw) != 0) ? 1 : 0;       // the reference masks only when BOTH were padded (see the kernel)
     const dim3 grid((unsigned)windows, heads, B);
-    const size_t lds = (size_t)(4 * T * 9 + 2 * T * (T + 1)) * sizeof(float);
+    const size_t lds = (size_t)(4 * T * 9 + T * (T + 1)) * sizeof(float);
     if (T == 64) {
         auto kern = window_attention_core_bwd_kernel<64>;
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds) != SS_OK) return SS_ERR_LAUNCH;
