@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (17 since round 6 (13-16 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (18 since round 6 (13-17 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -464,6 +464,12 @@ int ss_batchnorm_train_fwd_rs(const float* x, const float* residual, const float
 int ss_batchnorm_bwd_pg(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
                         const float* weight, float* grad_x, float* grad_residual, double* work, float* grad_weight, float* grad_bias,
                         int batch_statistics, int B, int C, long long N, int relu, ss_stream_t stream);
+/* (r06, training) The normalisation of groupwise_correlation_norm (models/submodule.py:213-222), once per feature map:
+ * y = x / (||x||_2 over each group's C / groups channels + eps), x [B,C,H,W]; and its backward (grad_x from grad_y and x).  The
+ * volume is then built from the normalised maps by ss_gwc_volume_fwd / _bwd. */
+int ss_group_normalise_fwd(const float* x, float* y, int B, int C, int H, int W, int groups, float eps, ss_stream_t stream);
+int ss_group_normalise_bwd(const float* grad_y, const float* x, float* grad_x, int B, int C, int H, int W, int groups, float eps,
+                           ss_stream_t stream);
 /* Weight gradient of the 1x1(x1) convolutions (redir1 / redir2 `models/SemStereo.py:131-132`, attention_block.qkv_3d /
  * final1x1 `models/submodule_other.py:799-800`, channelAtt.im_att `models/SemStereo.py:92-95`):
  * grad_out [B,Cout,npos], in [B,Cin,npos] -> grad_w [Cout,Cin]. */

@@ -554,6 +554,52 @@ extern "C" int ss_depthwise_patch_wgrad_fwd(const float* grad_out, const float* 
     return ss::check_launch();
 }
 
+// ---- the group normalisation of groupwise_correlation_norm (models/submodule.py:213-222: fea / (torch.norm(fea, 2, 2, True) + 1e-05) over
+// each group's channels), once per feature map, forward and backward (training: the volume kernel then runs un-normalised with its own
+// backward; r06: torch's norm / add / div and their three backward nodes were 12 launches per step) ----
+// one thread per (b, group, pixel): y_c = x_c / (n + eps), n = sqrt(sum_c x_c^2);
+// backward: gx_k = gy_k / (n + eps) - x_k * (sum_c gy_c x_c) / ((n + eps)^2 n)   (0 for the second term where n == 0, as torch's norm backward)
+template <bool BWD>
+__global__ __launch_bounds__(256) void group_normalise_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ out,
+                                                               int C, int cg, long long plane, long long total, float eps) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // over B * groups * plane
+    if (i >= total) return;
+    const long long pix = i % plane, bg = i / plane;                      // bg = b * groups + g: channel base bg * cg
+    const float* xp = x + bg * cg * plane + pix;
+    float ss2 = 0.f, dot = 0.f;
+    for (int c = 0; c < cg; ++c) {
+        const float v = xp[c * plane];
+        ss2 = fmaf(v, v, ss2);
+        if (BWD) dot = fmaf(gy[bg * cg * plane + pix + c * plane], v, dot);
+    }
+    const float n = sqrtf(ss2), inv = 1.0f / (n + eps);
+    const float k2 = (BWD && n > 0.f) ? dot * inv * inv / n : 0.f;
+    float* op = out + bg * cg * plane + pix;
+    for (int c = 0; c < cg; ++c) {
+        const float v = xp[c * plane];
+        op[c * plane] = BWD ? gy[bg * cg * plane + pix + c * plane] * inv - v * k2 : v * inv;
+    }
+}
+
+extern "C" int ss_group_normalise_fwd(const float* x, float* y, int B, int C, int H, int W, int groups, float eps, ss_stream_t stream) {
+    SS_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0);
+    const long long plane = (long long)H * W, total = (long long)B * groups * plane, blocks = ss::ceil_div_ll(total, 256);
+    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(group_normalise_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ss::as_stream(stream), x, nullptr, y, C, C / groups, plane,
+                       total, eps);
+    return ss::check_launch();
+}
+
+extern "C" int ss_group_normalise_bwd(const float* grad_y, const float* x, float* grad_x, int B, int C, int H, int W, int groups, float eps,
+                                      ss_stream_t stream) {
+    SS_REQUIRE(grad_y && x && grad_x && B > 0 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0);
+    const long long plane = (long long)H * W, total = (long long)B * groups * plane, blocks = ss::ceil_div_ll(total, 256);
+    if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(group_normalise_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ss::as_stream(stream), x, grad_y, grad_x, C, C / groups,
+                       plane, total, eps);
+    return ss::check_launch();
+}
+
 // channelAtt gate (models/SemStereo.py:101-102), gradient of the logits: grad_att [B,C,H,W] = s (1 - s) * sum_d grad_out * cv
 extern "C" int ss_channel_gate_bwd_logits(const float* grad_out, const float* cv, const float* att_logits, float* grad_att, int B, int C,
                                           int D, int H, int W, ss_stream_t stream) {

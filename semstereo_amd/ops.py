@@ -73,11 +73,40 @@ def _check_pair(a, b, groups=None):
         assert a.shape[1] % groups == 0
 
 
+class _GroupNormalise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, groups):
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            call("ss_group_normalise_fwd", ptr(x), ptr(y), B, C, H, W, groups, 1e-05)
+        ctx.save_for_backward(x)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _c(g)
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            call("ss_group_normalise_bwd", ptr(g), ptr(x), ptr(gx), B, C, H, W, ctx.groups, 1e-05)
+        return gx, None
+
+
 def _group_normalise(x, groups):
-    """x / (||x||_2 over each group's channels + 1e-5) with differentiable torch ops (training path)."""
+    """x / (||x||_2 over each group's channels + 1e-5), differentiable (training path): one HIP launch each way for fp32 device maps
+    (ss_group_normalise_fwd / _bwd), torch ops otherwise."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and GROUP_NORMALISE_HIP:
+        return _GroupNormalise.apply(x, int(groups))
     B, C, H, W = x.shape
     v = x.reshape(B, groups, C // groups, H, W)
     return (v / (torch.linalg.vector_norm(v, 2, dim=2, keepdim=True) + 1e-05)).reshape(B, C, H, W)
+
+
+GROUP_NORMALISE_HIP = True
 
 
 @dfr.realising
