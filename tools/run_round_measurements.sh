@@ -20,6 +20,8 @@ for k in stem_gather deconv conv_s2 wgrad; do timeout 300 bash tools/pmc_sq.sh $
 # r06: the training step at the size the reference trains at -- ms per step by batch, then a rocprofv3 kernel trace of it
 timeout 400 python tools/bench_train.py --batches 1,2,4 --out $o/${tag}_bench_train.json > /dev/null 2>&1
 timeout 300 bash tools/profile_train.sh ${tag} 1 > /dev/null 2>&1
+timeout 300 bash tools/profile_train.sh ${tag}_b4 4 > /dev/null 2>&1
+timeout 300 python tools/train_glue_sources.py > $o/${tag}_glue_sources.txt 2>&1
 timeout 600 python bench.py --steps 20 --warmup 5 --detail $o/${tag}_bench_detail_k20.json > $o/${tag}_bench_k20.json 2> /dev/null     # the driver's form
 timeout 900 python bench.py --detail $o/${tag}_bench_detail_b1.json > $o/${tag}_bench_b1.json 2> $o/${tag}_bench_b1.err
 timeout 300 python bench.py --batch 4 --side-config-steps 0 --train-steps 0 --no-cpu-baseline --no-other-engines --no-side-rooflines --detail /tmp/d4.json > $o/${tag}_bench_b4.json 2>/dev/null
@@ -28,7 +30,7 @@ timeout 300 python bench.py --height 2048 --width 2048 --maxdisp 192 --no-cpu-ba
 timeout 300 bash tools/profile_step.sh ${tag} > /dev/null 2>&1
 timeout 600 python tools/strict_report.py f1024_md128_cal f1024_md128_cal_b f1024_md128_cal_c f2048_md192_cal f1024_md128 > $o/${tag}_strict_report.txt 2>/dev/null
 timeout 600 python tools/err_stages.py > $o/${tag}_err_stages.txt 2>/dev/null
-for k in stem_gather stem_left strength ssr ssr2048 topk upsoft patch gwc_fused head_cl catt4 catt8 deconv deconv5 deconv_att6 deconv_att5 conv_s2 conv_mid conv_low attn wgrad wgrad_stem wgrad_mid wgrad_low wgrad_s2 wgrad_head; do timeout 120 python tools/run_kernel.py $k 1 20 2>/dev/null | tail -1; done > $o/${tag}_ops_b1.txt
+for k in stem_gather stem_left strength ssr ssr2048 topk upsoft patch gwc_fused head_cl catt4 catt8 deconv deconv5 deconv_att6 deconv_att5 conv_s2 conv_mid conv_low attn wgrad wgrad_stem wgrad_mid wgrad_low wgrad_s2 wgrad_head strength_bwd_ws warp_bwd_smooth warp_bwd; do timeout 120 python tools/run_kernel.py $k 1 20 2>/dev/null | tail -1; done > $o/${tag}_ops_b1.txt
 tail -3 $o/${tag}_tests.log
 python - <<PY
 import json
