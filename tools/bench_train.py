@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--maxdisp", type=int, default=64)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--warmup-seconds", type=float, default=1.5, help="keep warming up at least this long per batch size (r06: the first size "
+                    "timed in a fresh process came out at 27-34 ms instead of 15 now and then -- six steps are 0.1 s, less than the part takes "
+                    "to leave its idle power state)")
     ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam's default (foreach) implementation instead of fused=True")
     ap.add_argument("--no-checks", action="store_true", help="skip the determinism / eval-comparison passes (profiling runs)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_train.json"))
@@ -146,8 +149,12 @@ def main():
                 return loss
 
             torch.cuda.reset_peak_memory_stats()
-            for _ in range(args.warmup):
+            n_warm, t_w = 0, time.perf_counter()
+            while n_warm < args.warmup or (time.perf_counter() - t_w) < args.warmup_seconds:
                 step()
+                n_warm += 1
+                if n_warm % 4 == 0:
+                    torch.cuda.synchronize()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
@@ -161,7 +168,7 @@ def main():
             assert sa.modules.PATH_COUNTS["torch"] == before["torch"], "a PyTorch layer ran inside the 3-D stack"
             rec.update({"ms_per_step": ms, "pairs_per_s": 1e3 * B / ms, "host_wall_ms_per_step": 1e3 * wall / args.steps,
                         "peak_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,
-                        "hip_train_calls_per_step": (sa.modules.PATH_COUNTS.get("hip_train", 0) - before.get("hip_train", 0)) / (args.warmup + args.steps),
+                        "hip_train_calls_per_step": (sa.modules.PATH_COUNTS.get("hip_train", 0) - before.get("hip_train", 0)) / (n_warm + args.steps),
                         "loss": float(loss),
                         # forward + data gradient + weight gradient of every 3x3x3 layer: 3 x the forward's flops (fp32-equivalent)
                         "fp32_equivalent_tflops_3x3x3": 3.0 * flops_fwd * B / (ms * 1e-3) / 1e12})

@@ -85,6 +85,26 @@ def main():
         rec[0] += 1
         rec[1] += dt
         rec[2][e.name] += 1
+    # hipMemcpyAsync / hipMemsetAsync issued by the step (the C entry points' own zero-fills, torch's contiguous copy_ and clone): not
+    # kernels in the profiler's eyes, but each is a 4 us launch on the stream all the same -- by the node they were issued under
+    runtime = collections.defaultdict(collections.Counter)
+    for e in events:
+        if "Memcpy" not in e.name and "Memset" not in e.name:
+            continue
+        if e.device_type != torch.autograd.DeviceType.CPU:
+            continue
+        p = e.cpu_parent
+        chain = []
+        while p is not None:
+            chain.append(p.name)
+            p = p.cpu_parent
+        node = next((c for c in chain if "Backward" in c or c.startswith("_") or "Optimizer" in c), None) or (chain[0] if chain else "?")
+        inner = next((c for c in chain if c.startswith("aten::")), "")
+        runtime[e.name][f"{node} {inner}".strip()] += 1
+    for name, ctr in runtime.items():
+        print(f"{name}: {sum(ctr.values())} calls in the step; by node:")
+        for node, n in ctr.most_common(14):
+            print(f"    {n:5d}  {node}")
     print(f"{n_leaf} launching aten ops in one step at batch {B}; by source (launches, device us, ops):")
     for src, (n, dt, ops) in sorted(by_src.items(), key=lambda kv: -kv[1][0])[:args.top]:
         print(f"{n:5d} {dt:9.1f} us  {src[-110:]}   {dict(ops.most_common(4))}")
