@@ -182,6 +182,9 @@ __device__ __forceinline__ void lds_owned_addn(int* tag, unsigned k, bool take, 
         }
     }
 }
+// a plain (non-volatile) read through an explicit LDS pointer: keeps the optimiser from merging it with a global load of the other
+// arm of a branch into one flat access (which the gfx950 backend then fails to select: "Operand has incorrect register class", r06)
+__device__ __forceinline__ float lds_ld(const float* p) { return *(const float __attribute__((address_space(3)))*)p; }
 __device__ __forceinline__ float lds_get(const float* p) { return *(lds_vf_t)p; }
 __device__ __forceinline__ void lds_put(float* p, float v) { *(lds_vf_t)p = v; }
 

@@ -657,24 +657,34 @@ extern "C" int ss_concat_sampled_fwd(const float* left, const float* right, cons
 
 // ---- backward of ss_concat_sampled_fwd (training: models/SemStereo.py:316-318, `att_topk * cat(left broadcast, warp(right))`, as ONE
 // pass over the gradient of the volume instead of the backward of a warp, a cat and a multiply: r06, those were 402 MB x 6 of traffic
-// per pair at 1024^2).  The candidates are INDICES (no gradient).  A wave owns 64 pixels of row h and CSB_CH channels; per candidate j:
+// per pair at 1024^2).  The candidates are INDICES (no gradient).  A wave owns 64 pixels of row h and CSB_CH = 4 channels (8 per wave: 169 registers, two waves per SIMD, 300 us against 239; 2: 244); per candidate j:
 //   grad_left[c]   += att[j] * gL[c,j]                                  (registers, one plain store at the end)
 //   grad_att[j]    += sum_c gL[c,j] * left[c] + gR[c,j] * warp(right)[c,j]   (the workgroup's waves meet in LDS once per pair of candidates)
 //   grad_right[c]  <- att[j] * w_tap * gR[c,j] at the four taps           (the two row windows of warp_bwd_blocks_kernel)
 // with gL / gR the two halves of the volume's gradient.  `margin`: the |disparity| the windows cover (a hint: taps beyond go to
 // memory one atomic at a time, still right).
-constexpr int CSB_NW = 4, CSB_CH = 8, CSB_JU = 2;
+#ifndef SS_CSB_CH
+#define SS_CSB_CH 4
+#endif
+#ifndef SS_CSB_NW
+#define SS_CSB_NW 8
+#endif
+#ifndef SS_CSB_JU
+#define SS_CSB_JU 2
+#endif
+constexpr int CSB_NW = SS_CSB_NW, CSB_CH = SS_CSB_CH, CSB_JU = SS_CSB_JU;
 __global__ __launch_bounds__(64 * CSB_NW) void concat_sampled_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__ left,
                                                                          const float* __restrict__ right, const float* __restrict__ disp,
                                                                          const float* __restrict__ att, float* __restrict__ g_left,
                                                                          float* __restrict__ g_right, float* __restrict__ g_att, int C,
                                                                          int H, int W, int nd, float half_w, float half_h, int margin,
                                                                          int rs, int att_atomic) {
-    extern __shared__ float csb_lds[];   // [NW][2][CH][rs] windows | [NW][2][rs] tags | [2][NW][JU][64] partial grad_att
+    extern __shared__ float csb_lds[];   // [NW][2][CH][rs] gradient windows | [NW][2][CH][rs] windows of `right` | [NW][2][rs] tags | [2][NW][JU][64] partial grad_att
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* rows = csb_lds + (size_t)wave * (2 * CSB_CH * rs);
-    int* tags = reinterpret_cast<int*>(csb_lds + (size_t)CSB_NW * (2 * CSB_CH * rs)) + (size_t)wave * (2 * rs);
-    float* red = csb_lds + (size_t)CSB_NW * (2 * CSB_CH * rs) + (size_t)CSB_NW * (2 * rs);
+    float* rwin = csb_lds + (size_t)(CSB_NW + wave) * (2 * CSB_CH * rs);
+    int* tags = reinterpret_cast<int*>(csb_lds + (size_t)2 * CSB_NW * (2 * CSB_CH * rs)) + (size_t)wave * (2 * rs);
+    float* red = csb_lds + (size_t)2 * CSB_NW * (2 * CSB_CH * rs) + (size_t)CSB_NW * (2 * rs);
     const int rb = 64 + 2 * margin + 2;                       // live slots of a window
     const long long plane = (long long)H * W;
     const long long i = (long long)blockIdx.x * 64 + lane;    // over B * H * W (whole blocks: W % 64 == 0)
@@ -696,6 +706,21 @@ __global__ __launch_bounds__(64 * CSB_NW) void concat_sampled_bwd_kernel(const f
         cl[n] = (n < nlive) ? left[(b * C + c0 + n) * plane + pix] : 0.f;
         gcl[n] = 0.f;
     }
+    // the same two windows of `right` itself (zeros outside the image): the forward's warp(right)[c, j], which grad_att needs, is four
+    // taps per channel and candidate -- as global gathers they were 100 of the kernel's 246 us (ablation r06, EXPERIMENTS.md F.20)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = r == 0 ? h : other;
+        const bool row_ok = row >= 0 && row < H;
+        for (int idx = lane; idx < rs; idx += 64) {
+            const int col = xb + idx;
+            const bool ok = row_ok && idx < rb && col >= 0 && col < W;
+#pragma unroll
+            for (int n = 0; n < CSB_CH; ++n)
+                ss::lds_put(&rwin[(r * CSB_CH + n) * rs + idx], (ok && n < nlive) ? rp[n * plane + (long long)row * W + col] : 0.f);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
     int par = 0;
     for (int j0 = 0; j0 < nd; j0 += CSB_JU, par ^= 1) {
         float dv[CSB_JU], av[CSB_JU], gL[CSB_JU][CSB_CH], gR[CSB_JU][CSB_CH], part[CSB_JU];
@@ -717,10 +742,27 @@ __global__ __launch_bounds__(64 * CSB_NW) void concat_sampled_bwd_kernel(const f
             const Taps tp = make_taps(dv[u], h, w, H, W, half_w, half_h);
             const float a = av[u];
             float s = 0.f;
+            const int row_n = (tp.o_nw >= 0 ? tp.o_nw : tp.o_ne) / W, row_s = (tp.o_sw >= 0 ? tp.o_sw : tp.o_se) / W;
+            // a tap's value: from the window it lies in, from memory beyond (the same arithmetic as warp.hip::sample, tap by tap)
+            auto tap = [&](int n, int o, int row) -> float {
+                const unsigned k = (unsigned)(o - row * W - xb);
+                const bool inw = o >= 0 && (row == h || row == other) && k < (unsigned)rb;
+                float v = 0.f;
+                if (inw) v = ss::lds_ld(&rwin[(((row == h) ? 0 : 1) * CSB_CH + n) * rs + k]);
+                if (o >= 0 && !inw) v = __builtin_nontemporal_load(rp + n * plane + o);
+                return v;
+            };
+            auto wval = [&](int n) -> float {
+                float r = ss::mul_rn(tap(n, tp.o_nw, row_n), tp.w_nw);
+                r = ss::add_rn(r, ss::mul_rn(tap(n, tp.o_ne, row_n), tp.w_ne));
+                r = ss::add_rn(r, ss::mul_rn(tap(n, tp.o_sw, row_s), tp.w_sw));
+                r = ss::add_rn(r, ss::mul_rn(tap(n, tp.o_se, row_s), tp.w_se));
+                return r;
+            };
 #pragma unroll
             for (int n = 0; n < CSB_CH; ++n) {
                 gcl[n] = fmaf(a, gL[u][n], gcl[n]);
-                const float val = (n < nlive) ? sample(rp + n * plane, tp) : 0.f;       // the forward's warp(right)[c, j]
+                const float val = (n < nlive) ? wval(n) : 0.f;                          // the forward's warp(right)[c, j]
                 s = fmaf(gL[u][n], cl[n], s);
                 s = fmaf(gR[u][n], val, s);
             }
@@ -741,7 +783,6 @@ __global__ __launch_bounds__(64 * CSB_NW) void concat_sampled_bwd_kernel(const f
                     }
                     ss::lds_owned_addn<CSB_CH>(tags + r * rs, k, in_win, rows + r * (CSB_CH * rs), rs, v, nlive);
                 };
-                const int row_n = (tp.o_nw >= 0 ? tp.o_nw : tp.o_ne) / W, row_s = (tp.o_sw >= 0 ? tp.o_sw : tp.o_se) / W;
                 add(tp.o_nw, row_n, tp.w_nw); add(tp.o_ne, row_n, tp.w_ne); add(tp.o_sw, row_s, tp.w_sw); add(tp.o_se, row_s, tp.w_se);
             }
         }
@@ -795,7 +836,7 @@ extern "C" int ss_concat_sampled_bwd(const float* grad_out, const float* left, c
     const long long plane = (long long)H * W;
     margin = std::min(margin, 96);
     const int rs = 64 + 2 * margin + 2 + 6;                   // (+ 6: the row stride off the 32-bank period)
-    const size_t lds = ((size_t)CSB_NW * 2 * CSB_CH * rs + (size_t)CSB_NW * 2 * rs + (size_t)2 * CSB_NW * CSB_JU * 64) * sizeof(float);
+    const size_t lds = ((size_t)2 * CSB_NW * 2 * CSB_CH * rs + (size_t)CSB_NW * 2 * rs + (size_t)2 * CSB_NW * CSB_JU * 64) * sizeof(float);
     if (lds > 160 * 1024) return SS_ERR_UNSUPPORTED;
     const int gy = ss::ceil_div(C, CSB_NW * CSB_CH);
     if (grad_right && hipMemsetAsync(grad_right, 0, (size_t)B * C * plane * sizeof(float), st) != hipSuccess) return SS_ERR_LAUNCH;

@@ -191,6 +191,18 @@ elif name in ("strength_bwd", "strength_bwd_ws", "warp_bwd", "warp_bwd_smooth"):
         gy = torch.empty_like(y)
         fn = lambda: lib.call("ss_warp_sampled_bwd", lib.ptr(g), None, lib.ptr(y), lib.ptr(smp), None, lib.ptr(gy), None, B, 32, 256, 256, 24)   # noqa: E731
         nbytes = 4.0 * B * (32 * 24 + 24 + 32) * 256 * 256
+elif name == "concat_bwd":           # backward of the gated sparse concat volume (models/SemStereo.py:316-318) at the 1024^2 training shape
+    lib = sa._lib
+    cl, cr = R(B, 32, 256, 256), R(B, 32, 256, 256)
+    yy, xx = torch.meshgrid(torch.arange(256, device=dev), torch.arange(256, device=dev), indexing="ij")
+    d0 = torch.round(10.0 * torch.sin(xx / 40.0) * torch.cos(yy / 55.0))
+    smp = (d0[None, None] + torch.arange(-12, 12, device=dev).float()[None, :, None, None]).expand(B, 24, 256, 256).contiguous()
+    att = torch.rand(B, 24, 256, 256, device=dev)
+    g = R(B, 64, 24, 256, 256)
+    gl, gr, ga = torch.empty_like(cl), torch.empty_like(cr), torch.empty_like(att)
+    fn = lambda: lib.call("ss_concat_sampled_bwd", lib.ptr(g), lib.ptr(cl), lib.ptr(cr), lib.ptr(smp), lib.ptr(att), lib.ptr(gl), lib.ptr(gr), lib.ptr(ga),   # noqa: E731
+                          B, 32, 256, 256, 24, 16)
+    nbytes = 4.0 * B * (64 * 24 + 24 * 3 + 32 * 4) * 256 * 256
 elif name.startswith("wgrad"):   # weight gradients of the training step (1024^2 / md64): wgrad = classif.0 (32 -> 32 at [24,256,256]), wgrad_stem = concat_stem (64 -> 32),
     # wgrad_mid = hourglass2.conv2 (64 -> 64 at [12,128,128]), wgrad_low = conv4 (128 -> 128 at [6,64,64]), wgrad_s2 = conv1 (32 -> 64, stride 2), wgrad_head (32 -> 1)
     from semstereo_amd import train_layers as TL
