@@ -34,7 +34,7 @@ enum ss_status {
     SS_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* ABI version (18 since round 6 (13-17 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
+/* ABI version (19 since round 6 (13-18 earlier in it); 12 since round 5; ss_abi_version() is authoritative and semstereo_amd/_lib.py checks it at load): bumped on any
  * signature change or new entry point the Python binding requires. */
 int ss_abi_version(void);
 /* The library's tuning switches (SS_CONV_TILE, SS_GWC_STREAM, SS_WARP_STREAM, SS_WARP_VEC, SS_DECONV_SPLIT, ...; A/B
@@ -460,10 +460,11 @@ int ss_batchnorm_train_fwd_rs(const float* x, const float* residual, const float
                               ss_stream_t stream);
 /* (r06) Both backward forms with the parameter gradients also as floats, grad_weight / grad_bias [C] (either may be NULL; the doubles
  * stay in `work`); grad_residual may be NULL; batch_statistics = 1: the backward of ss_batchnorm_train_fwd / _res_fwd / _fwd_rs,
- * 0: of ss_batchnorm_eval_fwd. */
+ * 0: of ss_batchnorm_eval_fwd.  `bias`: the forward's (NULL = none).  y may be NULL where the forward had a ReLU and no residual: the
+ * mask is recomputed from x with the forward's own expression, and y is not read (two of the backward's seven tensor passes). */
 int ss_batchnorm_bwd_pg(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
-                        const float* weight, float* grad_x, float* grad_residual, double* work, float* grad_weight, float* grad_bias,
-                        int batch_statistics, int B, int C, long long N, int relu, ss_stream_t stream);
+                        const float* weight, const float* bias, float* grad_x, float* grad_residual, double* work, float* grad_weight,
+                        float* grad_bias, int batch_statistics, int B, int C, long long N, int relu, ss_stream_t stream);
 /* (r06, training) The normalisation of groupwise_correlation_norm (models/submodule.py:213-222), once per feature map:
  * y = x / (||x||_2 over each group's C / groups channels + eps), x [B,C,H,W]; and its backward (grad_x from grad_y and x).  The
  * volume is then built from the normalised maps by ss_gwc_volume_fwd / _bwd. */

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsemstereo_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -87,7 +87,7 @@ _SIGNATURES = {
     "ss_group_normalise_fwd": [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _P],
     "ss_group_normalise_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _P],
     "ss_batchnorm_train_fwd_rs": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_double, _I, _I, ctypes.c_longlong, ctypes.c_float, _I, _P],
-    "ss_batchnorm_bwd_pg": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_longlong, _I, _P],
+    "ss_batchnorm_bwd_pg": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_longlong, _I, _P],
     "ss_batchnorm_eval_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],
     "ss_batchnorm_eval_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_longlong, _I, _P],
     "ss_channel_sum_fwd": [_P, _P, _I, _I, ctypes.c_longlong, _P],

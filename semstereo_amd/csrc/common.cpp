@@ -102,7 +102,7 @@ extern "C" int ss_reload_tuning(void) {
     return SS_OK;
 }
 
-extern "C" int ss_abi_version(void) { return 18; }   // 18: + ss_group_normalise_fwd / _bwd; 17: + ss_concat_sampled_bwd (the sparse concat volume's backward in one pass); 16: + ss_batchnorm_train_fwd_rs, ss_batchnorm_bwd_pg (running statistics and float parameter gradients inside the kernels); 15: + ss_sample_strength_bwd_ws; 14: + ss_regression_topk_patched_fwd (the classifier's patch sum folded into the top-2 soft-argmax); 13: + ss_conv3d_wgrad_bf16s_fwd (weight gradients on the bf16 matrix core); 12: + ss_conv3d_gather_fwd (sparse concat formed inside concat_stem), ss_ssr_upsample2_fwd; 11: + training leftovers (ss_batchnorm_train_res_fwd/_bwd: residual + ReLU inside the BatchNorm apply; ss_window_attention_core_pad_bwd; the attention-tail backward kernels); 10: + training side (ss_batchnorm_train_fwd/_bwd, ss_channel_sum_fwd, ss_depthwise_patch_wgrad_fwd, ss_channel_gate_bwd_logits, ss_window_attention_core_bwd), ss_tool_copy_fwd; 9: + ss_concat_sampled_presplit_fwd, ss_conv3d_presplit_fwd (pre-split operands, LDS-DMA staging); 8: channels-last hand-off inside the classifiers (ss_conv3d_bf16s_cl_fwd, ss_conv3d_head_bf16s_cl_fwd); 7: disparity ranges (dmin, ndisp) instead of maxdisp, ss_conv3d_wgrad_fwd, backward entry points; 6: + ss_channel_att_logits_fwd, ss_upsample_softmax_regression_fwd (5: ss_reload_tuning)
+extern "C" int ss_abi_version(void) { return 19; }   // 19: ss_batchnorm_bwd_pg takes the forward's bias (ReLU mask from x when y is NULL); 18: + ss_group_normalise_fwd / _bwd; 17: + ss_concat_sampled_bwd (the sparse concat volume's backward in one pass); 16: + ss_batchnorm_train_fwd_rs, ss_batchnorm_bwd_pg (running statistics and float parameter gradients inside the kernels); 15: + ss_sample_strength_bwd_ws; 14: + ss_regression_topk_patched_fwd (the classifier's patch sum folded into the top-2 soft-argmax); 13: + ss_conv3d_wgrad_bf16s_fwd (weight gradients on the bf16 matrix core); 12: + ss_conv3d_gather_fwd (sparse concat formed inside concat_stem), ss_ssr_upsample2_fwd; 11: + training leftovers (ss_batchnorm_train_res_fwd/_bwd: residual + ReLU inside the BatchNorm apply; ss_window_attention_core_pad_bwd; the attention-tail backward kernels); 10: + training side (ss_batchnorm_train_fwd/_bwd, ss_channel_sum_fwd, ss_depthwise_patch_wgrad_fwd, ss_channel_gate_bwd_logits, ss_window_attention_core_bwd), ss_tool_copy_fwd; 9: + ss_concat_sampled_presplit_fwd, ss_conv3d_presplit_fwd (pre-split operands, LDS-DMA staging); 8: channels-last hand-off inside the classifiers (ss_conv3d_bf16s_cl_fwd, ss_conv3d_head_bf16s_cl_fwd); 7: disparity ranges (dmin, ndisp) instead of maxdisp, ss_conv3d_wgrad_fwd, backward entry points; 6: + ss_channel_att_logits_fwd, ss_upsample_softmax_regression_fwd (5: ss_reload_tuning)
 
 extern "C" const char* ss_status_string(int status) {
     switch (status) {

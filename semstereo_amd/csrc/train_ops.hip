@@ -18,7 +18,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __restrict__ a, const float* __restrict__ x,
                                                               const float* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, double* __restrict__ sums, int C,
-                                                              long long N, long long per_block, int relu) {
+                                                              long long N, long long per_block, int relu,
+                                                              const float* __restrict__ w = nullptr, const float* __restrict__ bias = nullptr) {
     const int c = blockIdx.y;
     const long long total = (long long)gridDim.z * N;       // (unused: batch is blockIdx.z)
     (void)total;
@@ -27,9 +28,12 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __rest
     const long long i0 = (long long)blockIdx.x * per_block, i1 = min(i0 + per_block, N);
     float s0 = 0.f, s1 = 0.f;
     const float mu = (MODE == 1) ? mean[c] : 0.f, is = (MODE == 1) ? invstd[c] : 0.f;
+    // (r06) y == NULL with relu: the ReLU mask from x itself -- the forward's own fmaf(x, sc, sh) > 0 -- instead of a third tensor read
+    const bool remask = MODE == 1 && relu && y == nullptr;
+    const float msc = remask ? is * (w ? w[c] : 1.f) : 0.f, msh = remask ? fmaf(-mu, msc, bias ? bias[c] : 0.f) : 0.f;
     // (r06) 16 bytes per lane where the channel rows allow it (N % 4 == 0; per_block is then a multiple of 4): the scalar loop ran at
     // ~2 TB/s of traffic, 4.4 ms of the 1024^2 training step in the four BatchNorm passes
-    const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | (MODE == 1 ? reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) : 0);
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | (MODE == 1 ? reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) : 0);   // (NULL y: no bits)
     if ((N & 3) == 0 && (per_block & 3) == 0 && (bits & 15) == 0) {
         for (long long i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
             const float4 av = *reinterpret_cast<const float4*>(a + base + i);
@@ -41,7 +45,10 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __rest
                 const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
                 const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
                 float ye[4] = {1.f, 1.f, 1.f, 1.f};
-                if (relu) {
+                if (remask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ye[e] = fmaf(xe[e], msc, msh);
+                } else if (relu) {
                     const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
                     ye[0] = yv.x; ye[1] = yv.y; ye[2] = yv.z; ye[3] = yv.w;
                 }
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __rest
             s0 += v; s1 += v * v;
         } else if (MODE == 1) {
             float g = a[base + i];
-            if (relu && !(y[base + i] > 0.f)) g = 0.f;
+            if (relu && !((remask ? fmaf(x[base + i], msc, msh) : y[base + i]) > 0.f)) g = 0.f;
             s0 += g; s1 += g * ((x[base + i] - mu) * is);
         } else {
             s0 += a[base + i];
@@ -111,8 +118,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c = (int)((i / N) % C);
-    const float sc = invstd[c] * (w ? w[c] : 1.f), sh = (bias ? bias[c] : 0.f) - mean[c] * sc;
-    float v = x[i] * sc + sh;
+    const float sc = invstd[c] * (w ? w[c] : 1.f), sh = fmaf(-mean[c], sc, bias ? bias[c] : 0.f);
+    float v = fmaf(x[i], sc, sh);             // (the backward recomputes this very expression for the ReLU mask when it is not given y)
     if (res) v += res[i];
     if (relu) v = fmaxf(v, 0.f);
     y[i] = v;
@@ -125,10 +132,10 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restric
                                                            float* __restrict__ y, int C, long long N, int relu) {
     const int c = blockIdx.y;
     const long long base = ((long long)blockIdx.z * C + c) * N;
-    const float sc = invstd[c] * (w ? w[c] : 1.f), sh = (bias ? bias[c] : 0.f) - mean[c] * sc;
+    const float sc = invstd[c] * (w ? w[c] : 1.f), sh = fmaf(-mean[c], sc, bias ? bias[c] : 0.f);
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < N; i += (long long)gridDim.x * 1024) {
         const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-        float v[4] = {xv.x * sc + sh, xv.y * sc + sh, xv.z * sc + sh, xv.w * sc + sh};
+        float v[4] = {fmaf(xv.x, sc, sh), fmaf(xv.y, sc, sh), fmaf(xv.z, sc, sh), fmaf(xv.w, sc, sh)};
         if (res) {
             const float4 rv = *reinterpret_cast<const float4*>(res + base + i);
             v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
@@ -146,10 +153,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
                                                                const float* __restrict__ invstd, const float* __restrict__ w,
                                                                const double* __restrict__ sums, float* __restrict__ dx,
                                                                float* __restrict__ dres, int C, long long N, double count, int relu,
-                                                               float* __restrict__ gw, float* __restrict__ gb) {
+                                                               float* __restrict__ gw, float* __restrict__ gb, const float* __restrict__ bias) {
     const int c = blockIdx.y;
     const long long base = ((long long)blockIdx.z * C + c) * N;
     const float mu = mean[c], is = invstd[c], ws = (w ? w[c] : 1.f) * is;
+    const bool remask = relu && y == nullptr;                // (the mask from x: see channel_reduce_kernel)
+    const float msh = fmaf(-mu, ws, bias ? bias[c] : 0.f);
     const float mg = (float)(sums[2 * c] / count), mgx = (float)(sums[2 * c + 1] / count);
     if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {      // the parameter gradients as floats (r06: two strided copies per layer)
         if (gb) gb[c] = (float)sums[2 * c];
@@ -160,7 +169,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
         const float4 xq = *reinterpret_cast<const float4*>(x + base + i);
         float gv[4] = {gq.x, gq.y, gq.z, gq.w};
         const float xe[4] = {xq.x, xq.y, xq.z, xq.w};
-        if (relu) {
+        if (remask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!(fmaf(xe[e], ws, msh) > 0.f)) gv[e] = 0.f;
+        } else if (relu) {
             const float4 yq = *reinterpret_cast<const float4*>(y + base + i);
             const float ye[4] = {yq.x, yq.y, yq.z, yq.w};
 #pragma unroll
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                             const double* __restrict__ sums, float* __restrict__ dx,
                                                             float* __restrict__ dres, int C,
                                                             long long N, long long total, double count, int relu,
-                                                            float* __restrict__ gw, float* __restrict__ gb) {
+                                                            float* __restrict__ gw, float* __restrict__ gb, const float* __restrict__ bias) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     if (i < C) {                                             // (total = B * C * N >= C)
@@ -194,7 +207,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
     const int c = (int)((i / N) % C);
     float gv = g[i];
-    if (relu && !(y[i] > 0.f)) gv = 0.f;
+    if (relu) {
+        const float sc = invstd[c] * (w ? w[c] : 1.f);
+        const float pre = (y != nullptr) ? y[i] : fmaf(x[i], sc, fmaf(-mean[c], sc, bias ? bias[c] : 0.f));
+        if (!(pre > 0.f)) gv = 0.f;
+    }
     if (dres) dres[i] = gv;                   // the residual's gradient: the incoming one behind the ReLU mask
     const float xh = (x[i] - mean[c]) * invstd[c];
     const float mg = (float)(sums[2 * c] / count), mgx = (float)(sums[2 * c + 1] / count);
@@ -462,13 +479,16 @@ extern "C" int ss_batchnorm_train_fwd_rs(const float* x, const float* residual, 
 static int batchnorm_train_bwd_impl(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
                                     const float* weight, float* grad_x, float* grad_res, double* work, int B, int C, long long N, int relu,
                                     ss_stream_t stream, float* grad_weight = nullptr, float* grad_bias = nullptr,
-                                    bool batch_statistics = true) {
-    SS_REQUIRE(grad_y && x && mean && invstd && grad_x && work && B > 0 && C > 0 && N > 0 && (y || !relu) && C <= 65535 && B <= 65535);
+                                    bool batch_statistics = true, const float* bias = nullptr, bool mask_from_x = false) {
+    // (y == NULL with relu: only where the caller says the mask can be recomputed from x -- ss_batchnorm_bwd_pg without a residual)
+    SS_REQUIRE(grad_y && x && mean && invstd && grad_x && work && B > 0 && C > 0 && N > 0 && (y || !relu || (mask_from_x && !grad_res)) &&
+               C <= 65535 && B <= 65535);
     hipStream_t st = ss::as_stream(stream);
     if (hipMemsetAsync(work, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return SS_ERR_LAUNCH;
     long long per_block;
     const int gx = reduce_grid(N, per_block);
-    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(gx, C, B), dim3(256), 0, st, grad_y, x, y, mean, invstd, work, C, N, per_block, relu);
+    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(gx, C, B), dim3(256), 0, st, grad_y, x, y, mean, invstd, work, C, N, per_block, relu, weight,
+                       bias);
     const long long total = (long long)B * C * N;
     const long long blocks = ss::ceil_div_ll(total, 256);
     if (blocks > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
@@ -476,10 +496,10 @@ static int batchnorm_train_bwd_impl(const float* grad_y, const float* x, const f
     const double count = batch_statistics ? (double)B * (double)N : (double)INFINITY;
     if (vec4_ok(N, grad_y, x, y, grad_x, grad_res))
         hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(apply_grid(N), C, B), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x,
-                           grad_res, C, N, count, relu, grad_weight, grad_bias);
+                           grad_res, C, N, count, relu, grad_weight, grad_bias, bias);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_y, x, y, mean, invstd, weight, work, grad_x,
-                           grad_res, C, N, total, count, relu, grad_weight, grad_bias);
+                           grad_res, C, N, total, count, relu, grad_weight, grad_bias, bias);
     return ss::check_launch();
 }
 
@@ -524,12 +544,16 @@ extern "C" int ss_batchnorm_eval_bwd(const float* grad_y, const float* x, const 
 }
 
 // Both backward forms with the parameter gradients ALSO as floats: grad_weight / grad_bias [C] (either may be NULL) beside the doubles in
-// `work`; grad_residual may be NULL; batch_statistics = 1: the backward of ss_batchnorm_train_fwd / _res_fwd, 0: of ss_batchnorm_eval_fwd
+// `work`; grad_residual may be NULL; batch_statistics = 1: the backward of ss_batchnorm_train_fwd / _res_fwd, 0: of ss_batchnorm_eval_fwd.
+// y may be NULL where the forward had a ReLU and NO residual: the mask is then recomputed from x -- fmaf(x, invstd * w, bias - mean *
+// invstd * w) > 0, the forward's own expression, with `bias` the forward's (NULL = none) -- and two of the backward's seven tensor
+// passes (y in the statistics pass and in the apply pass) are not read
 extern "C" int ss_batchnorm_bwd_pg(const float* grad_y, const float* x, const float* y, const float* mean, const float* invstd,
-                                   const float* weight, float* grad_x, float* grad_residual, double* work, float* grad_weight,
-                                   float* grad_bias, int batch_statistics, int B, int C, long long N, int relu, ss_stream_t stream) {
+                                   const float* weight, const float* bias, float* grad_x, float* grad_residual, double* work,
+                                   float* grad_weight, float* grad_bias, int batch_statistics, int B, int C, long long N, int relu,
+                                   ss_stream_t stream) {
     return batchnorm_train_bwd_impl(grad_y, x, y, mean, invstd, weight, grad_x, grad_residual, work, B, C, N, relu, stream, grad_weight,
-                                    grad_bias, batch_statistics != 0);
+                                    grad_bias, batch_statistics != 0, bias, true);
 }
 
 extern "C" int ss_channel_sum_fwd(const float* a, double* sums, int B, int C, long long N, ss_stream_t stream) {

@@ -68,7 +68,8 @@ class _BatchNormTrain(torch.autograd.Function):
         for t in (rm, rv, nbt):                              # (written through raw pointers: the packed-weight caches key on versions)
             if t is not None:
                 torch.autograd.graph.increment_version(t)
-        ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
+        # (y is saved only where a residual joined before the ReLU: without one the backward recomputes the mask from x)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, invstd, weight, bias)
         ctx.relu, ctx.has_bias, ctx.has_res = bool(relu), bias is not None, residual is not None
         ctx.mark_non_differentiable(mean, var_u)
         ctx.set_materialize_grads(False)                     # (no zero-filled gradients for `mean` / `var_u`: two launches per layer)
@@ -76,7 +77,7 @@ class _BatchNormTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
-        x, y, mean, invstd, weight = ctx.saved_tensors
+        x, y, mean, invstd, weight, bias = ctx.saved_tensors
         if g is None:
             return (None,) * 7
         g = _c(g)
@@ -88,8 +89,8 @@ class _BatchNormTrain(torch.autograd.Function):
         gw = torch.empty(C, dtype=torch.float32, device=x.device) if weight is not None else None
         gb = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         with torch.cuda.device(x.device):
-            call("ss_batchnorm_bwd_pg", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(gres), ptr(work), ptr(gw), ptr(gb),
-                 1, B, C, N, int(ctx.relu))
+            call("ss_batchnorm_bwd_pg", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(gx), ptr(gres), ptr(work),
+                 ptr(gw), ptr(gb), 1, B, C, N, int(ctx.relu))
         return gx, gw, gb, None, None, gres, None
 
 
@@ -106,13 +107,13 @@ class _BatchNormEval(torch.autograd.Function):
         residual = None if residual is None else _c(residual)
         with torch.cuda.device(x.device):
             call("ss_batchnorm_eval_fwd", ptr(x), ptr(residual), ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(y), B, C, N, int(relu))
-        ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, invstd, weight, bias)
         ctx.relu, ctx.has_bias, ctx.has_res = bool(relu), bias is not None, residual is not None
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y, mean, invstd, weight = ctx.saved_tensors
+        x, y, mean, invstd, weight, bias = ctx.saved_tensors
         g = _c(g)
         B, C = x.shape[0], x.shape[1]
         N = x[0, 0].numel()
@@ -122,8 +123,8 @@ class _BatchNormEval(torch.autograd.Function):
         gw = torch.empty(C, dtype=torch.float32, device=x.device) if weight is not None else None
         gb = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         with torch.cuda.device(x.device):
-            call("ss_batchnorm_bwd_pg", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(gx), ptr(gres), ptr(work), ptr(gw), ptr(gb),
-                 0, B, C, N, int(ctx.relu))
+            call("ss_batchnorm_bwd_pg", ptr(g), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(gx), ptr(gres), ptr(work),
+                 ptr(gw), ptr(gb), 0, B, C, N, int(ctx.relu))
         return gx, gw, gb, None, None, None, gres
 
 
