@@ -228,19 +228,21 @@ __global__ __launch_bounds__(256) void depthwise_patch_wgrad_kernel(const float*
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-    for (int r = r0; r < r1; ++r) {
+    // (the threads run over the block's rows x W positions together: with one row at a time and W = 128 -- the 1/8-scale volume of the
+    // 1024^2 pair -- half of them had nothing to do, r06)
+    const int npos = (r1 - r0) * W;
+    for (int idx = threadIdx.x; idx < npos; idx += 256) {
+        const int r = r0 + idx / W, w = idx % W;
         const int d = r / H, h = r - d * H;
-        for (int w = threadIdx.x; w < W; w += 256) {
-            const float gv = g[base + ((long long)d * H + h) * W + w];
+        const float gv = g[base + ((long long)d * H + h) * W + w];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int hh = h + kh - 1;
-                if ((unsigned)hh >= (unsigned)H) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+            if ((unsigned)hh >= (unsigned)H) continue;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ww = w + kw - 1;
-                    if ((unsigned)ww < (unsigned)W) acc[kh * 3 + kw] += gv * x[base + ((long long)d * H + hh) * W + ww];
-                }
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = w + kw - 1;
+                if ((unsigned)ww < (unsigned)W) acc[kh * 3 + kw] += gv * x[base + ((long long)d * H + hh) * W + ww];
             }
         }
     }
