@@ -94,6 +94,7 @@ __device__ __forceinline__ float exp_fast(float x) {
 // fp32 add into LDS as ONE ds_add_f32 (no return value).  `p` must point into LDS: through a generic pointer the atomic is a FLAT
 // instruction, and pointer arithmetic that leaves the LDS aperture on the way (a negative intermediate offset) faults the queue
 // (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, r06).
+// (No product kernel uses it any more -- ss::lds_owned_add* below -- it stays for the timing ablations that measured why.)
 __device__ __forceinline__ void lds_add(float* p, float v) {
     typedef float __attribute__((address_space(3))) * lds_ptr_t;
     __hip_atomic_fetch_add((lds_ptr_t)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
