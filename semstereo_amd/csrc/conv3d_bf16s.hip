@@ -872,12 +872,16 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, unsigned 
     wsplit[i] = (unsigned short)(term == 0 ? h : (term == 1 ? m : l));
 }
 
-// f16 form, pass 1: per output channel, the power of two that brings max |w| into [2^14, 2^15); its inverse is stored
-// behind the packed terms (float[Cout]) for the conv kernel's epilogue.  One workgroup per channel.
-__global__ __launch_bounds__(256) void weight_unscale_f16s_kernel(const float* __restrict__ w, float* __restrict__ wunscale,
-                                                                   int per_co) {
+// f16 form: per output channel, the power of two that brings max |w| into [2^14, 2^15) -- its inverse is stored behind the packed terms
+// (float[Cout]) for the conv kernel's epilogue -- then [Cout,Cin,taps] fp32 -> [ceil(Cin/8)][steps][2 terms][2 halves][Cout][8] fp16 of
+// w / wunscale[co].  One workgroup per output channel does both (r06: they were two launches, and training re-packs every layer's
+// weights every step: ~100 small launches per step; same arithmetic on the same values, bit-identical output).
+__global__ __launch_bounds__(256) void pack_weights_f16s_fused_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit,
+                                                                       float* __restrict__ wunscale, int Cout, int Cin, int ktaps) {
     __shared__ unsigned wmax[4];
-    const float* wc = w + (size_t)blockIdx.x * per_co;
+    __shared__ float unscale_s;
+    const int co = blockIdx.x, per_co = Cin * ktaps;
+    const float* wc = w + (size_t)co * per_co;
     float m = 0.f;
     for (int i = threadIdx.x; i < per_co; i += 256) m = fmaxf(m, fabsf(wc[i]));
     const unsigned wm = wave_max_bits(__float_as_uint(m));
@@ -885,29 +889,29 @@ __global__ __launch_bounds__(256) void weight_unscale_f16s_kernel(const float* _
     __syncthreads();
     if (threadIdx.x == 0) {
         const int e = max((int)(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])) >> 23), E_MIN);
-        wunscale[blockIdx.x] = __uint_as_float((unsigned)(127 - E_ONE + e) << 23);
+        const float u = __uint_as_float((unsigned)(127 - E_ONE + e) << 23);
+        wunscale[co] = u;
+        unscale_s = u;
     }
-}
-
-// pass 2: [Cout,Cin,taps] fp32 -> [ceil(Cin/8)][steps][2 terms][2 halves][Cout][8] fp16 of w / wunscale[co]
-__global__ void pack_weights_f16s_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsplit,
-                                         const float* __restrict__ wunscale, int Cout, int Cin, int ktaps, long long total) {
-    const int KSTEPS = (ktaps + 1) / 2;
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int j = (int)(i % 8);
-    long long r = i / 8;
-    const int co = (int)(r % Cout); r /= Cout;
-    const int half = (int)(r % 2); r /= 2;
-    const int term = (int)(r % 2); r /= 2;
-    const int s = (int)(r % KSTEPS);
-    const int blk = (int)(r / KSTEPS);
-    const int tap = 2 * s + half, ci = blk * 8 + j;
-    float x = 0.f;
-    if (tap < ktaps && ci < Cin) x = w[((long long)co * Cin + ci) * ktaps + tap] / wunscale[co];   // exact: a power of two
-    const _Float16 h = (_Float16)x;
-    const _Float16 l = (_Float16)(x - (float)h);
-    wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
+    __syncthreads();
+    const float u = unscale_s;
+    const int KSTEPS = (ktaps + 1) / 2, nblk = (Cin + 7) / 8;
+    const int n = nblk * KSTEPS * 4 * 8;                      // this channel's slots: (blk, s, term, half, j)
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int j = e % 8;
+        int r = e / 8;
+        const int half = r % 2; r /= 2;
+        const int term = r % 2; r /= 2;
+        const int s = r % KSTEPS;
+        const int blk = r / KSTEPS;
+        const int tap = 2 * s + half, ci = blk * 8 + j;
+        float x = 0.f;
+        if (tap < ktaps && ci < Cin) x = wc[(size_t)ci * ktaps + tap] / u;       // exact: a power of two
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const long long i = ((((long long)(blk * KSTEPS + s) * 2 + term) * 2 + half) * Cout + co) * 8 + j;
+        wsplit[i] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
+    }
 }
 
 #endif  // !SS_CONV_GATHER_TU
@@ -1058,9 +1062,8 @@ extern "C" int ss_pack_conv3d_weights_f16s(const float* w, void* wsplit, int Cou
     SS_REQUIRE(w && wsplit && Cout > 0 && Cin > 0);
     const long long total = (long long)ss::ceil_div(Cin, 8) * KSTEPS * 2 * 2 * Cout * 8;
     float* wunscale = reinterpret_cast<float*>(reinterpret_cast<char*>(wsplit) + total * 2);
-    hipLaunchKernelGGL(weight_unscale_f16s_kernel, dim3(Cout), dim3(256), 0, ss::as_stream(stream), w, wunscale, Cin * 27);
-    hipLaunchKernelGGL(pack_weights_f16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
-                       ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), wunscale, Cout, Cin, 27, total);
+    hipLaunchKernelGGL(pack_weights_f16s_fused_kernel, dim3(Cout), dim3(256), 0, ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit),
+                       wunscale, Cout, Cin, 27);
     return ss::check_launch();
 }
 
@@ -1078,9 +1081,8 @@ extern "C" int ss_pack_conv2d_weights_f16s(const float* w, void* wsplit, int Cou
     SS_REQUIRE(w && wsplit && Cout > 0 && Cin > 0);
     const long long total = (long long)ss::ceil_div(Cin, 8) * 5 * 2 * 2 * Cout * 8;
     float* wunscale = reinterpret_cast<float*>(reinterpret_cast<char*>(wsplit) + total * 2);
-    hipLaunchKernelGGL(weight_unscale_f16s_kernel, dim3(Cout), dim3(256), 0, ss::as_stream(stream), w, wunscale, Cin * 9);
-    hipLaunchKernelGGL(pack_weights_f16s_kernel, dim3((unsigned)ss::ceil_div_ll(total, 256)), dim3(256), 0,
-                       ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit), wunscale, Cout, Cin, 9, total);
+    hipLaunchKernelGGL(pack_weights_f16s_fused_kernel, dim3(Cout), dim3(256), 0, ss::as_stream(stream), w, reinterpret_cast<unsigned short*>(wsplit),
+                       wunscale, Cout, Cin, 9);
     return ss::check_launch();
 }
 
