@@ -457,6 +457,167 @@ __global__ __launch_bounds__(576, 1) void conv3d_wgrad_bf16s_coop(const float* _
         for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
 }
 
+// ---- stride 2 with the gout chunk SHARED (r06, last): the per-wave form above is bound by its global loads (271 us as is, 135 without
+// them, 109 with neither loads nor staging: profiles/EXPERIMENTS.md F.23), and the loads that hurt are the gout fragments -- lane =
+// channel, 32 cache lines per instruction, and the same chunk fetched by all nine kernel rows.  Here a workgroup is the nine kernel rows
+// (kd, kh) of ONE chunk range: each wave keeps the per-wave form's private input tile (the nine rows 2 od + kd - 1, 2 oh + kh - 1 of a
+// chunk are nine different rows: nothing to share), and the gout chunk is staged once by eight of the waves together -- coalesced,
+// lane = (position pair, channel), as in the cooperative stride-1 kernel -- into a double-buffered LDS tile all nine read their A
+// fragments from.  One barrier per chunk.  (The cooperative stride-2 form that also shared the input rows needed 16-position chunks to
+// fit its ring in LDS and lost, F.12; this one keeps 32.)
+constexpr int S2A_LDS = 9 * WG<2>::TILE + 2 * CO_ATILE;   // 153 600 bytes: one workgroup of nine waves per CU
+
+__global__ __launch_bounds__(576, 1) void conv3d_wgrad_bf16s_s2a(const float* __restrict__ gout, const float* __restrict__ in,
+                                                                  float* __restrict__ ws, int Cin, int Cout, int D, int H, int W, int Do,
+                                                                  int Ho, int Wo, int chunks_per_row, int total_chunks, int chunks_per_unit,
+                                                                  int ci_tiles) {
+    using C = WG<2>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int kd = wave / 3, kh = wave - 3 * kd;
+    const int c_begin = blockIdx.x * chunks_per_unit, c_end = min(c_begin + chunks_per_unit, total_chunks);
+    const int co0 = (blockIdx.y / ci_tiles) * 32, ci0 = (blockIdx.y % ci_tiles) * 32;
+    const int b = blockIdx.z;
+    unsigned char* tile = lds_raw + wave * C::TILE;
+    unsigned char* abuf = lds_raw + 9 * C::TILE;
+
+    const long long ochan = (long long)Do * Ho * Wo, ichan = (long long)D * H * W;
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(gout + (long long)b * Cout * ochan), 0, (int)min((long long)Cout * ochan * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in + (long long)b * Cin * ichan), 0, (int)min((long long)Cin * ichan * 4, 0x7fffffffLL), 0x00020000);
+    const int q = lane & 15, csub = lane >> 4;             // staging: lane = (position pair q, channel 4 i + csub)
+    const int frag_base = l31 * C::RS;
+    const int ca = co0 + 4 * wave + csub;                  // the gout channel this lane stages (waves 0-7)
+    const unsigned a_chan = (wave < 8 && ca < Cout) ? (unsigned)(ca * ochan * 4) : 0x80000000u;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float rin[8 * C::NLD], rhalo = 0.f, ra[2] = {0.f, 0.f};
+    auto issue_in = [&](int id, int ih, int w0) {
+        const unsigned row_b = (unsigned)((((long long)id * H + ih) * W) * 4);
+        const int iw0 = (w0 + 2 * q) * 2;                  // first input column of this lane's pair
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = ci0 + 4 * i + csub;
+            const unsigned ch = (c < Cin) ? (unsigned)(c * ichan * 4) : 0x80000000u;
+#pragma unroll
+            for (int e = 0; e < C::NLD; ++e)
+                rin[i * C::NLD + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ires, (int)(ch + (unsigned)((iw0 + e) * 4)), (int)row_b, 0));
+        }
+        const int hw = 2 * w0 - 1;                          // halo: column 2 w0 - 1 of channel l31 (lanes 0-31)
+        const bool hok = (ci0 + l31 < Cin) && hw >= 0 && hw < W && half == 0;
+        rhalo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              ires, (int)(hok ? (unsigned)((ci0 + l31) * ichan * 4) + (unsigned)(hw * 4) : 0x80000000u), (int)row_b, 0));
+    };
+    auto store_in = [&](int w0, auto whole_tag) {
+        constexpr bool WHOLE = decltype(whole_tag)::value;
+        const int iw0 = (w0 + 2 * q) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v[C::NLD];
+#pragma unroll
+            for (int e = 0; e < C::NLD; ++e) v[e] = (WHOLE || iw0 + e < W) ? rin[i * C::NLD + e] : 0.f;
+            const int c = 4 * i + csub;
+            unsigned h, m, l;
+            split3_pk_w(v[0], v[2], h, m, l);              // even columns: E[j], E[j + 1]
+            unsigned char* p = tile + c * C::RS + 4 * q;
+            *reinterpret_cast<unsigned*>(p) = h;
+            *reinterpret_cast<unsigned*>(p + C::PLANE) = m;
+            *reinterpret_cast<unsigned*>(p + 2 * C::PLANE) = l;
+            split3_pk_w(v[1], v[3], h, m, l);              // odd columns: O[j], O[j + 1]
+            p = tile + 3 * C::PLANE + c * C::RS + 16 + 4 * q;
+            *reinterpret_cast<unsigned*>(p) = h;
+            *reinterpret_cast<unsigned*>(p + C::PLANE) = m;
+            *reinterpret_cast<unsigned*>(p + 2 * C::PLANE) = l;
+        }
+        if (half == 0) {
+            unsigned h, m, l;
+            split3_pk_w(rhalo, 0.f, h, m, l);
+            unsigned char* p = tile + 3 * C::PLANE + l31 * C::RS + 14;
+            *reinterpret_cast<unsigned short*>(p) = (unsigned short)h;
+            *reinterpret_cast<unsigned short*>(p + C::PLANE) = (unsigned short)m;
+            *reinterpret_cast<unsigned short*>(p + 2 * C::PLANE) = (unsigned short)l;
+        }
+    };
+    auto rd128 = [&](int off) { return *reinterpret_cast<const uint4*>(tile + off); };
+    auto rd32 = [&](int off) { return *reinterpret_cast<const unsigned*>(tile + off); };
+    auto where = [&](int c, int& od, int& oh, int& w0) {
+        const int row = c / chunks_per_row;
+        od = row / Ho; oh = row - od * Ho; w0 = (c - row * chunks_per_row) * CW;
+    };
+    auto issue = [&](int c) {                               // the loads of chunk c: this wave's input row (if it exists), its share of gout
+        int od, oh, w0;
+        where(c, od, oh, w0);
+        const int id = 2 * od + kd - 1, ih = 2 * oh + kh - 1;
+        if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H) issue_in(id, ih, w0);
+        const unsigned a_row = (unsigned)((((long long)od * Ho + oh) * Wo + w0) * 4);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            ra[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gres, (int)(a_chan + (unsigned)((2 * q + e) * 4)), (int)a_row, 0));
+    };
+
+    if (c_begin < c_end) issue(c_begin);
+    int par = 0;
+    for (int c = c_begin; c < c_end; ++c, par ^= 1) {
+        int od, oh, w0;
+        where(c, od, oh, w0);
+        const bool mine = (unsigned)(2 * od + kd - 1) < (unsigned)D && (unsigned)(2 * oh + kh - 1) < (unsigned)H;      // (wave-uniform)
+        const bool whole = w0 + CW <= Wo && (w0 + CW) * 2 + 1 <= W;
+        if (mine) {
+            if (whole) store_in(w0, std::true_type{});
+            else store_in(w0, std::false_type{});
+        }
+        if (wave < 8) {
+            const float v0 = (whole || w0 + 2 * q < Wo) ? ra[0] : 0.f, v1 = (whole || w0 + 2 * q + 1 < Wo) ? ra[1] : 0.f;
+            unsigned h, m, l;
+            split3_pk_w(v0, v1, h, m, l);
+            unsigned char* p = abuf + par * CO_ATILE + (4 * wave + csub) * CO_RSA + 4 * q;
+            *reinterpret_cast<unsigned*>(p) = h;
+            *reinterpret_cast<unsigned*>(p + 32 * CO_RSA) = m;
+            *reinterpret_cast<unsigned*>(p + 64 * CO_RSA) = l;
+        }
+        __syncthreads();
+        if (c + 1 < c_end) issue(c + 1);                    // the next chunk's loads fly under this chunk's MFMAs
+        if (mine) {
+            const unsigned char* at = abuf + par * CO_ATILE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 af[3], bfr[3][3];
+                const int offa = l31 * CO_RSA + 16 * (2 * s + half);
+                const int offe = frag_base + 16 * (2 * s + half), offo = 3 * C::PLANE + frag_base + 16 * (1 + 2 * s + half);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    af[t] = *reinterpret_cast<const uint4*>(at + t * 32 * CO_RSA + offa);
+                    const uint4 xe = rd128(t * C::PLANE + offe), xo = rd128(t * C::PLANE + offo);
+                    const unsigned pl = rd32(t * C::PLANE + offo - 4);
+                    bfr[0][t] = make_uint4(__builtin_amdgcn_alignbit(xo.x, pl, 16), __builtin_amdgcn_alignbit(xo.y, xo.x, 16),
+                                           __builtin_amdgcn_alignbit(xo.z, xo.y, 16), __builtin_amdgcn_alignbit(xo.w, xo.z, 16));
+                    bfr[1][t] = xe;
+                    bfr[2][t] = xo;
+                }
+                constexpr int pa[6] = {1, 0, 2, 0, 1, 0}, pb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[pa[p]]), __builtin_bit_cast(bf16x8, bfr[kw][pb[p]]),
+                                                                          acc[kw], 0, 0, 0);
+            }
+        }
+    }
+    float* wt = ws + ((long long)blockIdx.y * 27 + kd * 9 + kh * 3) * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
+}
+
 // ---- a single output channel (the classifiers' 32 -> 1 heads, models/SemStereo.py:228-234): dW[ci, tap] = sum_p' x[ci, p'] * g[p' - tap + 1].
 // With Cout = 1 the tile forms above spend 27 accumulator tiles on one live matrix row each (the head's weight gradient cost what a
 // 32 -> 32 layer's costs, 0.48 ms at [24,256,256]).  Here the 27 TAPS are the MFMA's N columns: A = x (lane = input channel, 8
@@ -611,7 +772,10 @@ extern "C" int ss_conv3d_wgrad_bf16s_fwd(const float* grad_out, const float* in,
         auto kern = conv3d_wgrad_bf16s_coop;
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), CO_LDS) != SS_OK) return SS_ERR_LAUNCH;
         const long long cols = (long long)Do * chunks_per_row;
-        int nseg_c = (int)std::min<long long>(std::max<long long>(1, 768 / std::max<long long>(1, cols * tiles * B)), std::max(1, Ho / 8));
+#ifndef SS_COOP_WGS
+#define SS_COOP_WGS 768
+#endif
+        int nseg_c = (int)std::min<long long>(std::max<long long>(1, SS_COOP_WGS / std::max<long long>(1, cols * tiles * B)), std::max(1, Ho / 8));
         const int seg_len = ss::ceil_div(Ho, nseg_c);
         nseg_c = ss::ceil_div(Ho, seg_len);
         if (cols * nseg_c > 0x7fffffffLL) return SS_ERR_UNSUPPORTED;
@@ -621,6 +785,19 @@ extern "C" int ss_conv3d_wgrad_bf16s_fwd(const float* grad_out, const float* in,
         auto kern = conv3d_wgrad_bf16s<1>;
         hipLaunchKernelGGL(kern, grid, dim3(192), 3 * WG<1>::TILE, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
                            total, per_unit, nsplit, ci_tiles);
+    } else if (ss::tuning().wgrad_coop != 0) {
+        // stride 2 with the gout chunk shared: a workgroup = the nine kernel rows of a chunk range; ONE workgroup per CU's worth of ranges (each
+        // ends with 27 648 atomics into the workspace: 768 ranges 234 us, 256 ranges 203, 3072 ranges 368 on hourglass.conv1's layer)
+        auto kern = conv3d_wgrad_bf16s_s2a;
+        if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), S2A_LDS) != SS_OK) return SS_ERR_LAUNCH;
+#ifndef SS_S2A_WGS
+#define SS_S2A_WGS 256
+#endif
+        int ns = std::max(1, SS_S2A_WGS / (tiles * B));
+        int pu = std::max(chunks_per_row >= 4 ? 4 : 1, ss::ceil_div(total, ns));
+        ns = ss::ceil_div(total, pu);
+        hipLaunchKernelGGL(kern, dim3(ns, tiles, B), dim3(576), S2A_LDS, st, grad_out, in, workspace, Cin, Cout, D, H, W, Do, Ho, Wo, chunks_per_row,
+                           total, pu, ci_tiles);
     } else {
         auto kern = conv3d_wgrad_bf16s<2>;
         if (ss::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 3 * WG<2>::TILE) != SS_OK) return SS_ERR_LAUNCH;
