@@ -454,7 +454,11 @@ __global__ __launch_bounds__(576, 1) void conv3d_wgrad_bf16s_coop(const float* _
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
+#ifdef SS_EXP_COOP_NOATOM                                   // (timing-only ablation: wrong results)
+        for (int r = 0; r < 16; ++r) wt[(t * 16 + r) * 64] = acc[t][r];
+#else
         for (int r = 0; r < 16; ++r) unsafeAtomicAdd(wt + (t * 16 + r) * 64, acc[t][r]);
+#endif
 }
 
 // ---- stride 2 with the gout chunk SHARED (r06, last): the per-wave form above is bound by its global loads (271 us as is, 135 without
