@@ -480,7 +480,14 @@ __global__ __launch_bounds__(576, 1) void conv3d_wgrad_bf16s_s2a(const float* __
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int kd = wave / 3, kh = wave - 3 * kd;
-    const int c_begin = blockIdx.x * chunks_per_unit, c_end = min(c_begin + chunks_per_unit, total_chunks);
+#ifdef SS_S2A_XCD
+    // consecutive chunk ranges (neighbouring depth planes: they read the same input planes) on the SAME XCD, i.e. behind one L2:
+    // workgroups go round-robin over the 8 XCDs, so XCD x takes the contiguous x-th eighth of the ranges
+    const int unit = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+#else
+    const int unit = blockIdx.x;
+#endif
+    const int c_begin = unit * chunks_per_unit, c_end = min(c_begin + chunks_per_unit, total_chunks);
     const int co0 = (blockIdx.y / ci_tiles) * 32, ci0 = (blockIdx.y % ci_tiles) * 32;
     const int b = blockIdx.z;
     unsigned char* tile = lds_raw + wave * C::TILE;
